@@ -1,0 +1,109 @@
+"""ctypes binding of libgypsum_hip.so (include/gypsum_hip.h).  Fails loudly if the library is missing."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libgypsum_hip.so"
+
+GYP_OK = 0
+GYP_E_BAD_ARG, GYP_E_BAD_RATE, GYP_E_NO_DEVICE, GYP_E_HIP, GYP_E_NO_FORMAT, GYP_E_NOMEM = -1, -2, -3, -4, -5, -6
+GYP_COHERENT, GYP_NON_COHERENT = 0, 1
+
+# numpy mirrors of the C records (layouts asserted against the header in tests/test_abi.py)
+CELL_DESC = np.dtype([("stream", "<i4"), ("sat_id", "<i4"), ("doppler_hz", "<f8"), ("tap_index", "<i4"),
+                      ("reserved", "<i4")], align=True)
+CELL = np.dtype([("peak", "<f4"), ("argmax", "<i4"), ("sum", "<f8"), ("n_max", "<i4"), ("reserved", "<i4"),
+                 ("tap_re", "<f4"), ("tap_im", "<f4")], align=True)
+ACQ_RESULT = np.dtype([("stream", "<i4"), ("sat_id", "<i4"), ("doppler_hz", "<i4"), ("code_phase", "<i4"),
+                       ("carrier_phase", "<f8"), ("strength", "<f8")], align=True)
+CHAN_IN = np.dtype([("stream", "<i4"), ("sat_id", "<i4"), ("doppler_hz", "<f8"), ("carrier_phase", "<f8"),
+                    ("code_phase", "<i4"), ("reserved", "<i4")], align=True)
+CHAN_OUT = np.dtype([("early_re", "<f4"), ("early_im", "<f4"), ("late_re", "<f4"), ("late_im", "<f4"),
+                     ("peak_re", "<f4"), ("peak_im", "<f4"), ("peak_mag", "<f4"), ("peak_offset", "<i4"),
+                     ("sum", "<f8"), ("n_max", "<i4"), ("reserved", "<i4")], align=True)
+CHAN_INIT = CHAN_IN
+TRACK_REC = np.dtype([("peak_re", "<f4"), ("peak_im", "<f4"), ("strength", "<f4"), ("discriminator", "<f4"),
+                      ("doppler_hz", "<f8"), ("carrier_phase", "<f8"), ("error", "<f8"), ("code_phase", "<i4"),
+                      ("peak_offset", "<i4"), ("pseudosymbol", "i1"), ("locked", "i1"), ("status", "i1"),
+                      ("nudged", "i1"), ("reserved", "<i4")], align=True)
+RECORD_SIZES = {"gyp_cell_desc": 24, "gyp_cell": 32, "gyp_acq_result": 32, "gyp_chan_in": 32, "gyp_chan_out": 48,
+                "gyp_track_rec": 56}
+
+EXPORTS = (
+    "gyp_version gyp_create gyp_destroy gyp_last_error gyp_device_name gyp_set_stream gyp_sync gyp_timer_start "
+    "gyp_timer_stop gyp_set_stream_format gyp_prn_chips gyp_prn_spectrum_lane_layout gyp_malloc gyp_free "
+    "gyp_memcpy_h2d gyp_memcpy_d2h gyp_cell_strength gyp_correlate_cells_dev gyp_correlate_cells gyp_acquire_dev "
+    "gyp_acquire gyp_track_step_dev gyp_track_step gyp_bank_create gyp_bank_destroy gyp_bank_size "
+    "gyp_track_block_dev gyp_track_block gyp_bank_get_state"
+).split()
+
+
+class GypsumHipError(RuntimeError):
+    def __init__(self, code: int, message: str) -> None:
+        super().__init__(f"libgypsum_hip error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library.  There is deliberately no fallback of any kind."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m gypsum_amd.build` (hipcc --offload-arch=gfx950). "
+            "gypsum_amd has no CPU or PyTorch fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    vp, i32, i64, u64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
+    sig = {
+        "gyp_version": (C.c_int, []),
+        "gyp_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "gyp_destroy": (None, [vp]),
+        "gyp_last_error": (C.c_char_p, [vp]),
+        "gyp_device_name": (C.c_int, [vp, C.c_char_p, C.c_int]),
+        "gyp_set_stream": (C.c_int, [vp, vp]),
+        "gyp_sync": (C.c_int, [vp]),
+        "gyp_timer_start": (C.c_int, [vp]),
+        "gyp_timer_stop": (C.c_int, [vp, C.POINTER(C.c_float)]),
+        "gyp_set_stream_format": (C.c_int, [vp, i64, i32]),
+        "gyp_prn_chips": (C.c_int, [vp]),
+        "gyp_prn_spectrum_lane_layout": (C.c_int, [C.c_int, vp]),
+        "gyp_malloc": (C.c_int, [vp, u64, C.POINTER(vp)]),
+        "gyp_free": (C.c_int, [vp, vp]),
+        "gyp_memcpy_h2d": (C.c_int, [vp, vp, vp, u64]),
+        "gyp_memcpy_d2h": (C.c_int, [vp, vp, vp, u64]),
+        "gyp_cell_strength": (dbl, [vp, i32]),
+        "gyp_correlate_cells_dev": (C.c_int, [vp, vp, i64, i32, vp, i32, i32, vp, vp]),
+        "gyp_correlate_cells": (C.c_int, [vp, vp, i32, i32, vp, i32, i32, vp, vp]),
+        "gyp_acquire_dev": (C.c_int, [vp, vp, i32, i64, i32, vp, i32, vp]),
+        "gyp_acquire": (C.c_int, [vp, vp, i32, i32, vp, i32, vp]),
+        "gyp_track_step_dev": (C.c_int, [vp, vp, i64, vp, vp, i32, vp, vp]),
+        "gyp_track_step": (C.c_int, [vp, vp, i32, vp, vp, i32, vp, vp]),
+        "gyp_bank_create": (C.c_int, [vp, vp, i32, C.POINTER(vp)]),
+        "gyp_bank_destroy": (None, [vp]),
+        "gyp_bank_size": (C.c_int, [vp]),
+        "gyp_track_block_dev": (C.c_int, [vp, vp, i64, i32, vp, vp]),
+        "gyp_track_block": (C.c_int, [vp, vp, i32, i32, vp, vp]),
+        "gyp_bank_get_state": (C.c_int, [vp, vp, vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)   # AttributeError here == the library does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(a) -> C.c_void_p:
+    """Raw pointer of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return C.c_void_p(None)
+    if not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("array must be C-contiguous")
+    return C.c_void_p(a.ctypes.data)

@@ -1,0 +1,118 @@
+"""Sample-provider interface (host mirror of `gypsum/antenna_sample_provider.py:20-136`).
+
+The ABC, `SampleProviderAttributes`, `AntennaSampleChunk` and `NoMoreSamplesError`
+keep the reference's names and semantics; `AntennaSampleProviderBackedByFile`
+reads the same GNU Radio interleaved-float32 format with the same timestamps
+(`round(cursor / fs, 6)`).  `AntennaSampleProviderBackedByArray` serves an
+in-memory complex64 array (synthetic IQ) with identical chunking, which is what the
+parity tests and the benchmark use since no recording is available offline.
+"""
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+from dataclasses import dataclass
+from pathlib import Path
+
+import numpy as np
+
+PRN_REPETITIONS_PER_SECOND = 1000
+
+
+class NoMoreSamplesError(Exception):
+    pass
+
+
+@dataclass
+class SampleProviderAttributes:
+    samples_per_second: int
+    samples_per_prn_transmission: int
+
+
+@dataclass
+class AntennaSampleChunk:
+    start_time: float
+    end_time: float
+    samples: np.ndarray
+
+
+class AntennaSampleProvider(ABC):
+    @abstractmethod
+    def get_samples(self, sample_count: int) -> AntennaSampleChunk: ...
+
+    @abstractmethod
+    def peek_samples(self, sample_count: int) -> AntennaSampleChunk: ...
+
+    @abstractmethod
+    def seconds_since_start(self) -> float: ...
+
+    @abstractmethod
+    def get_attributes(self) -> SampleProviderAttributes: ...
+
+
+class _CursorProvider(AntennaSampleProvider):
+    sample_rate: float
+    cursor: int
+    utc_start_time: float
+
+    def _elapsed(self, cursor: int) -> float:
+        return round(cursor / self.sample_rate, 6)
+
+    def seconds_since_start(self) -> float:
+        return self._elapsed(self.cursor)
+
+    def get_samples(self, sample_count: int) -> AntennaSampleChunk:
+        chunk = self.peek_samples(sample_count)
+        self.cursor += sample_count
+        return chunk
+
+    def get_attributes(self) -> SampleProviderAttributes:
+        return SampleProviderAttributes(
+            samples_per_second=int(self.sample_rate),
+            samples_per_prn_transmission=int(self.sample_rate // PRN_REPETITIONS_PER_SECOND),
+        )
+
+
+class AntennaSampleProviderBackedByFile(_CursorProvider):
+    """GNU Radio recording: interleaved float32 I/Q (antenna_sample_provider.py:79-136)."""
+
+    def __init__(self, path: Path | str, sample_rate: float, utc_start_time: float = 0.0,
+                 sample_component_data_type=np.float32) -> None:
+        self.path = Path(path)
+        self.cursor = 0
+        self.sample_rate = sample_rate
+        self.utc_start_time = utc_start_time
+        self.sample_component_data_type = sample_component_data_type
+        self.file_size_in_bytes = self.path.stat().st_size
+
+    def peek_samples(self, sample_count: int) -> AntennaSampleChunk:
+        word_bytes = np.dtype(self.sample_component_data_type).itemsize
+        start = self.cursor * 2 * word_bytes
+        end = start + sample_count * 2 * word_bytes
+        if end >= self.file_size_in_bytes:   # same (off-by-one-conservative) bound as the reference, :106
+            raise NoMoreSamplesError(f"Ran out of samples at {self.seconds_since_start():.2f}s")
+        words = np.fromfile(self.path.as_posix(), dtype=self.sample_component_data_type,
+                            count=sample_count * 2, offset=start)
+        return AntennaSampleChunk(
+            start_time=self.seconds_since_start(),
+            end_time=self._elapsed(self.cursor + sample_count),
+            samples=(words[0::2]) + (1j * words[1::2]),
+        )
+
+
+class AntennaSampleProviderBackedByArray(_CursorProvider):
+    """In-memory complex64 IQ with the file provider's chunk/timestamp semantics."""
+
+    def __init__(self, iq: np.ndarray, sample_rate: float, utc_start_time: float = 0.0) -> None:
+        self.iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        self.cursor = 0
+        self.sample_rate = sample_rate
+        self.utc_start_time = utc_start_time
+
+    def peek_samples(self, sample_count: int) -> AntennaSampleChunk:
+        if self.cursor + sample_count > len(self.iq):
+            raise NoMoreSamplesError(f"Ran out of samples at {self.seconds_since_start():.2f}s")
+        return AntennaSampleChunk(
+            start_time=self.seconds_since_start(),
+            end_time=self._elapsed(self.cursor + sample_count),
+            samples=self.iq[self.cursor:self.cursor + sample_count],
+        )

@@ -1,0 +1,275 @@
+// corr_core.hpp -- wavefront-level building blocks of the gfx950 correlator kernels.
+//
+// One 64-lane wavefront computes one 1023-lag circular correlation of a complex input y[0..1022] with a
+// +-1 C/A code, embedded in a 2048-point FFT (zero-padded input, periodically extended code).  The
+// 2048-point transform is split (radix-2, decimation in frequency) into two 1024-point transforms, one per
+// 32-lane half-wave; each 1024-point transform is 32 x 32: an in-register 32-point FFT per lane, a
+// twiddle multiply, a transpose through LDS, and a second in-register 32-point FFT.
+//
+// The zero padding makes the forward radix-2 stage a pure twiddle (a[n+1024] == 0), and only lags
+// 0..1023 of the inverse are needed, so the inverse radix-2 stage is one add per output.
+//
+// Layout (lane = 32*h + l): time index m = 32*reg + l; frequency bin f = 2*(l + 32*g2) + h with g2 held
+// at physical register bitrev5(g2); output lag q = l + 32*(j + 16*h) for j = 0..15 after the half-wave
+// combine.  tests/lane_model.py is the numpy statement of exactly this data flow.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gyp {
+
+constexpr int kChips = 1023;
+constexpr int kXchRow = 34;                  // padded row: 272 B keeps rows 16-B aligned and ds_read_b128 conflict-free
+constexpr int kXchHalf = 32 * kXchRow;       // padded 32x32 transpose tile (complex elements)
+constexpr int kXchWave = 2 * kXchHalf;       // both half-waves
+constexpr int kXchWaveBytes = kXchWave * 8;  // 17408 B per wavefront
+
+typedef float2 cf;
+
+__device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
+// a * b
+__device__ __forceinline__ cf cmul(cf a, cf b) {
+    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+// a * conj(b)
+__device__ __forceinline__ cf cmulc(cf a, cf b) {
+    return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
+}
+
+__host__ __device__ constexpr int bitrev5(int v) {
+    return ((v & 1) << 4) | ((v & 2) << 2) | (v & 4) | ((v & 8) >> 2) | ((v & 16) >> 4);
+}
+
+// cos/sin(2*pi*t/32), t = 0..15 (t is a compile-time constant after unrolling)
+__device__ __forceinline__ constexpr float cos32(int t) {
+    switch (t) {
+        case 0: return 1.0f;
+        case 1: return 0.98078528040323044913f;
+        case 2: return 0.92387953251128675613f;
+        case 3: return 0.83146961230254523708f;
+        case 4: return 0.70710678118654752440f;
+        case 5: return 0.55557023301960222474f;
+        case 6: return 0.38268343236508977173f;
+        case 7: return 0.19509032201612826785f;
+        case 8: return 0.0f;
+        case 9: return -0.19509032201612826785f;
+        case 10: return -0.38268343236508977173f;
+        case 11: return -0.55557023301960222474f;
+        case 12: return -0.70710678118654752440f;
+        case 13: return -0.83146961230254523708f;
+        case 14: return -0.92387953251128675613f;
+        default: return -0.98078528040323044913f;
+    }
+}
+__device__ __forceinline__ constexpr float sin32(int t) { return t <= 8 ? cos32(8 - t) : cos32(t - 8); }
+
+// v * exp(DIR * 2*pi*i * t / 32), DIR = -1 forward, +1 inverse
+template <int DIR>
+__device__ __forceinline__ cf twiddle32(cf v, int t) {
+    constexpr float h = 0.70710678118654752440f;
+    if (t == 0) return v;
+    if (t == 8) return DIR < 0 ? make_float2(v.y, -v.x) : make_float2(-v.y, v.x);
+    if (t == 4) return DIR < 0 ? make_float2((v.x + v.y) * h, (v.y - v.x) * h) : make_float2((v.x - v.y) * h, (v.x + v.y) * h);
+    if (t == 12) return DIR < 0 ? make_float2((v.y - v.x) * h, -(v.x + v.y) * h) : make_float2(-(v.x + v.y) * h, (v.x - v.y) * h);
+    const float c = cos32(t), s = sin32(t);
+    return DIR < 0 ? make_float2(fmaf(v.x, c, v.y * s), fmaf(v.y, c, -v.x * s))
+                   : make_float2(fmaf(v.x, c, -v.y * s), fmaf(v.y, c, v.x * s));
+}
+
+// 32-point DFT, decimation in frequency: natural-order input, X[k] lands in x[bitrev5(k)].
+template <int DIR>
+__device__ __forceinline__ void fft32_dif(cf (&x)[32]) {
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int half = 16 >> s;
+#pragma unroll
+        for (int g = 0; g < 32; g += 2 * half) {
+#pragma unroll
+            for (int j = 0; j < half; ++j) {
+                const cf a = x[g + j], b = x[g + j + half];
+                x[g + j] = cadd(a, b);
+                x[g + j + half] = twiddle32<DIR>(csub(a, b), j << s);
+            }
+        }
+    }
+}
+
+// 32-point DFT, decimation in time: input element k expected in x[bitrev5(k)], natural-order output.
+template <int DIR>
+__device__ __forceinline__ void fft32_dit(cf (&x)[32]) {
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int half = 1 << s;
+#pragma unroll
+        for (int g = 0; g < 32; g += 2 * half) {
+#pragma unroll
+            for (int j = 0; j < half; ++j) {
+                const cf a = x[g + j];
+                const cf b = twiddle32<DIR>(x[g + j + half], j << (4 - s));
+                x[g + j] = cadd(a, b);
+                x[g + j + half] = csub(a, b);
+            }
+        }
+    }
+}
+
+// All 64 lanes of this wavefront have issued their LDS writes; make them visible to the reads that follow.
+// LDS operations of one wavefront execute in order, so only the compiler needs restraining.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Lane l reads row l of the transpose tile: 16 x ds_read_b128 (two complex values each).
+__device__ __forceinline__ void read_transposed(cf (&x)[32], const cf* xch_half, int l) {
+    const float4* row = reinterpret_cast<const float4*>(xch_half + kXchRow * l);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float4 v = row[j];
+        x[2 * j] = make_float2(v.x, v.y);
+        x[2 * j + 1] = make_float2(v.z, v.w);
+    }
+}
+
+// LDS-resident tables shared by the wavefronts of a workgroup.
+struct LdsTables {
+    const cf* tw1024;  // [32][32]: exp(-2*pi*i * g*n / 1024)
+    const cf* tw2048;  // [1024]  : exp(-2*pi*i * n / 2048)
+};
+
+// Forward transform.  In: x[j] = y[32*j + l] (identical in both half-waves; y[1023] must be 0).
+// Out: physical register i holds bin f = 2*(l + 32*bitrev5(i)) + h.
+__device__ __forceinline__ void wave_fft_fwd(cf (&x)[32], cf* xch_half, const LdsTables& t, int l, int h) {
+    if (h) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) x[j] = cmul(x[j], t.tw2048[32 * j + l]);
+    }
+    fft32_dif<-1>(x);
+#pragma unroll
+    for (int g = 0; g < 32; ++g) {
+        cf v = x[bitrev5(g)];
+        if (g) v = cmul(v, t.tw1024[32 * g + l]);
+        xch_half[kXchRow * g + l] = v;
+    }
+    wave_lds_fence();
+    read_transposed(x, xch_half, l);
+    wave_lds_fence();
+    fft32_dif<-1>(x);
+}
+
+// Inverse transform (un-normalised; the 1/2048 lives in the PRN spectrum table) + half-wave combine.
+// In: physical register i holds bin f = 2*(l + 32*bitrev5(i)) + h.
+// Out: c[j], j = 0..15: lag q = l + 32*(j + 16*h).
+__device__ __forceinline__ void wave_fft_inv(cf (&x)[32], cf (&c)[16], cf* xch_half, const LdsTables& t, int l, int h) {
+    fft32_dit<+1>(x);
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        cf v = x[q];
+        if (q) v = cmulc(v, t.tw1024[32 * q + l]);
+        xch_half[kXchRow * q + l] = v;
+    }
+    wave_lds_fence();
+    read_transposed(x, xch_half, l);
+    wave_lds_fence();
+    fft32_dif<+1>(x);
+    // lag q = l + 32*qb sits in x[bitrev5(qb)]; the odd half carries exp(+2*pi*i*q/2048)
+    if (h) {
+#pragma unroll
+        for (int qb = 0; qb < 32; ++qb) x[bitrev5(qb)] = cmulc(x[bitrev5(qb)], t.tw2048[32 * qb + l]);
+    }
+    // c[q] = even[q] + odd[q].  Registers bitrev5(qb) and bitrev5(qb+16) = bitrev5(qb)+1 are swapped across the
+    // half-waves so the low half finishes qb = 0..15 and the high half qb = 16..31.
+#pragma unroll
+    for (int qb = 0; qb < 16; ++qb) {
+        const int p = bitrev5(qb);
+        auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[p].x), __float_as_uint(x[p + 1].x), false, false);
+        auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[p].y), __float_as_uint(x[p + 1].y), false, false);
+        c[qb] = make_float2(__uint_as_float(rx[0]) + __uint_as_float(rx[1]),
+                            __uint_as_float(ry[0]) + __uint_as_float(ry[1]));
+    }
+}
+
+// The per-satellite frequency-domain replica table is [32 sats][32 physical regs][64 lanes] complex.
+__device__ __forceinline__ const cf* replica_column(const cf* __restrict__ table, int sat_index, int lane) {
+    return table + (size_t)sat_index * 32 * 64 + lane;
+}
+// Multiply the spectrum held in registers by the replica (read through L1/L2: 32 coalesced 512-byte rows).
+__device__ __forceinline__ void spectrum_mul(cf (&x)[32], const cf* __restrict__ rep_column) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) x[i] = cmul(x[i], rep_column[64 * i]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// carrier NCO: exp(-2*pi*i * u), u in cycles, float64 range reduction then float32 sincos
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ cf carrier_from_cycles(double u) {
+    const double fr = u - rint(u);  // [-0.5, 0.5]: tiny per-sample increments keep their relative precision
+    float s, c;
+    sincospif(2.0f * (float)fr, &s, &c);
+    return make_float2(c, -s);
+}
+
+// Wipe-off + polyphase pre-sum for one chip index m of one millisecond block.
+//   y_r[m] = sum_{j<K} x[(K*m + r + j) mod N] * carrier(K*m + r + j mod N),   r = 0..K-1
+// block: the N = K*1023 samples of this millisecond; u0: carrier cycles at sample 0 of the block;
+// du: cycles per sample (f / fs); rot1 = exp(-2*pi*i*du); rot_wrap = exp(+2*pi*i*du*N) for samples that wrap.
+template <int K>
+__device__ __forceinline__ void stage_chip(const cf* __restrict__ block, int m, double u0, double du, cf rot1,
+                                           cf rot_wrap, cf* (&y_rows)[K]) {
+    constexpr int N = K * kChips;
+    constexpr int S = 2 * K - 1;
+    cf xs[S];
+    const int n0 = K * m;
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        int idx = n0 + i;
+        idx = idx >= N ? idx - N : idx;
+        xs[i] = block[idx];
+    }
+    cf car = carrier_from_cycles(u0 + du * (double)n0);
+    cf pre[S + 1];
+    pre[0] = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        cf cw = (n0 + i >= N) ? cmul(car, rot_wrap) : car;
+        pre[i + 1] = cadd(pre[i], cmul(xs[i], cw));
+        car = cmul(car, rot1);
+    }
+#pragma unroll
+    for (int r = 0; r < K; ++r) y_rows[r][m] = csub(pre[r + K], pre[r]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// reductions
+// ---------------------------------------------------------------------------------------------------------
+struct Best {
+    float v;
+    int key;  // tie-break: smaller key wins
+};
+__device__ __forceinline__ Best better(Best a, Best b) {
+    return (b.v > a.v || (b.v == a.v && b.key < a.key)) ? b : a;
+}
+__device__ __forceinline__ Best wave_best(Best b) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        Best o;
+        o.v = __shfl_xor(b.v, off);
+        o.key = __shfl_xor(b.key, off);
+        b = better(b, o);
+    }
+    return b;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+}  // namespace gyp

@@ -1,0 +1,633 @@
+// gypsum_hip.hip -- C ABI of libgypsum_hip.so (see include/gypsum_hip.h).  gfx950 / ROCm only.
+//
+// Host side: context, PRN code generation (integer LFSRs), float64 construction of the per-satellite
+// frequency-domain replicas and FFT twiddle tables, device buffers, kernel launches.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gypsum_hip.h"
+#include "kernels.hpp"
+
+using namespace gyp;
+
+// ---------------------------------------------------------------------------------------------------------
+// PRN codes (gps_ca_prn_codes.py:100-250): 10-stage G1/G2 registers as bit masks, stage i = bit i-1
+// ---------------------------------------------------------------------------------------------------------
+static const uint8_t kG2Taps[32][2] = {
+    {2, 6}, {3, 7}, {4, 8}, {5, 9}, {1, 9}, {2, 10}, {1, 8}, {2, 9}, {3, 10}, {2, 3}, {3, 4}, {5, 6}, {6, 7}, {7, 8},
+    {8, 9}, {9, 10}, {1, 4}, {2, 5}, {3, 6}, {4, 7}, {5, 8}, {6, 9}, {1, 3}, {4, 6}, {5, 7}, {6, 8}, {7, 9}, {8, 10},
+    {1, 6}, {2, 7}, {3, 8}, {4, 9}};
+static const uint16_t kFirstTenChipsOctal[32] = {
+    01440, 01620, 01710, 01744, 01133, 01455, 01131, 01454, 01626, 01504, 01642, 01750, 01764, 01772, 01775, 01776,
+    01156, 01467, 01633, 01715, 01746, 01763, 01063, 01706, 01743, 01761, 01770, 01774, 01127, 01453, 01625, 01712};
+
+static inline unsigned stage(unsigned reg, int i) { return (reg >> (i - 1)) & 1u; }
+
+static int make_prn_chips(uint8_t* out /*32*1023*/) {
+    unsigned g1 = 0x3FF, g2 = 0x3FF;
+    for (int c = 0; c < kChips; ++c) {
+        const unsigned o1 = stage(g1, 10);
+        for (int sv = 0; sv < 32; ++sv) out[sv * kChips + c] = (uint8_t)(o1 ^ stage(g2, kG2Taps[sv][0]) ^ stage(g2, kG2Taps[sv][1]));
+        const unsigned fb1 = stage(g1, 3) ^ stage(g1, 10);
+        const unsigned fb2 = stage(g2, 2) ^ stage(g2, 3) ^ stage(g2, 6) ^ stage(g2, 8) ^ stage(g2, 9) ^ stage(g2, 10);
+        g1 = ((g1 << 1) & 0x3FF) | fb1;
+        g2 = ((g2 << 1) & 0x3FF) | fb2;
+    }
+    for (int sv = 0; sv < 32; ++sv) {
+        unsigned head = 0;
+        for (int c = 0; c < 10; ++c) head = (head << 1) | out[sv * kChips + c];
+        if (head != kFirstTenChipsOctal[sv]) return GYP_E_BAD_ARG;
+    }
+    return GYP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// float64 host FFT (radix-2, in place) for the replica spectra
+// ---------------------------------------------------------------------------------------------------------
+typedef std::complex<double> cd;
+static void host_fft(std::vector<cd>& a) {
+    const size_t n = a.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const double ang = -2.0 * M_PI / (double)len;
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const cd w(std::cos(ang * (double)k), std::sin(ang * (double)k));
+                const cd u = a[i + k], v = a[i + k + len / 2] * w;
+                a[i + k] = u + v;
+                a[i + k + len / 2] = u - v;
+            }
+    }
+}
+
+// conj(FFT2048(periodic +-1 code)) / 2048 in the kernel's [physical reg][lane] layout:
+// physical register i of lane (h, l) holds bin f = 2*(l + 32*bitrev5(i)) + h.
+static void make_replica_lane_layout(const uint8_t* chips, float* out /*32*64*2*/) {
+    std::vector<cd> pp(2048, cd(0.0, 0.0));
+    for (int m = 0; m < kChips; ++m) pp[m] = chips[m] ? 1.0 : -1.0;
+    for (int j = 1; j < kChips; ++j) pp[2048 - j] = chips[kChips - j] ? 1.0 : -1.0;
+    host_fft(pp);
+    for (int i = 0; i < 32; ++i)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int l = lane & 31, h = lane >> 5;
+            const int f = 2 * (l + 32 * bitrev5(i)) + h;
+            const cd v = std::conj(pp[f]) / 2048.0;
+            out[(i * 64 + lane) * 2 + 0] = (float)v.real();
+            out[(i * 64 + lane) * 2 + 1] = (float)v.imag();
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------------------
+static thread_local std::string g_create_error;
+
+struct gyp_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int n_cus = 256;
+    std::string err;
+    // stream format
+    int64_t fs = 0;
+    int32_t n = 0;
+    int k = 0;
+    cf* d_replicas = nullptr;  // [32][32][64]
+    cf* d_tw = nullptr;        // tw1024[1024] ++ tw2048[1024]
+    // growable scratch for the host-buffer entry points and the acquisition driver
+    void* scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_cap[6] = {0, 0, 0, 0, 0, 0};
+};
+
+struct gyp_bank {
+    gyp_ctx* ctx = nullptr;
+    int n_chan = 0;
+    ChanState* d_states = nullptr;
+};
+
+static int fail(gyp_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+#define HIP_TRY(ctx, call)                                                                                   \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail(ctx, GYP_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+
+static int ensure_scratch(gyp_ctx* ctx, int slot, size_t bytes) {
+    if (ctx->scratch_cap[slot] >= bytes) return GYP_OK;
+    if (ctx->scratch[slot]) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(ctx->scratch[slot]));
+        ctx->scratch[slot] = nullptr;
+        ctx->scratch_cap[slot] = 0;
+    }
+    const size_t cap = bytes + bytes / 4 + 4096;
+    HIP_TRY(ctx, hipMalloc(&ctx->scratch[slot], cap));
+    ctx->scratch_cap[slot] = cap;
+    return GYP_OK;
+}
+
+extern "C" {
+
+int gyp_version(void) { return GYP_VERSION; }
+
+const char* gyp_last_error(const gyp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int gyp_create(int device_ordinal, gyp_ctx** out) {
+    if (!out) return fail(nullptr, GYP_E_BAD_ARG, "gyp_create: out is NULL");
+    *out = nullptr;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0)
+        return fail(nullptr, GYP_E_NO_DEVICE, std::string("no HIP device available (") + hipGetErrorString(e) +
+                                                  "); libgypsum_hip has no CPU fallback");
+    if (device_ordinal < 0 || device_ordinal >= n_dev) return fail(nullptr, GYP_E_BAD_ARG, "device ordinal out of range");
+    HIP_TRY(nullptr, hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device_ordinal));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, GYP_E_NO_DEVICE, std::string("libgypsum_hip is built for gfx950 only, found ") + prop.gcnArchName);
+    gyp_ctx* ctx = new gyp_ctx();
+    ctx->device = device_ordinal;
+    ctx->n_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, GYP_E_HIP, "stream/event creation failed");
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return GYP_OK;
+}
+
+void gyp_destroy(gyp_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 6; ++i)
+        if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    if (ctx->d_replicas) (void)hipFree(ctx->d_replicas);
+    if (ctx->d_tw) (void)hipFree(ctx->d_tw);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int gyp_device_name(gyp_ctx* ctx, char* out, int cap) {
+    if (!ctx || !out || cap <= 0) return GYP_E_BAD_ARG;
+    hipDeviceProp_t prop;
+    HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    std::snprintf(out, (size_t)cap, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return GYP_OK;
+}
+
+int gyp_set_stream(gyp_ctx* ctx, void* hip_stream) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return GYP_OK;
+}
+
+int gyp_sync(gyp_ctx* ctx) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GYP_OK;
+}
+
+int gyp_timer_start(gyp_ctx* ctx) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return GYP_OK;
+}
+
+int gyp_timer_stop(gyp_ctx* ctx, float* elapsed_ms) {
+    if (!ctx || !elapsed_ms) return GYP_E_BAD_ARG;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    HIP_TRY(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return GYP_OK;
+}
+
+int gyp_prn_chips(uint8_t* out_32x1023) {
+    if (!out_32x1023) return GYP_E_BAD_ARG;
+    return make_prn_chips(out_32x1023);
+}
+
+int gyp_prn_spectrum_lane_layout(int sat_id, float* out_32x64x2) {
+    if (sat_id < 1 || sat_id > 32 || !out_32x64x2) return GYP_E_BAD_ARG;
+    std::vector<uint8_t> chips(32 * kChips);
+    const int rc = make_prn_chips(chips.data());
+    if (rc != GYP_OK) return rc;
+    make_replica_lane_layout(chips.data() + (sat_id - 1) * kChips, out_32x64x2);
+    return GYP_OK;
+}
+
+int gyp_set_stream_format(gyp_ctx* ctx, int64_t fs_hz, int32_t samples_per_ms) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    if (fs_hz <= 0 || samples_per_ms <= 0 || fs_hz / 1000 != samples_per_ms || fs_hz % 1000 != 0)
+        return fail(ctx, GYP_E_BAD_RATE, "samples_per_ms must equal fs_hz / 1000");
+    if (samples_per_ms % kChips != 0)
+        return fail(ctx, GYP_E_BAD_RATE, "sample rate must be an integer multiple of 1.023 MHz (the replica is np.repeat(chips, N // 1023))");
+    const int k = samples_per_ms / kChips;
+    if (k != 1 && k != 2 && k != 4 && k != 8)
+        return fail(ctx, GYP_E_BAD_RATE, "supported rates this release: 1.023, 2.046, 4.092, 8.184 Msps");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_replicas) {
+        std::vector<uint8_t> chips(32 * kChips);
+        if (make_prn_chips(chips.data()) != GYP_OK) return fail(ctx, GYP_E_BAD_ARG, "PRN self-check against IS-GPS-200 markers failed");
+        std::vector<float> rep(32 * 32 * 64 * 2);
+        for (int sv = 0; sv < 32; ++sv) make_replica_lane_layout(chips.data() + sv * kChips, rep.data() + (size_t)sv * 32 * 64 * 2);
+        std::vector<float> tw(2048 * 2);
+        for (int g = 0; g < 32; ++g)
+            for (int n = 0; n < 32; ++n) {
+                const double a = -2.0 * M_PI * (double)(g * n) / 1024.0;
+                tw[(g * 32 + n) * 2 + 0] = (float)std::cos(a);
+                tw[(g * 32 + n) * 2 + 1] = (float)std::sin(a);
+            }
+        for (int n = 0; n < 1024; ++n) {
+            const double a = -2.0 * M_PI * (double)n / 2048.0;
+            tw[(1024 + n) * 2 + 0] = (float)std::cos(a);
+            tw[(1024 + n) * 2 + 1] = (float)std::sin(a);
+        }
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_replicas, rep.size() * sizeof(float)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tw, tw.size() * sizeof(float)));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_replicas, rep.data(), rep.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    ctx->fs = fs_hz;
+    ctx->n = samples_per_ms;
+    ctx->k = k;
+    return GYP_OK;
+}
+
+int gyp_malloc(gyp_ctx* ctx, uint64_t bytes, void** dptr) {
+    if (!ctx || !dptr) return GYP_E_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e != hipSuccess) return fail(ctx, GYP_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return GYP_OK;
+}
+
+int gyp_free(gyp_ctx* ctx, void* dptr) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    if (dptr) HIP_TRY(ctx, hipFree(dptr));
+    return GYP_OK;
+}
+
+int gyp_memcpy_h2d(gyp_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes) {
+    if (!ctx || (!dst_dev && bytes) || (!src_host && bytes)) return GYP_E_BAD_ARG;
+    HIP_TRY(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return GYP_OK;
+}
+
+int gyp_memcpy_d2h(gyp_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes) {
+    if (!ctx || (!dst_host && bytes) || (!src_dev && bytes)) return GYP_E_BAD_ARG;
+    HIP_TRY(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GYP_OK;
+}
+
+double gyp_cell_strength(const gyp_cell* c, int32_t samples_per_ms) {
+    const double pk = (double)c->peak;
+    return pk / ((c->sum - (double)c->n_max * pk) / (double)(samples_per_ms - c->n_max));
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// launches
+// ---------------------------------------------------------------------------------------------------------
+static int blocks_per_cu(int k) { return k >= 4 ? 1 : (k == 2 ? 3 : 4); }
+
+template <typename KernelT, typename ParamsT>
+static int launch_k(gyp_ctx* ctx, KernelT kernel, int k, int grid, const ParamsT& p, size_t lds) {
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * k), lds, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    return GYP_OK;
+}
+
+static int launch_cells(gyp_ctx* ctx, const CellsParams& p, int integration) {
+    const int grid = std::max(1, std::min(p.n_cells, ctx->n_cus * blocks_per_cu(ctx->k)));
+    const bool coh = integration == GYP_COHERENT;
+    switch (ctx->k) {
+        case 1: return coh ? launch_k(ctx, corr_cells_kernel<1, true>, 1, grid, p, lds_bytes<1>()) : launch_k(ctx, corr_cells_kernel<1, false>, 1, grid, p, lds_bytes<1>());
+        case 2: return coh ? launch_k(ctx, corr_cells_kernel<2, true>, 2, grid, p, lds_bytes<2>()) : launch_k(ctx, corr_cells_kernel<2, false>, 2, grid, p, lds_bytes<2>());
+        case 4: return coh ? launch_k(ctx, corr_cells_kernel<4, true>, 4, grid, p, lds_bytes<4>()) : launch_k(ctx, corr_cells_kernel<4, false>, 4, grid, p, lds_bytes<4>());
+        case 8: return coh ? launch_k(ctx, corr_cells_kernel<8, true>, 8, grid, p, lds_bytes<8>()) : launch_k(ctx, corr_cells_kernel<8, false>, 8, grid, p, lds_bytes<8>());
+    }
+    return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
+}
+
+static int launch_track_step(gyp_ctx* ctx, const TrackStepParams& p) {
+    const int grid = std::max(1, std::min(p.n_chan, ctx->n_cus * blocks_per_cu(ctx->k)));
+    switch (ctx->k) {
+        case 1: return launch_k(ctx, track_step_kernel<1>, 1, grid, p, lds_bytes<1>());
+        case 2: return launch_k(ctx, track_step_kernel<2>, 2, grid, p, lds_bytes<2>());
+        case 4: return launch_k(ctx, track_step_kernel<4>, 4, grid, p, lds_bytes<4>());
+        case 8: return launch_k(ctx, track_step_kernel<8>, 8, grid, p, lds_bytes<8>());
+    }
+    return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
+}
+
+static int launch_track_block(gyp_ctx* ctx, const TrackBlockParams& p) {
+    const int grid = p.n_chan;
+    switch (ctx->k) {
+        case 1: return launch_k(ctx, track_block_kernel<1>, 1, grid, p, lds_bytes<1>());
+        case 2: return launch_k(ctx, track_block_kernel<2>, 2, grid, p, lds_bytes<2>());
+        case 4: return launch_k(ctx, track_block_kernel<4>, 4, grid, p, lds_bytes<4>());
+        case 8: return launch_k(ctx, track_block_kernel<8>, 8, grid, p, lds_bytes<8>());
+    }
+    return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
+}
+
+extern "C" {
+
+// ---------------------------------------------------------------- correlation cells ----------------------
+int gyp_correlate_cells_dev(gyp_ctx* ctx, const float* iq_dev, int64_t stream_stride_samples, int32_t n_ms,
+                            const gyp_cell_desc* cells_dev, int32_t n_cells, int32_t integration,
+                            gyp_cell* out_dev, float* profile_out_dev) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    if (!ctx->k) return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
+    if (!iq_dev || !cells_dev || !out_dev || n_ms < 0 || n_cells < 0 || (integration != GYP_COHERENT && integration != GYP_NON_COHERENT))
+        return fail(ctx, GYP_E_BAD_ARG, "gyp_correlate_cells_dev: bad argument");
+    if (n_cells == 0) return GYP_OK;
+    CellsParams p;
+    p.iq = reinterpret_cast<const cf*>(iq_dev);
+    p.stream_stride = stream_stride_samples;
+    p.n_ms = n_ms;
+    p.cells = cells_dev;
+    p.n_cells = n_cells;
+    p.out = out_dev;
+    p.profile_out = profile_out_dev;
+    p.replica_table = ctx->d_replicas;
+    p.tw_tables = ctx->d_tw;
+    p.inv_fs = 1.0 / (double)ctx->fs;
+    return launch_cells(ctx, p, integration);
+}
+
+int gyp_correlate_cells(gyp_ctx* ctx, const float* iq_host, int32_t n_streams, int32_t n_ms,
+                        const gyp_cell_desc* cells_host, int32_t n_cells, int32_t integration,
+                        gyp_cell* out_host, float* profile_out_host) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    if (!ctx->k) return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
+    if (!iq_host || !cells_host || !out_host || n_streams <= 0 || n_ms < 0 || n_cells < 0)
+        return fail(ctx, GYP_E_BAD_ARG, "gyp_correlate_cells: bad argument");
+    for (int i = 0; i < n_cells; ++i)
+        if (cells_host[i].stream < 0 || cells_host[i].stream >= n_streams || cells_host[i].sat_id < 1 || cells_host[i].sat_id > 32 ||
+            cells_host[i].tap_index >= ctx->n)
+            return fail(ctx, GYP_E_BAD_ARG, "gyp_correlate_cells: cell descriptor out of range");
+    if (n_cells == 0) return GYP_OK;
+    const size_t iq_bytes = (size_t)n_streams * n_ms * ctx->n * 8;
+    int rc;
+    if ((rc = ensure_scratch(ctx, 0, iq_bytes ? iq_bytes : 8))) return rc;
+    if ((rc = ensure_scratch(ctx, 1, (size_t)n_cells * sizeof(gyp_cell_desc)))) return rc;
+    if ((rc = ensure_scratch(ctx, 2, (size_t)n_cells * sizeof(gyp_cell)))) return rc;
+    const size_t prof_bytes = (size_t)n_cells * ctx->n * (integration == GYP_COHERENT ? 8 : 4);
+    if (profile_out_host && (rc = ensure_scratch(ctx, 3, prof_bytes))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[0], iq_host, iq_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[1], cells_host, (size_t)n_cells * sizeof(gyp_cell_desc), hipMemcpyHostToDevice, ctx->stream));
+    rc = gyp_correlate_cells_dev(ctx, (const float*)ctx->scratch[0], (int64_t)n_ms * ctx->n, n_ms,
+                                 (const gyp_cell_desc*)ctx->scratch[1], n_cells, integration, (gyp_cell*)ctx->scratch[2],
+                                 profile_out_host ? (float*)ctx->scratch[3] : nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out_host, ctx->scratch[2], (size_t)n_cells * sizeof(gyp_cell), hipMemcpyDeviceToHost, ctx->stream));
+    if (profile_out_host)
+        HIP_TRY(ctx, hipMemcpyAsync(profile_out_host, ctx->scratch[3], prof_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GYP_OK;
+}
+
+// ---------------------------------------------------------------- acquisition ----------------------------
+int gyp_acquire_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_t stream_stride_samples,
+                    int32_t n_ms, const int32_t* sat_ids_host, int32_t n_sats, gyp_acq_result* out_dev) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    if (!ctx->k) return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
+    if (!iq_dev || !sat_ids_host || !out_dev || n_streams <= 0 || n_sats <= 0 || n_ms <= 0)
+        return fail(ctx, GYP_E_BAD_ARG, "gyp_acquire_dev: bad argument");
+    for (int i = 0; i < n_sats; ++i)
+        if (sat_ids_host[i] < 1 || sat_ids_host[i] > 32) return fail(ctx, GYP_E_BAD_ARG, "satellite id out of range");
+    const int n_states = n_streams * n_sats;
+    std::vector<AcqSearchState> init((size_t)n_states);
+    for (int s = 0; s < n_streams; ++s)
+        for (int i = 0; i < n_sats; ++i) {
+            AcqSearchState& a = init[(size_t)s * n_sats + i];
+            std::memset(&a, 0, sizeof(a));
+            a.stream = s;
+            a.sat_id = sat_ids_host[i];
+            a.center = 0.0;       // acquisition.py:78
+            a.spread = 7000.0;    // acquisition.py:79
+        }
+    int rc;
+    const size_t n_cells = (size_t)n_states * kMaxBins;
+    if ((rc = ensure_scratch(ctx, 4, (size_t)n_states * sizeof(AcqSearchState)))) return rc;
+    if ((rc = ensure_scratch(ctx, 1, n_cells * sizeof(gyp_cell_desc)))) return rc;
+    if ((rc = ensure_scratch(ctx, 2, n_cells * sizeof(gyp_cell)))) return rc;
+    AcqSearchState* d_states = (AcqSearchState*)ctx->scratch[4];
+    gyp_cell_desc* d_cells = (gyp_cell_desc*)ctx->scratch[1];
+    gyp_cell* d_out = (gyp_cell*)ctx->scratch[2];
+    // the descriptors of a previous host-form call may still be in flight on this stream: ordering is by stream
+    HIP_TRY(ctx, hipMemcpyAsync(d_states, init.data(), init.size() * sizeof(AcqSearchState), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `init` is a local
+    const int tpb = 64, nblk = (n_states + tpb - 1) / tpb;
+    for (double spread = 7000.0; spread >= 10.0; spread /= 2.0) {  // acquisition.py:81,89
+        hipLaunchKernelGGL(acq_plan_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_cells);
+        rc = gyp_correlate_cells_dev(ctx, iq_dev, stream_stride_samples, n_ms, d_cells, (int32_t)n_cells, GYP_NON_COHERENT, d_out, nullptr);
+        if (rc) return rc;
+        hipLaunchKernelGGL(acq_reduce_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_out, ctx->n);
+    }
+    hipLaunchKernelGGL(acq_plan_coherent_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_cells);
+    rc = gyp_correlate_cells_dev(ctx, iq_dev, stream_stride_samples, n_ms, d_cells, n_states, GYP_COHERENT, d_out, nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(acq_finish_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_out, out_dev);
+    HIP_TRY(ctx, hipGetLastError());
+    return GYP_OK;
+}
+
+int gyp_acquire(gyp_ctx* ctx, const float* iq_host, int32_t n_streams, int32_t n_ms, const int32_t* sat_ids_host,
+                int32_t n_sats, gyp_acq_result* out_host) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    if (!ctx->k) return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
+    if (!iq_host || !out_host || n_streams <= 0 || n_ms <= 0 || n_sats <= 0) return fail(ctx, GYP_E_BAD_ARG, "gyp_acquire: bad argument");
+    const size_t iq_bytes = (size_t)n_streams * n_ms * ctx->n * 8;
+    const size_t out_bytes = (size_t)n_streams * n_sats * sizeof(gyp_acq_result);
+    int rc;
+    if ((rc = ensure_scratch(ctx, 0, iq_bytes))) return rc;
+    if ((rc = ensure_scratch(ctx, 5, out_bytes))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[0], iq_host, iq_bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = gyp_acquire_dev(ctx, (const float*)ctx->scratch[0], n_streams, (int64_t)n_ms * ctx->n, n_ms, sat_ids_host, n_sats,
+                         (gyp_acq_result*)ctx->scratch[5]);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out_host, ctx->scratch[5], out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GYP_OK;
+}
+
+// ---------------------------------------------------------------- tracking: explicit millisecond ----------
+int gyp_track_step_dev(gyp_ctx* ctx, const float* iq_dev, int64_t stream_stride_samples, const double* start_time_dev,
+                       const gyp_chan_in* chans_dev, int32_t n_chan, gyp_chan_out* out_dev, float* profile_out_dev) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    if (!ctx->k) return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
+    if (!iq_dev || !start_time_dev || !chans_dev || !out_dev || n_chan < 0) return fail(ctx, GYP_E_BAD_ARG, "gyp_track_step_dev: bad argument");
+    if (n_chan == 0) return GYP_OK;
+    TrackStepParams p;
+    p.iq = reinterpret_cast<const cf*>(iq_dev);
+    p.stream_stride = stream_stride_samples;
+    p.start_time = start_time_dev;
+    p.chans = chans_dev;
+    p.n_chan = n_chan;
+    p.out = out_dev;
+    p.profile_out = profile_out_dev;
+    p.replica_table = ctx->d_replicas;
+    p.tw_tables = ctx->d_tw;
+    p.inv_fs = 1.0 / (double)ctx->fs;
+    return launch_track_step(ctx, p);
+}
+
+int gyp_track_step(gyp_ctx* ctx, const float* iq_host, int32_t n_streams, const double* start_time_host,
+                   const gyp_chan_in* chans_host, int32_t n_chan, gyp_chan_out* out_host, float* profile_out_host) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    if (!ctx->k) return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
+    if (!iq_host || !start_time_host || !chans_host || !out_host || n_streams <= 0 || n_chan < 0)
+        return fail(ctx, GYP_E_BAD_ARG, "gyp_track_step: bad argument");
+    for (int i = 0; i < n_chan; ++i)
+        if (chans_host[i].stream < 0 || chans_host[i].stream >= n_streams || chans_host[i].sat_id < 1 || chans_host[i].sat_id > 32)
+            return fail(ctx, GYP_E_BAD_ARG, "gyp_track_step: channel descriptor out of range");
+    if (n_chan == 0) return GYP_OK;
+    const size_t iq_bytes = (size_t)n_streams * ctx->n * 8;
+    int rc;
+    if ((rc = ensure_scratch(ctx, 0, iq_bytes))) return rc;
+    if ((rc = ensure_scratch(ctx, 1, (size_t)n_chan * sizeof(gyp_chan_in)))) return rc;
+    if ((rc = ensure_scratch(ctx, 2, (size_t)n_chan * sizeof(gyp_chan_out)))) return rc;
+    if ((rc = ensure_scratch(ctx, 4, (size_t)n_streams * sizeof(double)))) return rc;
+    if (profile_out_host && (rc = ensure_scratch(ctx, 3, (size_t)n_chan * ctx->n * 4))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[0], iq_host, iq_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[1], chans_host, (size_t)n_chan * sizeof(gyp_chan_in), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[4], start_time_host, (size_t)n_streams * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = gyp_track_step_dev(ctx, (const float*)ctx->scratch[0], ctx->n, (const double*)ctx->scratch[4], (const gyp_chan_in*)ctx->scratch[1],
+                            n_chan, (gyp_chan_out*)ctx->scratch[2], profile_out_host ? (float*)ctx->scratch[3] : nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out_host, ctx->scratch[2], (size_t)n_chan * sizeof(gyp_chan_out), hipMemcpyDeviceToHost, ctx->stream));
+    if (profile_out_host)
+        HIP_TRY(ctx, hipMemcpyAsync(profile_out_host, ctx->scratch[3], (size_t)n_chan * ctx->n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GYP_OK;
+}
+
+// ---------------------------------------------------------------- tracking: device-resident loops --------
+int gyp_bank_create(gyp_ctx* ctx, const gyp_chan_init* chans_host, int32_t n_chan, gyp_bank** out) {
+    if (!ctx || !out) return GYP_E_BAD_ARG;
+    *out = nullptr;
+    if (!ctx->k) return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
+    if (!chans_host || n_chan <= 0) return fail(ctx, GYP_E_BAD_ARG, "gyp_bank_create: bad argument");
+    std::vector<ChanState> init((size_t)n_chan);
+    for (int i = 0; i < n_chan; ++i) {
+        if (chans_host[i].stream < 0 || chans_host[i].sat_id < 1 || chans_host[i].sat_id > 32)
+            return fail(ctx, GYP_E_BAD_ARG, "gyp_bank_create: channel descriptor out of range");
+        ChanState& s = init[i];
+        std::memset(&s, 0, sizeof(s));
+        s.stream = chans_host[i].stream;
+        s.sat_id = chans_host[i].sat_id;
+        s.doppler = chans_host[i].doppler_hz;
+        s.carrier_phase = chans_host[i].carrier_phase;
+        s.code_phase = chans_host[i].code_phase;
+        s.dll_phase = (double)chans_host[i].code_phase;  // tracker.py:224
+    }
+    gyp_bank* b = new gyp_bank();
+    b->ctx = ctx;
+    b->n_chan = n_chan;
+    hipError_t e = hipMalloc((void**)&b->d_states, init.size() * sizeof(ChanState));
+    if (e == hipSuccess) e = hipMemcpy(b->d_states, init.data(), init.size() * sizeof(ChanState), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (b->d_states) (void)hipFree(b->d_states);
+        delete b;
+        return fail(ctx, GYP_E_HIP, std::string("gyp_bank_create: ") + hipGetErrorString(e));
+    }
+    *out = b;
+    return GYP_OK;
+}
+
+void gyp_bank_destroy(gyp_bank* bank) {
+    if (!bank) return;
+    (void)hipStreamSynchronize(bank->ctx->stream);
+    if (bank->d_states) (void)hipFree(bank->d_states);
+    delete bank;
+}
+
+int gyp_bank_size(const gyp_bank* bank) { return bank ? bank->n_chan : GYP_E_BAD_ARG; }
+
+int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stride_samples, int32_t n_ms,
+                        const double* start_time_dev, gyp_track_rec* rec_out_dev) {
+    if (!bank) return GYP_E_BAD_ARG;
+    gyp_ctx* ctx = bank->ctx;
+    if (!iq_dev || !start_time_dev || n_ms < 0) return fail(ctx, GYP_E_BAD_ARG, "gyp_track_block_dev: bad argument");
+    if (n_ms == 0) return GYP_OK;
+    TrackBlockParams p;
+    p.iq = reinterpret_cast<const cf*>(iq_dev);
+    p.stream_stride = stream_stride_samples;
+    p.n_ms = n_ms;
+    p.start_time = start_time_dev;
+    p.states = bank->d_states;
+    p.n_chan = bank->n_chan;
+    p.rec_out = rec_out_dev;
+    p.replica_table = ctx->d_replicas;
+    p.tw_tables = ctx->d_tw;
+    p.inv_fs = 1.0 / (double)ctx->fs;
+    p.fs = (double)ctx->fs;
+    return launch_track_block(ctx, p);
+}
+
+int gyp_track_block(gyp_bank* bank, const float* iq_host, int32_t n_streams, int32_t n_ms, const double* start_time_host,
+                    gyp_track_rec* rec_out_host) {
+    if (!bank) return GYP_E_BAD_ARG;
+    gyp_ctx* ctx = bank->ctx;
+    if (!iq_host || !start_time_host || n_streams <= 0 || n_ms < 0) return fail(ctx, GYP_E_BAD_ARG, "gyp_track_block: bad argument");
+    if (n_ms == 0) return GYP_OK;
+    const size_t iq_bytes = (size_t)n_streams * n_ms * ctx->n * 8;
+    const size_t rec_bytes = (size_t)bank->n_chan * n_ms * sizeof(gyp_track_rec);
+    int rc;
+    if ((rc = ensure_scratch(ctx, 0, iq_bytes))) return rc;
+    if ((rc = ensure_scratch(ctx, 4, (size_t)n_ms * sizeof(double)))) return rc;
+    if (rec_out_host && (rc = ensure_scratch(ctx, 5, rec_bytes))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[0], iq_host, iq_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[4], start_time_host, (size_t)n_ms * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = gyp_track_block_dev(bank, (const float*)ctx->scratch[0], (int64_t)n_ms * ctx->n, n_ms, (const double*)ctx->scratch[4],
+                             rec_out_host ? (gyp_track_rec*)ctx->scratch[5] : nullptr);
+    if (rc) return rc;
+    if (rec_out_host) HIP_TRY(ctx, hipMemcpyAsync(rec_out_host, ctx->scratch[5], rec_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GYP_OK;
+}
+
+int gyp_bank_get_state(gyp_bank* bank, double* doppler_hz, double* carrier_phase, int32_t* code_phase, int32_t* lost) {
+    if (!bank) return GYP_E_BAD_ARG;
+    gyp_ctx* ctx = bank->ctx;
+    std::vector<ChanState> host((size_t)bank->n_chan);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(host.data(), bank->d_states, host.size() * sizeof(ChanState), hipMemcpyDeviceToHost));
+    for (int i = 0; i < bank->n_chan; ++i) {
+        if (doppler_hz) doppler_hz[i] = host[i].doppler;
+        if (carrier_phase) carrier_phase[i] = host[i].carrier_phase;
+        if (code_phase) code_phase[i] = host[i].code_phase;
+        if (lost) lost[i] = host[i].lost;
+    }
+    return GYP_OK;
+}
+
+}  // extern "C"

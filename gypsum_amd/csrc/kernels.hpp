@@ -1,0 +1,646 @@
+// kernels.hpp -- the __global__ kernels of libgypsum_hip.so (gfx950 only).
+//
+//   corr_cells_kernel   one workgroup per (stream, satellite, Doppler) cell, K wavefronts (K = samples per chip):
+//                       for each ms block: carrier wipe-off + polyphase pre-sum (global -> LDS), then per
+//                       wavefront FFT2048 -> x conj(PRN spectrum) -> IFFT2048, |.| / complex accumulation in
+//                       registers; finally max / argmax / sum / count-of-max reductions.
+//                       == utils.py:77-108 + the reductions of acquisition.py:180-189.
+//   track_step_kernel   same core for one explicit millisecond of one tracking channel, plus the early/late taps
+//                       and the rolled-PRN argmax of tracker.py:284-313.
+//   track_block_kernel  persistent per-channel loop over many milliseconds with the DLL / Costas / lock-detector
+//                       / circularity-watchdog state on the device (tracker.py:157-203, 246-262, 297-305, 331-389).
+//   acq_* kernels       the level-to-level bookkeeping of acquisition.py:70-152 on the device.
+#pragma once
+#include "corr_core.hpp"
+#include "../../include/gypsum_hip.h"
+
+namespace gyp {
+
+// ---------------------------------------------------------------------------------------------------------
+// shared-memory carve (dynamic LDS, 16-byte aligned base, all offsets multiples of 16)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kTablesBytes = 2 * 1024 * 8;  // tw1024 + tw2048
+constexpr int kRedBytes = 512;
+template <int K>
+constexpr int lds_bytes() { return kTablesBytes + K * kXchWaveBytes + kRedBytes; }
+
+struct RedScratch {
+    Best best[16];
+    double sum[16];
+    int cnt[16];
+    // track kernels
+    float taps[4];
+    double bcast[4];
+    int ibcast[4];
+};
+static_assert(sizeof(RedScratch) <= kRedBytes, "reduction scratch too large");
+
+struct Smem {
+    cf* tw1024;
+    cf* tw2048;
+    cf* xch;
+    RedScratch* red;
+};
+
+template <int K>
+__device__ __forceinline__ Smem carve_smem(char* base, const cf* __restrict__ tw_global) {
+    Smem s;
+    s.tw1024 = reinterpret_cast<cf*>(base);
+    s.tw2048 = s.tw1024 + 1024;
+    s.xch = s.tw2048 + 1024;
+    s.red = reinterpret_cast<RedScratch*>(base + kTablesBytes + K * kXchWaveBytes);
+    for (int i = threadIdx.x; i < 2048; i += 64 * K) s.tw1024[i] = tw_global[i];
+    return s;
+}
+
+// One millisecond of one cell/channel: stage (all waves) -> barrier -> per-wave correlation.
+// Returns c[j]: complex correlation at lag index k = K*(l + 32*(j + 16*h)) + wave.
+template <int K>
+__device__ __forceinline__ void correlate_ms(const cf* __restrict__ block, double u0, double du, const Smem& sm,
+                                             const cf* __restrict__ rep, cf (&c)[16]) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
+    cf* y_rows[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) y_rows[r] = sm.xch + r * kXchWave;
+    const cf rot1 = carrier_from_cycles(du);
+    const cf rw = carrier_from_cycles(du * (double)(K * kChips));
+    const cf rot_wrap = make_float2(rw.x, -rw.y);
+    for (int m = tid; m < kChips; m += 64 * K) stage_chip<K>(block, m, u0, du, rot1, rot_wrap, y_rows);
+    if (tid < K) y_rows[tid][kChips] = make_float2(0.f, 0.f);
+    __syncthreads();
+    cf x[32];
+    const cf* yw = y_rows[wave];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) x[j] = yw[32 * j + l];
+    wave_lds_fence();
+    cf* xch_half = sm.xch + wave * kXchWave + h * kXchHalf;
+    const LdsTables t{sm.tw1024, sm.tw2048};
+    wave_fft_fwd(x, xch_half, t, l, h);
+    spectrum_mul(x, rep);  // rep already points at this lane's column: 32 coalesced 512-B rows, L1/L2 resident
+    wave_fft_inv(x, c, xch_half, t, l, h);
+}
+
+// lag index of output slot j of this lane, or -1 for the one padding slot (q == 1023)
+template <int K>
+__device__ __forceinline__ int lag_index(int j) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = (lane & 31) + 32 * (j + 16 * (lane >> 5));
+    return q < kChips ? K * q + wave : -1;
+}
+
+struct ProfileStats {
+    Best best;   // max value + key
+    double sum;
+    int n_max;
+};
+
+// Workgroup-wide max / first-argmax (by key) / sum / count-of-max over vals[16] of every lane.
+// key_of(idx) orders ties (lowest key wins); result valid in every thread.
+template <int K, typename KeyFn>
+__device__ __forceinline__ ProfileStats profile_stats(const float (&vals)[16], RedScratch* red, KeyFn key_of) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    Best b{-1.0f, 0x7fffffff};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int idx = lag_index<K>(j);
+        if (idx >= 0) b = better(b, Best{vals[j], key_of(idx)});
+    }
+    b = wave_best(b);
+    if (lane == 0) red->best[wave] = b;
+    __syncthreads();
+    Best g = red->best[0];
+#pragma unroll
+    for (int w = 1; w < K; ++w) g = better(g, red->best[w]);
+    float part = 0.f;
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (lag_index<K>(j) >= 0) {
+            part += vals[j];
+            cnt += (vals[j] == g.v) ? 1 : 0;
+        }
+    }
+    const double s = wave_sum((double)part);
+    cnt = wave_sum(cnt);
+    if (lane == 0) {
+        red->sum[wave] = s;
+        red->cnt[wave] = cnt;
+    }
+    __syncthreads();
+    ProfileStats st;
+    st.best = g;
+    st.sum = 0.0;
+    st.n_max = 0;
+#pragma unroll
+    for (int w = 0; w < K; ++w) {
+        st.sum += red->sum[w];
+        st.n_max += red->cnt[w];
+    }
+    return st;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// correlation cells (acquisition building block)
+// ---------------------------------------------------------------------------------------------------------
+struct CellsParams {
+    const cf* iq;
+    int64_t stream_stride;
+    int32_t n_ms;
+    const gyp_cell_desc* cells;
+    int32_t n_cells;
+    gyp_cell* out;
+    float* profile_out;
+    const cf* replica_table;
+    const cf* tw_tables;
+    double inv_fs;
+};
+
+template <int K, bool COHERENT>
+__global__ __launch_bounds__(64 * K, 2) void corr_cells_kernel(CellsParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int N = K * kChips;
+    const Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
+    const int lane = threadIdx.x & 63;
+    __syncthreads();
+    for (int cell = blockIdx.x; cell < p.n_cells; cell += gridDim.x) {
+        const gyp_cell_desc d = p.cells[cell];
+        if (d.sat_id < 1 || d.sat_id > 32) continue;  // padding cell (uniform across the workgroup)
+        const cf* rep = replica_column(p.replica_table, d.sat_id - 1, lane);
+        const double du = d.doppler_hz * p.inv_fs;
+        const cf* stream = p.iq + (int64_t)d.stream * p.stream_stride;
+        float mag[16];
+        cf acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            mag[j] = 0.f;
+            acc[j] = make_float2(0.f, 0.f);
+        }
+        for (int ms = 0; ms < p.n_ms; ++ms) {
+            // utils.py:92-96: t = arange(N)/fs + (i*N)/fs ; carrier = exp(-1j*tau*f*t)
+            const double u0 = d.doppler_hz * ((double)((int64_t)ms * N) * p.inv_fs);
+            cf c[16];
+            correlate_ms<K>(stream + (int64_t)ms * N, u0, du, sm, rep, c);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (COHERENT) acc[j] = cadd(acc[j], c[j]);
+                else mag[j] += sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
+            }
+            __syncthreads();  // every wave is done with the exchange tiles before the next block is staged
+        }
+        if (COHERENT) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) mag[j] = sqrtf(fmaf(acc[j].x, acc[j].x, acc[j].y * acc[j].y));
+        }
+        const ProfileStats st = profile_stats<K>(mag, sm.red, [](int idx) { return idx; });
+        if (threadIdx.x == 0) {
+            gyp_cell o;
+            o.peak = st.best.v;
+            o.argmax = st.best.key;
+            o.sum = st.sum;
+            o.n_max = st.n_max;
+            o.reserved = 0;
+            o.tap_re = 0.f;
+            o.tap_im = 0.f;
+            if (d.tap_index < 0) p.out[cell] = o;
+            else {  // the lane that owns the tap fills tap_re / tap_im below
+                p.out[cell].peak = o.peak;
+                p.out[cell].argmax = o.argmax;
+                p.out[cell].sum = o.sum;
+                p.out[cell].n_max = o.n_max;
+                p.out[cell].reserved = 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int idx = lag_index<K>(j);
+            if (idx >= 0) {
+                if (idx == d.tap_index) {  // complex taps exist for coherent integration only
+                    p.out[cell].tap_re = COHERENT ? acc[j].x : 0.f;
+                    p.out[cell].tap_im = COHERENT ? acc[j].y : 0.f;
+                }
+                if (p.profile_out) {
+                    if (COHERENT) {  // complex integrated profile, interleaved re,im
+                        float2* prof = reinterpret_cast<float2*>(p.profile_out) + (int64_t)cell * N;
+                        prof[idx] = acc[j];
+                    } else {
+                        p.profile_out[(int64_t)cell * N + idx] = mag[j];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// tracking, one explicit millisecond
+// ---------------------------------------------------------------------------------------------------------
+struct TrackStepParams {
+    const cf* iq;
+    int64_t stream_stride;
+    const double* start_time;  // per stream
+    const gyp_chan_in* chans;
+    int32_t n_chan;
+    gyp_chan_out* out;
+    float* profile_out;
+    const cf* replica_table;
+    const cf* tw_tables;
+    double inv_fs;
+};
+
+__device__ __forceinline__ int mod_n(int v, int n) {
+    int r = v % n;
+    return r < 0 ? r + n : r;
+}
+
+// E/P/L of one millisecond given the un-rolled correlation c0:
+//   early = c0[(s-1) mod N], late = c0[(s+1) mod N], prompt profile[k] = c0[(s+k) mod N].
+template <int K>
+struct EplResult {
+    cf early, late, peak;
+    ProfileStats st;  // best.key = peak offset in the rolled profile
+};
+
+template <int K>
+__device__ __forceinline__ EplResult<K> epl_from_c0(const cf (&c)[16], int code_phase, RedScratch* red,
+                                                   float* profile_row) {
+    constexpr int N = K * kChips;
+    const int s = mod_n(code_phase, N);
+    const int ie = mod_n(s - 1, N), il = mod_n(s + 1, N);
+    float mag[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) mag[j] = sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
+    const ProfileStats st = profile_stats<K>(mag, red, [s](int idx) { int k = idx - s; return k < 0 ? k + N : k; });
+    const int ipk = mod_n(st.best.key + s, N);
+    // the owners of the three taps publish them (st's second barrier already separates this from the reads above)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int idx = lag_index<K>(j);
+        if (idx >= 0) {
+            if (idx == ie) { red->taps[0] = c[j].x; red->taps[1] = c[j].y; }
+            if (idx == il) { red->taps[2] = c[j].x; red->taps[3] = c[j].y; }
+            if (idx == ipk) { red->bcast[0] = (double)c[j].x; red->bcast[1] = (double)c[j].y; }
+            if (profile_row) { int k = idx - s; profile_row[k < 0 ? k + N : k] = mag[j]; }
+        }
+    }
+    __syncthreads();
+    EplResult<K> r;
+    r.early = make_float2(red->taps[0], red->taps[1]);
+    r.late = make_float2(red->taps[2], red->taps[3]);
+    r.peak = make_float2((float)red->bcast[0], (float)red->bcast[1]);
+    r.st = st;
+    return r;
+}
+
+template <int K>
+__global__ __launch_bounds__(64 * K, 2) void track_step_kernel(TrackStepParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int N = K * kChips;
+    const Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
+    const int lane = threadIdx.x & 63;
+    __syncthreads();
+    for (int ch = blockIdx.x; ch < p.n_chan; ch += gridDim.x) {
+        const gyp_chan_in in = p.chans[ch];
+        const cf* rep = replica_column(p.replica_table, in.sat_id - 1, lane);
+        // tracker.py:271-281: carrier = exp(-1j*(2*pi*f*t + phi)), t = n/fs + chunk.start_time
+        const double du = in.doppler_hz * p.inv_fs;
+        const double u0 = in.doppler_hz * p.start_time[in.stream] + in.carrier_phase * 0.15915494309189533577;
+        cf c[16];
+        correlate_ms<K>(p.iq + (int64_t)in.stream * p.stream_stride, u0, du, sm, rep, c);
+        const EplResult<K> r = epl_from_c0<K>(c, in.code_phase, sm.red,
+                                              p.profile_out ? p.profile_out + (int64_t)ch * N : nullptr);
+        if (threadIdx.x == 0) {
+            gyp_chan_out o;
+            o.early_re = r.early.x; o.early_im = r.early.y;
+            o.late_re = r.late.x; o.late_im = r.late.y;
+            o.peak_re = r.peak.x; o.peak_im = r.peak.y;
+            o.peak_mag = r.st.best.v;
+            o.peak_offset = r.st.best.key;
+            o.sum = r.st.sum;
+            o.n_max = r.st.n_max;
+            o.reserved = 0;
+            p.out[ch] = o;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// tracking, device-resident loops
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kLockWindow = 250;    // config.py:23
+constexpr int kPeakHistory = 1000;  // tracker.py:146 (deque maxlen)
+
+struct ChanState {
+    int32_t stream, sat_id;
+    double doppler, carrier_phase;   // current_doppler_shift / current_carrier_wave_phase_shift
+    double dll_phase;                // GpsSatelliteTracker.phase (tracker.py:224)
+    double last_watchdog_time;       // _time_since_last_constellation_circularity_induced_adjustment
+    int64_t n_steps;                 // milliseconds processed (== entries ever appended to the histories)
+    int32_t code_phase;              // current_prn_code_phase_shift
+    int32_t lost;
+    double err_ring[kLockWindow];    // carrier_wave_phase_errors, last 250
+    double peak_re[kPeakHistory];    // correlation_peaks_rolling_buffer
+    double peak_im[kPeakHistory];
+};
+
+// Python's float % positive-int
+__device__ __forceinline__ double pymod(double a, double b) {
+    double r = fmod(a, b);
+    if (r != 0.0 && ((r < 0.0) != (b < 0.0))) r += b;
+    return r;
+}
+
+// tracker.py:157-203 is_locked(), evaluated by wavefront 0 (all 64 lanes participate, result uniform).
+// n_err: number of errors appended so far (window = previous 250); n_peaks: peaks appended so far (including
+// the current one); rings are indexed by (count % size).
+__device__ __forceinline__ bool is_locked_wave(const ChanState* st, int64_t n_err, int64_t n_peaks, int lane) {
+    if (n_err < kLockWindow) return false;
+    const int e_newest = (int)((n_err - 1) % kLockWindow), p_newest = (int)((n_peaks - 1) % kPeakHistory);
+    double e[4], pr[4], pi[4];
+    bool ev[4];
+    double se = 0.0, sneg_re = 0.0, sneg_im = 0.0, spos_re = 0.0;
+    int cneg = 0, cpos = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = lane + 64 * i;  // k-th most recent (0 = newest)
+        ev[i] = k < kLockWindow;
+        const int ie = (e_newest - k + 2 * kLockWindow) % kLockWindow;
+        const int ip = (p_newest - k + kPeakHistory) % kPeakHistory;
+        e[i] = ev[i] ? st->err_ring[ie] : 0.0;
+        pr[i] = ev[i] ? st->peak_re[ip] : 0.0;
+        pi[i] = ev[i] ? st->peak_im[ip] : 0.0;
+        se += e[i];
+        if (ev[i]) {
+            if (pr[i] < 0.0) { sneg_re += pr[i]; sneg_im += pi[i]; ++cneg; }
+            else { spos_re += pr[i]; ++cpos; }
+        }
+    }
+    se = wave_sum(se);
+    sneg_re = wave_sum(sneg_re);
+    sneg_im = wave_sum(sneg_im);
+    spos_re = wave_sum(spos_re);
+    cneg = wave_sum(cneg);
+    cpos = wave_sum(cpos);
+    const double mean_e = se / kLockWindow;
+    const double mneg_re = cneg >= 2 ? sneg_re / cneg : 0.0, mneg_im = cneg >= 2 ? sneg_im / cneg : 0.0;
+    const double mneg_only_re = cneg > 0 ? sneg_re / cneg : 0.0;
+    const double mpos_re = cpos > 0 ? spos_re / cpos : 0.0;
+    double ve = 0.0, vneg = 0.0, vpos = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (ev[i]) {
+            const double d = e[i] - mean_e;
+            ve += d * d;
+            if (pr[i] < 0.0) { const double q = pr[i] - mneg_only_re; vneg += q * q; }
+            else { const double q = pr[i] - mpos_re; vpos += q * q; }
+        }
+    }
+    ve = wave_sum(ve) / kLockWindow;
+    vneg = cneg >= 2 ? wave_sum(vneg) / cneg : (wave_sum(vneg), 0.0);
+    vpos = cpos >= 2 ? wave_sum(vpos) / cpos : (wave_sum(vpos), 0.0);
+    const bool var_ok = ve < 900.0;                       // config.py:25
+    const bool i_ok = (vneg + vpos) / 2.0 < 2.0;          // tracker.py:188
+    const double ang = 180.0 - pymod((atan2(mneg_im, mneg_re) / 6.283185307179586) * 360.0, 180.0);
+    const double centered = ang < 90.0 ? ang : 180.0 - ang;
+    const bool rot_ok = centered < 6.0;                   // abs(bool) quirk, tracker.py:197
+    return var_ok && i_ok && rot_ok;
+}
+
+// utils.py:134-144 circularity and :119-131 rotation over the last min(n_peaks, 1000) peaks, by wavefront 0.
+// Returns via out[0] = circularity (or -1 if < 2 peaks), out[1] = rotation in degrees, out[2] = 1 if rotation valid.
+__device__ __forceinline__ void constellation_stats_wave(const ChanState* st, int64_t n_peaks, int lane, double (&out)[3]) {
+    const int n = (int)(n_peaks < kPeakHistory ? n_peaks : kPeakHistory);
+    double sr = 0.0, si = 0.0, lr = 0.0, li = 0.0;
+    int cl = 0;
+    for (int k = lane; k < n; k += 64) {
+        const double a = st->peak_re[k], b = st->peak_im[k];
+        sr += a; si += b;
+        if (a < 0.0) { lr += a; li += b; ++cl; }
+    }
+    sr = wave_sum(sr); si = wave_sum(si); lr = wave_sum(lr); li = wave_sum(li); cl = wave_sum(cl);
+    if (n < 2) { out[0] = -1.0; out[1] = 0.0; out[2] = 0.0; return; }
+    const double mr = sr / n, mi = si / n;
+    double vxx = 0.0, vyy = 0.0, vxy = 0.0;
+    for (int k = lane; k < n; k += 64) {
+        const double a = st->peak_re[k] - mr, b = st->peak_im[k] - mi;
+        vxx += a * a; vyy += b * b; vxy += a * b;
+    }
+    vxx = wave_sum(vxx) / (n - 1); vyy = wave_sum(vyy) / (n - 1); vxy = wave_sum(vxy) / (n - 1);
+    const double hs = 0.5 * (vxx + vyy), hd = 0.5 * (vxx - vyy);
+    const double rad = sqrt(hd * hd + vxy * vxy);
+    const double e1 = hs + rad, e2 = hs - rad;
+    out[0] = 1.0 - (e2 / e1);
+    if (cl < 2) { out[1] = 0.0; out[2] = 0.0; return; }
+    const double ang = 180.0 - pymod((atan2(li / cl, lr / cl) / 6.283185307179586) * 360.0, 180.0);
+    out[1] = ang > 90.0 ? ang - 180.0 : ang;
+    out[2] = 1.0;
+}
+
+struct TrackBlockParams {
+    const cf* iq;
+    int64_t stream_stride;
+    int32_t n_ms;
+    const double* start_time;  // [n_ms]
+    ChanState* states;
+    int32_t n_chan;
+    gyp_track_rec* rec_out;    // [n_chan][n_ms] or null
+    const cf* replica_table;
+    const cf* tw_tables;
+    double inv_fs;
+    double fs;
+};
+
+template <int K>
+__global__ __launch_bounds__(64 * K, 2) void track_block_kernel(TrackBlockParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int N = K * kChips;
+    const Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    const int ch = blockIdx.x;
+    if (ch >= p.n_chan) return;
+    ChanState* st = p.states + ch;
+    const cf* rep = replica_column(p.replica_table, st->sat_id - 1, lane);
+    const cf* stream = p.iq + (int64_t)st->stream * p.stream_stride;
+    // loop state, uniform across the workgroup (re-broadcast through LDS each millisecond)
+    double f = st->doppler, phi = st->carrier_phase;
+    int code_phase = st->code_phase;
+    int lost = st->lost;
+    // wavefront 0 carries the scalar loop state in registers (identical in all its lanes) and writes it back once
+    int64_t n_steps = st->n_steps;
+    double dll_phase = st->dll_phase, last_watchdog = st->last_watchdog_time;
+    for (int ms = 0; ms < p.n_ms; ++ms) {
+        gyp_track_rec* rec = p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + ms : nullptr;
+        if (lost) {  // a dropped channel stays dropped until the host re-creates it (receiver.py:259-267)
+            if (rec && threadIdx.x == 0) { gyp_track_rec z = {}; z.status = 2; z.doppler_hz = f; z.carrier_phase = phi; z.code_phase = code_phase; *rec = z; }
+            continue;
+        }
+        const double t0 = p.start_time[ms];
+        const double du = f * p.inv_fs;
+        const double u0 = f * t0 + phi * 0.15915494309189533577;
+        cf c[16];
+        correlate_ms<K>(stream + (int64_t)ms * N, u0, du, sm, rep, c);
+        const EplResult<K> r = epl_from_c0<K>(c, code_phase, sm.red, nullptr);
+        if (wave == 0) {
+            const int64_t n = n_steps;
+            // ---- code loop, tracker.py:297-303
+            const double er = r.early.x, ei = r.early.y, lr = r.late.x, li = r.late.y;
+            const double disc = ((er * er + ei * ei) - (lr * lr + li * li)) / 2.0;
+            double dll = dll_phase + disc * 0.002;
+            const int new_code_phase = (int)dll;           // int() truncates toward zero, before the wrap
+            dll = pymod(dll, 2046.0);
+            if (dll < 0.0) dll += 2046.0;
+            // ---- histories, tracker.py:346-347
+            const double pr = (double)r.peak.x, pim = (double)r.peak.y;
+            if (lane == 0) { st->peak_re[n % kPeakHistory] = pr; st->peak_im[n % kPeakHistory] = pim; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // ---- Costas loop, tracker.py:246-262
+            const double err = pr * pim;
+            const bool locked = is_locked_wave(st, n, n + 1, lane);
+            const double bw = locked ? 3.0 : 6.0;
+            const double tps = 1.0 / p.fs;
+            const double alpha = 4.0 * (1.0 / sqrt(2.0)) * bw * tps;
+            const double beta = 4.0 * (bw * bw) * tps;
+            double nphi = pymod(phi + err * alpha, 6.283185307179586);
+            double nf = f + err * beta;
+            if (lane == 0) st->err_ring[n % kLockWindow] = err;
+            const float mean_excl = (float)((r.st.sum - (double)r.st.n_max * (double)r.st.best.v) / (double)(N - r.st.n_max));
+            const double rec_f = nf, rec_phi = nphi;
+            // ---- circularity watchdog, tracker.py:370-387
+            int status = 0, nudged = 0;
+            if (t0 - last_watchdog >= 6.0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                double cs[3];
+                constellation_stats_wave(st, n + 1, lane, cs);
+                last_watchdog = t0;
+                if (cs[0] >= 0.0) {
+                    if (cs[0] < 0.2) { status = 1; lost = 1; }
+                    else if (cs[0] < 0.93 && cs[2] != 0.0) {
+                        const double sg = cs[1] > 0.0 ? 1.0 : (cs[1] < 0.0 ? -1.0 : 0.0);
+                        nf += -sg * 5.0;
+                        nphi += sg * (3.141592653589793 / 2.0);
+                        nudged = 1;
+                    }
+                }
+            }
+            dll_phase = dll;
+            n_steps = n + 1;
+            if (lane == 0) {
+                sm.red->bcast[2] = nf; sm.red->bcast[3] = nphi;
+                sm.red->ibcast[0] = new_code_phase; sm.red->ibcast[1] = lost;
+                if (rec) {
+                    gyp_track_rec o;
+                    o.peak_re = r.peak.x; o.peak_im = r.peak.y;
+                    o.strength = r.st.best.v / mean_excl;
+                    o.discriminator = (float)disc;
+                    o.doppler_hz = rec_f; o.carrier_phase = rec_phi; o.error = err;
+                    o.code_phase = new_code_phase; o.peak_offset = r.st.best.key;
+                    o.pseudosymbol = (int8_t)(pr > 0.0 ? 1 : (pr < 0.0 ? -1 : 0));
+                    o.locked = locked ? 1 : 0; o.status = (int8_t)status; o.nudged = (int8_t)nudged;
+                    o.reserved = 0;
+                    *rec = o;
+                }
+            }
+        }
+        __syncthreads();
+        f = sm.red->bcast[2]; phi = sm.red->bcast[3];
+        code_phase = sm.red->ibcast[0]; lost = sm.red->ibcast[1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        st->doppler = f; st->carrier_phase = phi; st->code_phase = code_phase; st->lost = lost;
+        st->dll_phase = dll_phase; st->n_steps = n_steps; st->last_watchdog_time = last_watchdog;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// acquisition bookkeeping (acquisition.py:70-152)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kMaxBins = 28;  // len(range(int(c-s), int(c+s), int(s/10))) never exceeds 28 for s = 7000/2^i >= 10
+
+struct AcqSearchState {
+    int32_t stream, sat_id;
+    double center, spread;
+    int32_t level;
+    int32_t has_best;
+    int32_t best_doppler, best_index;
+    double best_strength;
+    int32_t bins_lo, bins_step, n_bins, pad;
+};
+
+// Fill the descriptors of the current level: range(int(c-s), int(c+s), int(s/10)), padded to kMaxBins.
+__global__ void acq_plan_kernel(AcqSearchState* states, int n_states, gyp_cell_desc* cells) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_states) return;
+    AcqSearchState s = states[i];
+    const int lo = (int)(s.center - s.spread), hi = (int)(s.center + s.spread), step = (int)(s.spread / 10.0);
+    const int nb = hi > lo ? (hi - lo + step - 1) / step : 0;
+    states[i].bins_lo = lo; states[i].bins_step = step; states[i].n_bins = nb;
+    for (int b = 0; b < kMaxBins; ++b) {
+        gyp_cell_desc d;
+        d.stream = s.stream;
+        d.sat_id = b < nb ? s.sat_id : 0;
+        d.doppler_hz = (double)(lo + b * step);
+        d.tap_index = -1;
+        d.reserved = 0;
+        cells[i * kMaxBins + b] = d;
+    }
+}
+
+__device__ __forceinline__ double cell_strength(const gyp_cell& c, int n) {
+    const double pk = (double)c.peak;
+    return pk / ((c.sum - (double)c.n_max * pk) / (double)(n - c.n_max));
+}
+
+// Fold one level's cells into the search state: best bin = first bin holding the largest maximum
+// (acquisition.py:180-182), centre <- its Doppler, spread halves, overall best replaced on strictly greater
+// strength (:92-101).
+__global__ void acq_reduce_kernel(AcqSearchState* states, int n_states, const gyp_cell* cells, int n_samples) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_states) return;
+    AcqSearchState s = states[i];
+    int best_b = 0;
+    float best_peak = -1.f;
+    for (int b = 0; b < s.n_bins; ++b) {
+        const float pk = cells[i * kMaxBins + b].peak;
+        if (pk > best_peak) { best_peak = pk; best_b = b; }
+    }
+    const gyp_cell c = cells[i * kMaxBins + best_b];
+    const double strength = cell_strength(c, n_samples);
+    const int doppler = s.bins_lo + best_b * s.bins_step;
+    s.spread /= 2.0;
+    s.center = (double)doppler;
+    if (!s.has_best || strength > s.best_strength) {
+        s.has_best = 1; s.best_doppler = doppler; s.best_index = c.argmax; s.best_strength = strength;
+    }
+    s.level += 1;
+    states[i] = s;
+}
+
+// One coherent cell per (stream, satellite) at the winning Doppler, tapped at the winning code phase (:122-136).
+__global__ void acq_plan_coherent_kernel(const AcqSearchState* states, int n_states, gyp_cell_desc* cells) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_states) return;
+    gyp_cell_desc d;
+    d.stream = states[i].stream; d.sat_id = states[i].sat_id;
+    d.doppler_hz = (double)states[i].best_doppler;
+    d.tap_index = states[i].best_index; d.reserved = 0;
+    cells[i] = d;
+}
+
+__global__ void acq_finish_kernel(const AcqSearchState* states, int n_states, const gyp_cell* cells, gyp_acq_result* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_states) return;
+    gyp_acq_result r;
+    r.stream = states[i].stream; r.sat_id = states[i].sat_id;
+    r.doppler_hz = states[i].best_doppler; r.code_phase = states[i].best_index;
+    r.carrier_phase = atan2((double)cells[i].tap_im, (double)cells[i].tap_re);
+    r.strength = states[i].best_strength;
+    out[i] = r;
+}
+
+}  // namespace gyp

@@ -1,0 +1,221 @@
+"""`GypsumEngine`: thin Python object over one libgypsum_hip context (one per GPU).
+
+All numerics happen in the HIP library; this module only marshals numpy arrays
+through ctypes.  Nothing here computes a correlation on the CPU, and construction
+fails if the library or a gfx950 device is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import (ACQ_RESULT, CELL, CELL_DESC, CHAN_IN, CHAN_INIT, CHAN_OUT, GYP_COHERENT, GYP_NON_COHERENT,
+                   TRACK_REC, GypsumHipError, ptr)
+
+
+def _as_iq(iq: np.ndarray) -> np.ndarray:
+    """complex64, C-contiguous view/copy of the caller's samples (the reference hands complex64 chunks)."""
+    return np.ascontiguousarray(iq, dtype=np.complex64)
+
+
+class DeviceBuffer:
+    """RAII wrapper around gyp_malloc / gyp_free."""
+
+    def __init__(self, engine: "GypsumEngine", nbytes: int) -> None:
+        self.engine = engine
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        engine._check(engine.lib.gyp_malloc(engine.ctx, max(1, self.nbytes), C.byref(p)))
+        self.ptr = p
+
+    def upload(self, host: np.ndarray) -> "DeviceBuffer":
+        host = np.ascontiguousarray(host)
+        if host.nbytes > self.nbytes:
+            raise ValueError("host array larger than device buffer")
+        self.engine._check(self.engine.lib.gyp_memcpy_h2d(self.engine.ctx, self.ptr, ptr(host), host.nbytes))
+        self.engine.sync()   # `host` may be a temporary
+        return self
+
+    def download(self, dtype, count: int) -> np.ndarray:
+        out = np.empty(count, dtype=dtype)
+        self.engine._check(self.engine.lib.gyp_memcpy_d2h(self.engine.ctx, ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def free(self) -> None:
+        if self.ptr is not None and self.ptr.value:
+            self.engine.lib.gyp_free(self.engine.ctx, self.ptr)
+            self.ptr = None
+
+    def __del__(self) -> None:
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class GypsumEngine:
+    def __init__(self, device: int = 0) -> None:
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        rc = self.lib.gyp_create(device, C.byref(h))
+        if rc != 0:
+            raise GypsumHipError(rc, (self.lib.gyp_last_error(None) or b"").decode())
+        self.ctx = h
+        self.device = device
+        self.fs: Optional[int] = None
+        self.n: Optional[int] = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise GypsumHipError(rc, (self.lib.gyp_last_error(self.ctx) or b"").decode())
+
+    def close(self) -> None:
+        if getattr(self, "ctx", None) is not None and self.ctx.value:
+            self.lib.gyp_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_name(self) -> str:
+        buf = C.create_string_buffer(256)
+        self._check(self.lib.gyp_device_name(self.ctx, buf, 256))
+        return buf.value.decode()
+
+    def set_stream(self, hip_stream: Optional[int]) -> None:
+        self._check(self.lib.gyp_set_stream(self.ctx, C.c_void_p(hip_stream)))
+
+    def sync(self) -> None:
+        self._check(self.lib.gyp_sync(self.ctx))
+
+    def timer_start(self) -> None:
+        self._check(self.lib.gyp_timer_start(self.ctx))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        self._check(self.lib.gyp_timer_stop(self.ctx, C.byref(ms)))
+        return float(ms.value)
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def set_stream_format(self, samples_per_second: int, samples_per_prn_transmission: int) -> None:
+        self._check(self.lib.gyp_set_stream_format(self.ctx, int(samples_per_second), int(samples_per_prn_transmission)))
+        self.fs, self.n = int(samples_per_second), int(samples_per_prn_transmission)
+
+    # ------------------------------------------------------------------ correlation cells
+    def correlate_cells(self, iq: np.ndarray, n_streams: int, n_ms: int, cells: np.ndarray, integration: int,
+                        want_profiles: bool = False) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+        """iq: complex64[n_streams * n_ms * N] stream-major.  cells: CELL_DESC records."""
+        iq = _as_iq(iq).reshape(-1)
+        if iq.size != n_streams * n_ms * self.n:
+            raise ValueError(f"expected {n_streams}*{n_ms}*{self.n} samples, got {iq.size}")
+        cells = np.ascontiguousarray(cells, dtype=CELL_DESC)
+        out = np.zeros(len(cells), dtype=CELL)
+        prof = None
+        if want_profiles:
+            prof = np.zeros((len(cells), self.n), dtype=np.complex64 if integration == GYP_COHERENT else np.float32)
+        self._check(self.lib.gyp_correlate_cells(self.ctx, ptr(iq), n_streams, n_ms, ptr(cells), len(cells),
+                                                  integration, ptr(out), ptr(prof)))
+        return out, prof
+
+    def cell_strength(self, cells: np.ndarray) -> np.ndarray:
+        """utils.py:111-116 on the reduced record, float64."""
+        pk = cells["peak"].astype(np.float64)
+        return pk / ((cells["sum"] - cells["n_max"] * pk) / (self.n - cells["n_max"]))
+
+    # ------------------------------------------------------------------ acquisition
+    def acquire(self, iq: np.ndarray, n_streams: int, n_ms: int, sat_ids: Sequence[int]) -> np.ndarray:
+        iq = _as_iq(iq).reshape(-1)
+        if iq.size != n_streams * n_ms * self.n:
+            raise ValueError(f"expected {n_streams}*{n_ms}*{self.n} samples, got {iq.size}")
+        ids = np.ascontiguousarray(sat_ids, dtype=np.int32)
+        out = np.zeros(n_streams * len(ids), dtype=ACQ_RESULT)
+        self._check(self.lib.gyp_acquire(self.ctx, ptr(iq), n_streams, n_ms, ptr(ids), len(ids), ptr(out)))
+        return out
+
+    # ------------------------------------------------------------------ tracking
+    def track_step(self, iq_1ms: np.ndarray, n_streams: int, start_times: Sequence[float], chans: np.ndarray,
+                   want_profiles: bool = False) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+        iq = _as_iq(iq_1ms).reshape(-1)
+        if iq.size != n_streams * self.n:
+            raise ValueError(f"expected {n_streams}*{self.n} samples, got {iq.size}")
+        t0 = np.ascontiguousarray(start_times, dtype=np.float64)
+        chans = np.ascontiguousarray(chans, dtype=CHAN_IN)
+        out = np.zeros(len(chans), dtype=CHAN_OUT)
+        prof = np.zeros((len(chans), self.n), dtype=np.float32) if want_profiles else None
+        self._check(self.lib.gyp_track_step(self.ctx, ptr(iq), n_streams, ptr(t0), ptr(chans), len(chans), ptr(out),
+                                             ptr(prof)))
+        return out, prof
+
+    def create_bank(self, inits: np.ndarray) -> "ChannelBank":
+        return ChannelBank(self, inits)
+
+
+class ChannelBank:
+    """Device-resident tracking channels (gyp_bank_*)."""
+
+    def __init__(self, engine: GypsumEngine, inits: np.ndarray) -> None:
+        self.engine = engine
+        inits = np.ascontiguousarray(inits, dtype=CHAN_INIT)
+        h = C.c_void_p()
+        engine._check(engine.lib.gyp_bank_create(engine.ctx, ptr(inits), len(inits), C.byref(h)))
+        self.handle = h
+        self.n_chan = len(inits)
+
+    def track_block(self, iq: np.ndarray, n_streams: int, n_ms: int, start_times: Sequence[float],
+                    want_records: bool = True) -> Optional[np.ndarray]:
+        e = self.engine
+        iq = _as_iq(iq).reshape(-1)
+        if iq.size != n_streams * n_ms * e.n:
+            raise ValueError(f"expected {n_streams}*{n_ms}*{e.n} samples, got {iq.size}")
+        t0 = np.ascontiguousarray(start_times, dtype=np.float64)
+        if len(t0) != n_ms:
+            raise ValueError("one start time per millisecond expected")
+        rec = np.zeros((self.n_chan, n_ms), dtype=TRACK_REC) if want_records else None
+        e._check(e.lib.gyp_track_block(self.handle, ptr(iq), n_streams, n_ms, ptr(t0), ptr(rec)))
+        return rec
+
+    def track_block_dev(self, iq_ptr: int, stream_stride: int, n_ms: int, start_times_ptr: int, rec_ptr: int = 0) -> None:
+        e = self.engine
+        e._check(e.lib.gyp_track_block_dev(self.handle, C.c_void_p(iq_ptr), stream_stride, n_ms,
+                                           C.c_void_p(start_times_ptr), C.c_void_p(rec_ptr or None)))
+
+    def state(self) -> Dict[str, np.ndarray]:
+        f = np.zeros(self.n_chan)
+        phi = np.zeros(self.n_chan)
+        cp = np.zeros(self.n_chan, dtype=np.int32)
+        lost = np.zeros(self.n_chan, dtype=np.int32)
+        self.engine._check(self.engine.lib.gyp_bank_get_state(self.handle, ptr(f), ptr(phi), ptr(cp), ptr(lost)))
+        return {"doppler_hz": f, "carrier_phase": phi, "code_phase": cp, "lost": lost}
+
+    def close(self) -> None:
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self.engine.lib.gyp_bank_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_engines: Dict[int, GypsumEngine] = {}
+
+
+def default_engine(samples_per_second: int, samples_per_prn_transmission: int, device: int = 0) -> GypsumEngine:
+    """Process-wide engine for the drop-in classes (the reference is single-threaded, one stream format)."""
+    eng = _default_engines.get(device)
+    if eng is None:
+        eng = _default_engines[device] = GypsumEngine(device)
+    if eng.fs != samples_per_second or eng.n != samples_per_prn_transmission:
+        eng.set_stream_format(samples_per_second, samples_per_prn_transmission)
+    return eng

@@ -1,0 +1,222 @@
+/*
+ * gypsum_hip.h -- C ABI of libgypsum_hip.so, the MI355X (gfx950) GPS L1 C/A correlator engine.
+ *
+ * The reference (codyd51/gypsum) is pure Python + numpy and has no FFI layer; its correlator hot path is
+ * reached through plain Python call sites.  Each entry point below names the
+ * reference interface it replaces (file:line under /root/reference/gypsum).  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++ or torch types cross the boundary.
+ *   - return 0 (GYP_OK) or a negative GYP_E_* code; gyp_last_error() gives the message.
+ *   - IQ is the reference's on-disk format: interleaved float32 I,Q (antenna_sample_provider.py:112-119),
+ *     i.e. complex64.  A "sample" is one I,Q pair.
+ *   - functions without a suffix take HOST buffers the caller owns for the duration of the call and are
+ *     synchronous.  Functions ending in _dev take DEVICE pointers (allocated with gyp_malloc or by any other
+ *     HIP allocator in the same process, e.g. a torch tensor's data_ptr()), are enqueued on the context's
+ *     stream and return without synchronising; call gyp_sync() before reading results.
+ *   - one context per GPU, not thread-safe (the reference is single-threaded).
+ *   - satellite ids are 1..32 everywhere.
+ *   - no CPU fallback exists: without a usable HIP device gyp_create fails with GYP_E_NO_DEVICE.
+ */
+#ifndef GYPSUM_HIP_H
+#define GYPSUM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GYP_VERSION 100 /* 0.1.0 */
+
+enum {
+    GYP_OK = 0,
+    GYP_E_BAD_ARG = -1,
+    GYP_E_BAD_RATE = -2,    /* fs not a multiple of 1.023 MHz, N != fs/1000, or an unsupported multiple */
+    GYP_E_NO_DEVICE = -3,
+    GYP_E_HIP = -4,
+    GYP_E_NO_FORMAT = -5,   /* gyp_set_stream_format has not been called */
+    GYP_E_NOMEM = -6
+};
+
+/* utils.py:23-25 IntegrationType */
+enum { GYP_COHERENT = 0, GYP_NON_COHERENT = 1 };
+
+typedef struct gyp_ctx gyp_ctx;
+
+/* ---------------------------------------------------------------- context ---------------------------- */
+int gyp_version(void);
+int gyp_create(int device_ordinal, gyp_ctx** out);
+void gyp_destroy(gyp_ctx* ctx);
+/* ctx may be NULL: returns the message of the last failed gyp_create on this thread. */
+const char* gyp_last_error(const gyp_ctx* ctx);
+int gyp_device_name(gyp_ctx* ctx, char* out, int cap);
+/* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. NULL restores it. */
+int gyp_set_stream(gyp_ctx* ctx, void* hip_stream);
+int gyp_sync(gyp_ctx* ctx);
+/* hipEvent pair on the context's stream: the kernels' device time, as bench.py reports it. */
+int gyp_timer_start(gyp_ctx* ctx);
+int gyp_timer_stop(gyp_ctx* ctx, float* elapsed_ms);
+
+/* Stream descriptor -- replaces SampleProviderAttributes (antenna_sample_provider.py:24-28) and the PRN
+ * replica construction of receiver.py:45-53 / satellite.py:20-31.  Requires samples_per_ms == fs_hz/1000 and
+ * samples_per_ms == K*1023 with K in {1,2,4,8} (wider rates are a later round).  Builds the
+ * on-device PRN spectrum table (32 satellites) and the FFT twiddle tables. */
+int gyp_set_stream_format(gyp_ctx* ctx, int64_t fs_hz, int32_t samples_per_ms);
+
+/* ---------------------------------------------------------------- PRN codes (host only, no GPU needed) -- */
+/* gps_ca_prn_codes.py:134-250 generate_replica_prn_signals: 32 x 1023 chips in {0,1}, row-major, SV 1 first.
+ * Fails with GYP_E_BAD_ARG if a generated code misses its IS-GPS-200 first-10-chip marker (:190-247). */
+int gyp_prn_chips(uint8_t* out_32x1023);
+/* The per-satellite frequency-domain replica in the kernel's register/lane layout: conj(FFT2048(periodic
+ * +-1 code))/2048 as float re,im [32 regs][64 lanes]; exposed so tests can check it against numpy. */
+int gyp_prn_spectrum_lane_layout(int sat_id, float* out_32x64x2);
+
+/* ---------------------------------------------------------------- device memory helpers --------------- */
+int gyp_malloc(gyp_ctx* ctx, uint64_t bytes, void** dptr);
+int gyp_free(gyp_ctx* ctx, void* dptr);
+int gyp_memcpy_h2d(gyp_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes); /* async on the stream */
+int gyp_memcpy_d2h(gyp_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes); /* synchronises */
+
+/* ---------------------------------------------------------------- correlation cells ------------------- */
+/* One (stream, satellite, Doppler) cell of the search grid = one call of
+ * utils.py:77-108 integrate_correlation_with_doppler_shifted_prn. */
+typedef struct gyp_cell_desc {
+    int32_t stream;     /* which IQ stream (0-based) */
+    int32_t sat_id;     /* 1..32 */
+    double doppler_hz;  /* wipe-off frequency; carrier = exp(-1j*tau*f*t), t from the buffer start (utils.py:92-96) */
+    int32_t tap_index;  /* sample offset whose (integrated) complex value is returned in tap_re/tap_im; <0: none */
+    int32_t reserved;
+} gyp_cell_desc;
+
+/* What acquisition.py:180-189 reduces each integrated profile to. strength (utils.py:111-116) is
+ * peak / ((sum - n_max*peak) / (N - n_max)), to be evaluated in float64 by the caller (gyp_cell_strength). */
+typedef struct gyp_cell {
+    float peak;         /* np.max(profile) */
+    int32_t argmax;     /* np.argmax(profile): lowest index among equal maxima */
+    double sum;         /* sum(profile) */
+    int32_t n_max;      /* number of elements equal to the maximum */
+    int32_t reserved;
+    float tap_re;       /* integrated complex correlation at desc.tap_index (coherent: sum_i c_i[tap]; */
+    float tap_im;       /*  non-coherent: c of the LAST block), 0 if tap_index < 0 */
+} gyp_cell;
+
+double gyp_cell_strength(const gyp_cell* c, int32_t samples_per_ms);
+
+/* iq_dev: n_streams x n_ms x N samples, stream-major (stream s starts at sample s*stream_stride).
+ * cells_dev/out_dev: n_cells records.  profile_out_dev (may be NULL): the whole integrated profile per cell
+ * for callers that need it (utils-level drop-in, tracker_visualizer): non-coherent -> n_cells x N float32
+ * (sum |c|); coherent -> n_cells x N x 2 float32 (sum c, interleaved re,im). */
+int gyp_correlate_cells_dev(gyp_ctx* ctx, const float* iq_dev, int64_t stream_stride_samples, int32_t n_ms,
+                            const gyp_cell_desc* cells_dev, int32_t n_cells, int32_t integration,
+                            gyp_cell* out_dev, float* profile_out_dev);
+/* Host-buffer form: copies iq (n_streams*n_ms*N samples, stream stride n_ms*N) and descriptors in, results out. */
+int gyp_correlate_cells(gyp_ctx* ctx, const float* iq_host, int32_t n_streams, int32_t n_ms,
+                        const gyp_cell_desc* cells_host, int32_t n_cells, int32_t integration,
+                        gyp_cell* out_host, float* profile_out_host);
+
+/* ---------------------------------------------------------------- acquisition ------------------------- */
+/* acquisition.py:35-41 SatelliteAcquisitionAttemptResult */
+typedef struct gyp_acq_result {
+    int32_t stream;
+    int32_t sat_id;
+    int32_t doppler_hz;      /* doppler_shift (int, a member of one of the search ranges) */
+    int32_t code_phase;      /* prn_phase_shift, sample offset of the correlation peak, [0, N) */
+    double carrier_phase;    /* carrier_wave_phase_shift = angle(coherent[code_phase]), radians (-pi, pi] */
+    double strength;         /* correlation_strength of the best non-coherent profile */
+} gyp_acq_result;
+
+/* acquisition.py:70-152 _attempt_acquisition_for_satellite_id for every (stream, satellite): the 10-level
+ * coarse-to-fine Doppler search (spread 7000 Hz halving while >= 10, bins range(int(c-s), int(c+s), int(s/10)),
+ * non-coherent over the n_ms blocks), then the coherent pass for the carrier phase.  The threshold of
+ * acquisition.py:65 is left to the caller.  out: n_streams x n_sats records, stream-major, sat order as given. */
+int gyp_acquire_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_t stream_stride_samples,
+                    int32_t n_ms, const int32_t* sat_ids_host, int32_t n_sats, gyp_acq_result* out_dev);
+int gyp_acquire(gyp_ctx* ctx, const float* iq_host, int32_t n_streams, int32_t n_ms,
+                const int32_t* sat_ids_host, int32_t n_sats, gyp_acq_result* out_host);
+
+/* ---------------------------------------------------------------- tracking: one explicit millisecond -- */
+/* Numeric core of tracker.py:264-329 _run_prn_code_tracking_loop_iteration for a batch of channels:
+ * carrier wipe-off with (doppler, carrier_phase) at time start_time + n/fs, early/late single-lag correlators at
+ * code_phase -/+ 1 sample, full prompt correlation against the PRN rolled by code_phase, its argmax and the
+ * reductions peak strength needs.  The loop-filter updates stay with the caller (or use gyp_track_block). */
+typedef struct gyp_chan_in {
+    int32_t stream;
+    int32_t sat_id;
+    double doppler_hz;       /* current_doppler_shift */
+    double carrier_phase;    /* current_carrier_wave_phase_shift, radians */
+    int32_t code_phase;      /* current_prn_code_phase_shift (any integer; rolled mod N like np.roll) */
+    int32_t reserved;
+} gyp_chan_in;
+
+typedef struct gyp_chan_out {
+    float early_re, early_im;   /* np.correlate(xw, roll(prn, s-1)) */
+    float late_re, late_im;     /* np.correlate(xw, roll(prn, s+1)) */
+    float peak_re, peak_im;     /* coherent_prompt_correlation[argmax |.|] */
+    float peak_mag;             /* max |prompt| */
+    int32_t peak_offset;        /* argmax of |prompt| (index into the profile of the rolled PRN) */
+    double sum;                 /* sum |prompt| */
+    int32_t n_max;
+    int32_t reserved;
+} gyp_chan_out;
+
+/* iq_dev: n_streams x N samples of the current millisecond (stream stride given); start_time_host[n_streams]:
+ * AntennaSampleChunk.start_time per stream.  profile_out_dev (may be NULL): n_chan x N float32 |prompt|. */
+int gyp_track_step_dev(gyp_ctx* ctx, const float* iq_dev, int64_t stream_stride_samples,
+                       const double* start_time_dev, const gyp_chan_in* chans_dev, int32_t n_chan,
+                       gyp_chan_out* out_dev, float* profile_out_dev);
+int gyp_track_step(gyp_ctx* ctx, const float* iq_host, int32_t n_streams, const double* start_time_host,
+                   const gyp_chan_in* chans_host, int32_t n_chan, gyp_chan_out* out_host,
+                   float* profile_out_host);
+
+/* ---------------------------------------------------------------- tracking: device-resident loops ----- */
+/* A bank of channels whose whole per-millisecond loop state lives on the GPU: tracker.py:206-389
+ * GpsSatelliteTracker.process_samples (code loop, Costas loop with the is_locked() bandwidth switch of
+ * :157-203, 6-second circularity watchdog of :370-387) advanced for many milliseconds per launch. */
+typedef struct gyp_bank gyp_bank;
+
+typedef struct gyp_chan_init {   /* from SatelliteAcquisitionAttemptResult, pipeline.py:56-62 */
+    int32_t stream;
+    int32_t sat_id;
+    double doppler_hz;
+    double carrier_phase;
+    int32_t code_phase;
+    int32_t reserved;
+} gyp_chan_init;
+
+/* one record per channel per millisecond: what process_samples appends to the history deques (tracker.py:146-155) */
+typedef struct gyp_track_rec {
+    float peak_re, peak_im;       /* correlation_peaks_rolling_buffer entry */
+    float strength;               /* correlation_peak_strengths_rolling_buffer entry */
+    float discriminator;          /* (|E|^2 - |L|^2)/2 */
+    double doppler_hz;            /* current_doppler_shift after the update (doppler_shifts entry) */
+    double carrier_phase;         /* current_carrier_wave_phase_shift after the update */
+    double error;                 /* carrier_wave_phase_errors entry (I*Q) */
+    int32_t code_phase;           /* current_prn_code_phase_shift after the update (int(self.phase), pre-wrap) */
+    int32_t peak_offset;
+    int8_t pseudosymbol;          /* sign(peak.real): -1, +1, 0 (the reference raises KeyError on 0) */
+    int8_t locked;                /* is_locked() as evaluated inside the Costas loop this millisecond */
+    int8_t status;                /* 0 ok, 1 LostSatelliteLockError raised this ms (circularity < 0.2), 2 already lost */
+    int8_t nudged;                /* circularity watchdog adjusted doppler/phase after this ms */
+    int32_t reserved;
+} gyp_track_rec;
+
+int gyp_bank_create(gyp_ctx* ctx, const gyp_chan_init* chans_host, int32_t n_chan, gyp_bank** out);
+void gyp_bank_destroy(gyp_bank* bank);
+int gyp_bank_size(const gyp_bank* bank);
+/* Advance every channel n_ms milliseconds.  iq_dev: n_streams x n_ms x N (stream stride given);
+ * start_time_dev/end_time_dev: n_ms doubles (shared by all streams): chunk.start_time / chunk.end_time;
+ * rec_out_dev: n_chan x n_ms records (channel-major), may be NULL. */
+int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stride_samples, int32_t n_ms,
+                        const double* start_time_dev, gyp_track_rec* rec_out_dev);
+int gyp_track_block(gyp_bank* bank, const float* iq_host, int32_t n_streams, int32_t n_ms,
+                    const double* start_time_host, gyp_track_rec* rec_out_host);
+/* Read back the live estimates (GpsSatelliteTrackingParameters.current_*): n_chan entries each. */
+int gyp_bank_get_state(gyp_bank* bank, double* doppler_hz, double* carrier_phase, int32_t* code_phase,
+                       int32_t* lost);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GYPSUM_HIP_H */
