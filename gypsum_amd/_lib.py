@@ -29,7 +29,9 @@ TRACK_REC = np.dtype([("peak_re", "<f4"), ("peak_im", "<f4"), ("strength", "<f4"
                       ("doppler_hz", "<f8"), ("carrier_phase", "<f8"), ("error", "<f8"), ("code_phase", "<i4"),
                       ("peak_offset", "<i4"), ("pseudosymbol", "i1"), ("locked", "i1"), ("status", "i1"),
                       ("nudged", "i1"), ("reserved", "<i4")], align=True)
-RECORD_SIZES = {"gyp_cell_desc": 24, "gyp_cell": 32, "gyp_acq_result": 32, "gyp_chan_in": 32, "gyp_chan_out": 48,
+SYNTH_SAT = np.dtype([("sat_id", "<i4"), ("code_phase", "<i4"), ("doppler_hz", "<f8"), ("carrier_phase", "<f8"),
+                      ("amplitude", "<f4"), ("nav_bit_offset_ms", "<i4")], align=True)
+RECORD_SIZES = {"gyp_synth_sat": 32, "gyp_cell_desc": 24, "gyp_cell": 32, "gyp_acq_result": 32, "gyp_chan_in": 32, "gyp_chan_out": 48,
                 "gyp_track_rec": 56}
 
 EXPORTS = (
@@ -37,7 +39,7 @@ EXPORTS = (
     "gyp_timer_stop gyp_set_stream_format gyp_prn_chips gyp_prn_spectrum_lane_layout gyp_malloc gyp_free "
     "gyp_memcpy_h2d gyp_memcpy_d2h gyp_cell_strength gyp_correlate_cells_dev gyp_correlate_cells gyp_acquire_dev "
     "gyp_acquire gyp_track_step_dev gyp_track_step gyp_bank_create gyp_bank_destroy gyp_bank_size "
-    "gyp_track_block_dev gyp_track_block gyp_bank_get_state"
+    "gyp_track_block_dev gyp_track_block gyp_bank_get_state gyp_synth_iq_dev gyp_synth_nav_bit gyp_bank_reset_dev"
 ).split()
 
 
@@ -91,6 +93,9 @@ def load() -> C.CDLL:
         "gyp_track_block_dev": (C.c_int, [vp, vp, i64, i32, vp, vp]),
         "gyp_track_block": (C.c_int, [vp, vp, i32, i32, vp, vp]),
         "gyp_bank_get_state": (C.c_int, [vp, vp, vp, vp, vp]),
+        "gyp_bank_reset_dev": (C.c_int, [vp, vp]),
+        "gyp_synth_iq_dev": (C.c_int, [vp, vp, i32, i64, i32, vp, i32, C.c_float, u64]),
+        "gyp_synth_nav_bit": (C.c_int, [u64, i32, i32, i32, i64]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # AttributeError here == the library does not export what the header declares

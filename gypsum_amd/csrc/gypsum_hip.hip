@@ -106,6 +106,7 @@ struct gyp_ctx {
     int k = 0;
     cf* d_replicas = nullptr;  // [32][32][64]
     cf* d_tw = nullptr;        // tw1024[1024] ++ tw2048[1024]
+    uint8_t* d_chips = nullptr;  // [32][1023], synthetic generator only
     // growable scratch for the host-buffer entry points and the acquisition driver
     void* scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t scratch_cap[6] = {0, 0, 0, 0, 0, 0};
@@ -184,6 +185,7 @@ void gyp_destroy(gyp_ctx* ctx) {
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->d_replicas) (void)hipFree(ctx->d_replicas);
     if (ctx->d_tw) (void)hipFree(ctx->d_tw);
+    if (ctx->d_chips) (void)hipFree(ctx->d_chips);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -269,6 +271,8 @@ int gyp_set_stream_format(gyp_ctx* ctx, int64_t fs_hz, int32_t samples_per_ms) {
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tw, tw.size() * sizeof(float)));
         HIP_TRY(ctx, hipMemcpy(ctx->d_replicas, rep.data(), rep.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMemcpy(ctx->d_tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_chips, chips.size()));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_chips, chips.data(), chips.size(), hipMemcpyHostToDevice));
     }
     ctx->fs = fs_hz;
     ctx->n = samples_per_ms;
@@ -615,6 +619,15 @@ int gyp_track_block(gyp_bank* bank, const float* iq_host, int32_t n_streams, int
     return GYP_OK;
 }
 
+int gyp_bank_reset_dev(gyp_bank* bank, const gyp_chan_init* inits_dev) {
+    if (!bank) return GYP_E_BAD_ARG;
+    gyp_ctx* ctx = bank->ctx;
+    if (!inits_dev) return fail(ctx, GYP_E_BAD_ARG, "gyp_bank_reset_dev: bad argument");
+    hipLaunchKernelGGL(bank_reset_kernel, dim3((bank->n_chan + 63) / 64), dim3(64), 0, ctx->stream, bank->d_states, inits_dev, bank->n_chan);
+    HIP_TRY(ctx, hipGetLastError());
+    return GYP_OK;
+}
+
 int gyp_bank_get_state(gyp_bank* bank, double* doppler_hz, double* carrier_phase, int32_t* code_phase, int32_t* lost) {
     if (!bank) return GYP_E_BAD_ARG;
     gyp_ctx* ctx = bank->ctx;
@@ -628,6 +641,42 @@ int gyp_bank_get_state(gyp_bank* bank, double* doppler_hz, double* carrier_phase
         if (lost) lost[i] = host[i].lost;
     }
     return GYP_OK;
+}
+
+// ---------------------------------------------------------------- synthetic IQ ----------------------------
+int gyp_synth_iq_dev(gyp_ctx* ctx, float* out_dev, int32_t n_streams, int64_t stream_stride_samples, int32_t n_ms,
+                     const gyp_synth_sat* sats_host, int32_t n_sats, float noise_sigma, uint64_t seed) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    if (!ctx->k) return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
+    if (!out_dev || !sats_host || n_streams <= 0 || n_ms <= 0 || n_ms > 65535 || n_sats < 0)
+        return fail(ctx, GYP_E_BAD_ARG, "gyp_synth_iq_dev: bad argument (n_ms must be 1..65535)");
+    for (int i = 0; i < n_streams * n_sats; ++i)
+        if (sats_host[i].sat_id < 1 || sats_host[i].sat_id > 32 || sats_host[i].code_phase < 0 || sats_host[i].code_phase >= ctx->n)
+            return fail(ctx, GYP_E_BAD_ARG, "gyp_synth_iq_dev: satellite descriptor out of range");
+    int rc;
+    const size_t bytes = (size_t)std::max(1, n_streams * n_sats) * sizeof(gyp_synth_sat);
+    if ((rc = ensure_scratch(ctx, 1, bytes))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[1], sats_host, (size_t)n_streams * n_sats * sizeof(gyp_synth_sat), hipMemcpyHostToDevice, ctx->stream));
+    SynthParams p;
+    p.out = reinterpret_cast<cf*>(out_dev);
+    p.stream_stride = stream_stride_samples;
+    p.n_ms = n_ms;
+    p.n_per_ms = ctx->n;
+    p.k = ctx->k;
+    p.n_sats = n_sats;
+    p.sats = (const gyp_synth_sat*)ctx->scratch[1];
+    p.chips = ctx->d_chips;
+    p.sigma = noise_sigma;
+    p.seed = seed;
+    p.inv_fs = 1.0 / (double)ctx->fs;
+    hipLaunchKernelGGL(synth_iq_kernel, dim3((ctx->n + 255) / 256, n_ms, n_streams), dim3(256), 0, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // sats_host may be a temporary; scratch[1] is reused by other calls
+    return GYP_OK;
+}
+
+int gyp_synth_nav_bit(uint64_t seed, int32_t stream, int32_t sat_id, int32_t nav_bit_offset_ms, int64_t ms) {
+    return synth_nav_bit(seed, stream, sat_id, nav_bit_offset_ms, ms);
 }
 
 }  // extern "C"

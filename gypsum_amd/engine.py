@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (ACQ_RESULT, CELL, CELL_DESC, CHAN_IN, CHAN_INIT, CHAN_OUT, GYP_COHERENT, GYP_NON_COHERENT,
-                   TRACK_REC, GypsumHipError, ptr)
+                   SYNTH_SAT, TRACK_REC, GypsumHipError, ptr)
 
 
 def _as_iq(iq: np.ndarray) -> np.ndarray:
@@ -141,6 +141,23 @@ class GypsumEngine:
         self._check(self.lib.gyp_acquire(self.ctx, ptr(iq), n_streams, n_ms, ptr(ids), len(ids), ptr(out)))
         return out
 
+    def acquire_dev(self, iq_ptr: int, n_streams: int, stream_stride: int, n_ms: int, sat_ids: Sequence[int],
+                    out_ptr: int) -> None:
+        """Device-pointer form (asynchronous on the engine's stream): out_ptr receives n_streams*len(sat_ids) records."""
+        ids = np.ascontiguousarray(sat_ids, dtype=np.int32)
+        self._check(self.lib.gyp_acquire_dev(self.ctx, C.c_void_p(iq_ptr), n_streams, stream_stride, n_ms, ptr(ids),
+                                              len(ids), C.c_void_p(out_ptr)))
+
+    def synth_iq(self, out: "DeviceBuffer", n_streams: int, stream_stride: int, n_ms: int, sats: np.ndarray,
+                 noise_sigma: float, seed: int) -> None:
+        """Generate synthetic baseband straight into HBM (bench / test support). sats: SYNTH_SAT[n_streams, n_sats]."""
+        sats = np.ascontiguousarray(sats, dtype=SYNTH_SAT).reshape(n_streams, -1)
+        self._check(self.lib.gyp_synth_iq_dev(self.ctx, out.ptr, n_streams, stream_stride, n_ms, ptr(sats),
+                                               sats.shape[1], float(noise_sigma), int(seed)))
+
+    def synth_nav_bit(self, seed: int, stream: int, sat_id: int, offset_ms: int, ms: int) -> int:
+        return int(self.lib.gyp_synth_nav_bit(int(seed), stream, sat_id, offset_ms, ms))
+
     # ------------------------------------------------------------------ tracking
     def track_step(self, iq_1ms: np.ndarray, n_streams: int, start_times: Sequence[float], chans: np.ndarray,
                    want_profiles: bool = False) -> Tuple[np.ndarray, Optional[np.ndarray]]:
@@ -187,6 +204,9 @@ class ChannelBank:
         e = self.engine
         e._check(e.lib.gyp_track_block_dev(self.handle, C.c_void_p(iq_ptr), stream_stride, n_ms,
                                            C.c_void_p(start_times_ptr), C.c_void_p(rec_ptr or None)))
+
+    def reset_dev(self, inits_ptr: int) -> None:
+        self.engine._check(self.engine.lib.gyp_bank_reset_dev(self.handle, C.c_void_p(inits_ptr)))
 
     def state(self) -> Dict[str, np.ndarray]:
         f = np.zeros(self.n_chan)

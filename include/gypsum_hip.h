@@ -212,9 +212,33 @@ int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stri
                         const double* start_time_dev, gyp_track_rec* rec_out_dev);
 int gyp_track_block(gyp_bank* bank, const float* iq_host, int32_t n_streams, int32_t n_ms,
                     const double* start_time_host, gyp_track_rec* rec_out_host);
+/* Re-initialise every channel from n_chan device-resident gyp_chan_init records (same semantics as a fresh
+ * gyp_bank_create: histories cleared, DLL phase = code_phase).  Enqueued on the stream. */
+int gyp_bank_reset_dev(gyp_bank* bank, const gyp_chan_init* inits_dev);
 /* Read back the live estimates (GpsSatelliteTrackingParameters.current_*): n_chan entries each. */
 int gyp_bank_get_state(gyp_bank* bank, double* doppler_hz, double* carrier_phase, int32_t* code_phase,
                        int32_t* lost);
+
+/* ---------------------------------------------------------------- synthetic IQ (bench / test support) ---- */
+/* No recording ships with the reference (vendored_signals/ is git-ignored), so benchmarks run on synthetic
+ * baseband generated straight into HBM:  x[n] = sum_k a_k * code_k[(n - cp_k) mod N] * bit_k(n) *
+ * exp(1j*(2*pi*d_k*n/fs + phi_k)) + sigma*(N(0,1) + 1j*N(0,1)),  bit_k = +-1 per 20 ms from a counter hash
+ * (gyp_synth_nav_bit gives the same value on the host).  Noise is a counter-based hash + Box-Muller keyed by
+ * (seed, stream, n). */
+typedef struct gyp_synth_sat {
+    int32_t sat_id;        /* 1..32 */
+    int32_t code_phase;    /* samples, [0, N) */
+    double doppler_hz;
+    double carrier_phase;  /* radians */
+    float amplitude;
+    int32_t nav_bit_offset_ms;
+} gyp_synth_sat;
+
+/* out_dev: n_streams x n_ms x N samples (stream stride given); sats_host: n_streams x n_sats descriptors. */
+int gyp_synth_iq_dev(gyp_ctx* ctx, float* out_dev, int32_t n_streams, int64_t stream_stride_samples, int32_t n_ms,
+                     const gyp_synth_sat* sats_host, int32_t n_sats, float noise_sigma, uint64_t seed);
+/* +-1 data bit satellite `sat_id` of stream `stream` carries during millisecond `ms` (host mirror of the kernel). */
+int gyp_synth_nav_bit(uint64_t seed, int32_t stream, int32_t sat_id, int32_t nav_bit_offset_ms, int64_t ms);
 
 #ifdef __cplusplus
 }
