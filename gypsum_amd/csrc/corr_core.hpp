@@ -26,6 +26,14 @@ constexpr int kXchWaveBytes = kXchWave * 8;  // 17408 B per wavefront
 
 typedef float2 cf;
 
+// Hide a thread-id-derived value from the optimiser so that everything computed from it is re-derived where it
+// is used (a handful of integer instructions) instead of being hoisted out of the per-millisecond loop as a
+// loop invariant and then spilled: every scratch reload is a ~250-cycle stall in these latency-bound kernels.
+__device__ __forceinline__ int launder(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 __device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
 // a * b
@@ -195,10 +203,15 @@ __device__ __forceinline__ void wave_fft_inv(cf (&x)[32], cf (&c)[16], cf* xch_h
 __device__ __forceinline__ const cf* replica_column(const cf* __restrict__ table, int sat_index, int lane) {
     return table + (size_t)sat_index * 32 * 64 + lane;
 }
-// Multiply the spectrum held in registers by the replica (read through L1/L2: 32 coalesced 512-byte rows).
-__device__ __forceinline__ void spectrum_mul(cf (&x)[32], const cf* __restrict__ rep_column) {
+// Fetch this lane's 32 replica values (32 coalesced 512-byte rows, L1/L2 resident).  Issued before the forward
+// transform so the latency hides behind it.
+__device__ __forceinline__ void load_replica(cf (&p)[32], const cf* __restrict__ rep_column) {
 #pragma unroll
-    for (int i = 0; i < 32; ++i) x[i] = cmul(x[i], rep_column[64 * i]);
+    for (int i = 0; i < 32; ++i) p[i] = rep_column[64 * i];
+}
+__device__ __forceinline__ void spectrum_mul(cf (&x)[32], const cf (&p)[32]) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) x[i] = cmul(x[i], p[i]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -211,39 +224,110 @@ __device__ __forceinline__ cf carrier_from_cycles(double u) {
     return make_float2(c, -s);
 }
 
-// Wipe-off + polyphase pre-sum for one chip index m of one millisecond block.
-//   y_r[m] = sum_{j<K} x[(K*m + r + j) mod N] * carrier(K*m + r + j mod N),   r = 0..K-1
-// block: the N = K*1023 samples of this millisecond; u0: carrier cycles at sample 0 of the block;
-// du: cycles per sample (f / fs); rot1 = exp(-2*pi*i*du); rot_wrap = exp(+2*pi*i*du*N) for samples that wrap.
+// ---------------------------------------------------------------------------------------------------------
+// staging: carrier wipe-off + polyphase pre-sum,  global IQ -> LDS rows y_r[0..1022]
+//   y_r[m] = sum_{j<K} xw[(K*m + r + j) mod N],  xw[n] = x[n] * carrier(n),   r = 0..K-1
+// Thread t owns chips m = t + c*T (T = 64*K threads, c < CH).  For each chip it needs its own K samples and
+// the first K-1 samples of the next chip ((m+1) mod 1023).  All global loads of all CH chips are issued
+// before the first use (one exposed memory latency per millisecond) and are 16-byte vectors where possible.
+// ---------------------------------------------------------------------------------------------------------
+template <int C>
+__device__ __forceinline__ void load_samples(const cf* __restrict__ p, cf* dst) {  // p 16-B aligned when C >= 2
+#pragma unroll
+    for (int i = 0; i + 1 < C; i += 2) {
+        const float4 v = *reinterpret_cast<const float4*>(p + i);
+        dst[i] = make_float2(v.x, v.y);
+        dst[i + 1] = make_float2(v.z, v.w);
+    }
+    if (C & 1) dst[C - 1] = p[C - 1];
+}
+
 template <int K>
-__device__ __forceinline__ void stage_chip(const cf* __restrict__ block, int m, double u0, double du, cf rot1,
-                                           cf rot_wrap, cf* (&y_rows)[K]) {
-    constexpr int N = K * kChips;
+struct StageRaw {
+    static constexpr int T = 64 * K;
+    static constexpr int CH = (kChips + T - 1) / T;
+    cf own[CH][K];
+    cf nxt[CH][K > 1 ? K - 1 : 1];
+};
+
+template <int K>
+__device__ __forceinline__ void stage_load(StageRaw<K>& raw, const cf* __restrict__ block, int tid) {
+#pragma unroll
+    for (int c = 0; c < StageRaw<K>::CH; ++c) {
+        const int m = tid + c * StageRaw<K>::T;
+        if (m < kChips) {
+            load_samples<K>(block + K * m, raw.own[c]);
+            const int mn = (m + 1 == kChips) ? 0 : m + 1;
+            if (K > 1) load_samples<K - 1>(block + K * mn, raw.nxt[c]);
+        }
+    }
+}
+
+// u0: carrier cycles at sample 0 of the block; du: cycles per sample (f / fs).
+template <int K>
+__device__ __forceinline__ void stage_compute(const StageRaw<K>& raw, double u0, double du, cf* (&y_rows)[K], int tid) {
     constexpr int S = 2 * K - 1;
-    cf xs[S];
-    const int n0 = K * m;
+    const cf rot1 = carrier_from_cycles(du);                          // exp(-2*pi*i*du)
+    const cf rwc = carrier_from_cycles(du * (double)(K * kChips));
+    const cf rot_wrap = make_float2(rwc.x, -rwc.y);                   // exp(+2*pi*i*du*N): samples that wrapped
 #pragma unroll
-    for (int i = 0; i < S; ++i) {
-        int idx = n0 + i;
-        idx = idx >= N ? idx - N : idx;
-        xs[i] = block[idx];
+    for (int c = 0; c < StageRaw<K>::CH; ++c) {
+        const int m = tid + c * StageRaw<K>::T;
+        if (m < kChips) {
+            cf car = carrier_from_cycles(u0 + du * (double)(K * m));
+            cf pre[S + 1];
+            pre[0] = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                pre[i + 1] = cadd(pre[i], cmul(raw.own[c][i], car));
+                car = cmul(car, rot1);
+            }
+            if (K > 1) {
+                if (m + 1 == kChips) car = cmul(car, rot_wrap);
+#pragma unroll
+                for (int i = 0; i < K - 1; ++i) {
+                    pre[K + i + 1] = cadd(pre[K + i], cmul(raw.nxt[c][i], car));
+                    car = cmul(car, rot1);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < K; ++r) y_rows[r][m] = csub(pre[r + K], pre[r]);
+        }
     }
-    cf car = carrier_from_cycles(u0 + du * (double)n0);
-    cf pre[S + 1];
-    pre[0] = make_float2(0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < S; ++i) {
-        cf cw = (n0 + i >= N) ? cmul(car, rot_wrap) : car;
-        pre[i + 1] = cadd(pre[i], cmul(xs[i], cw));
-        car = cmul(car, rot1);
-    }
-#pragma unroll
-    for (int r = 0; r < K; ++r) y_rows[r][m] = csub(pre[r + K], pre[r]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// reductions
+// wavefront reductions on the DPP network (no LDS traffic): all-reduce inside each row of 16 lanes with
+// quad_perm / row_half_mirror / row_mirror, then the four row results are combined through v_readlane.
 // ---------------------------------------------------------------------------------------------------------
+constexpr int kDppXor1 = 0xB1;         // quad_perm:[1,0,3,2]
+constexpr int kDppXor2 = 0x4E;         // quad_perm:[2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;  // row_half_mirror
+constexpr int kDppMirror = 0x140;      // row_mirror
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return (int)__builtin_amdgcn_update_dpp(0u, (unsigned)v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)__double2loint(v), CTRL, 0xF, 0xF, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)__double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double((int)hi, (int)lo);
+}
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane));
+}
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
 struct Best {
     float v;
     int key;  // tie-break: smaller key wins
@@ -251,25 +335,39 @@ struct Best {
 __device__ __forceinline__ Best better(Best a, Best b) {
     return (b.v > a.v || (b.v == a.v && b.key < a.key)) ? b : a;
 }
+template <int CTRL>
+__device__ __forceinline__ Best best_step(Best b) {
+    Best o;
+    o.v = dpp_f<CTRL>(b.v);
+    o.key = dpp_i<CTRL>(b.key);
+    return better(b, o);
+}
+// result is uniform across the wavefront
 __device__ __forceinline__ Best wave_best(Best b) {
+    b = best_step<kDppXor1>(b);
+    b = best_step<kDppXor2>(b);
+    b = best_step<kDppHalfMirror>(b);
+    b = best_step<kDppMirror>(b);
+    Best r{readlane_f(b.v, 0), __builtin_amdgcn_readlane(b.key, 0)};
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        Best o;
-        o.v = __shfl_xor(b.v, off);
-        o.key = __shfl_xor(b.key, off);
-        b = better(b, o);
-    }
-    return b;
+    for (int row = 1; row < 4; ++row)
+        r = better(r, Best{readlane_f(b.v, 16 * row), __builtin_amdgcn_readlane(b.key, 16 * row)});
+    return r;
 }
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    v += dpp_d<kDppXor1>(v);
+    v += dpp_d<kDppXor2>(v);
+    v += dpp_d<kDppHalfMirror>(v);
+    v += dpp_d<kDppMirror>(v);
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
 __device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    v += dpp_i<kDppXor1>(v);
+    v += dpp_i<kDppXor2>(v);
+    v += dpp_i<kDppHalfMirror>(v);
+    v += dpp_i<kDppMirror>(v);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
+           (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
 
 }  // namespace gyp

@@ -107,6 +107,7 @@ struct gyp_ctx {
     cf* d_replicas = nullptr;  // [32][32][64]
     cf* d_tw = nullptr;        // tw1024[1024] ++ tw2048[1024]
     uint8_t* d_chips = nullptr;  // [32][1023], synthetic generator only
+    long long* d_prof = nullptr; // debug: per-phase cycle counters of track_block workgroup 0
     // growable scratch for the host-buffer entry points and the acquisition driver
     void* scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t scratch_cap[6] = {0, 0, 0, 0, 0, 0};
@@ -186,6 +187,7 @@ void gyp_destroy(gyp_ctx* ctx) {
     if (ctx->d_replicas) (void)hipFree(ctx->d_replicas);
     if (ctx->d_tw) (void)hipFree(ctx->d_tw);
     if (ctx->d_chips) (void)hipFree(ctx->d_chips);
+    if (ctx->d_prof) (void)hipFree(ctx->d_prof);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -594,6 +596,7 @@ int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stri
     p.tw_tables = ctx->d_tw;
     p.inv_fs = 1.0 / (double)ctx->fs;
     p.fs = (double)ctx->fs;
+    p.prof = ctx->d_prof;
     return launch_track_block(ctx, p);
 }
 
@@ -672,6 +675,20 @@ int gyp_synth_iq_dev(gyp_ctx* ctx, float* out_dev, int32_t n_streams, int64_t st
     hipLaunchKernelGGL(synth_iq_kernel, dim3((ctx->n + 255) / 256, n_ms, n_streams), dim3(256), 0, ctx->stream, p);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // sats_host may be a temporary; scratch[1] is reused by other calls
+    return GYP_OK;
+}
+
+int gyp_debug_track_profile(gyp_ctx* ctx, int enable, long long* out8) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    if (enable && !ctx->d_prof) {
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_prof, 8 * sizeof(long long)));
+        HIP_TRY(ctx, hipMemset(ctx->d_prof, 0, 8 * sizeof(long long)));
+    }
+    if (out8 && ctx->d_prof) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(out8, ctx->d_prof, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    }
+    if (!enable && ctx->d_prof) { HIP_TRY(ctx, hipFree(ctx->d_prof)); ctx->d_prof = nullptr; }
     return GYP_OK;
 }
 

@@ -20,18 +20,23 @@ namespace gyp {
 // shared-memory carve (dynamic LDS, 16-byte aligned base, all offsets multiples of 16)
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kTablesBytes = 2 * 1024 * 8;  // tw1024 + tw2048
-constexpr int kRedBytes = 512;
+constexpr int kRedBytes = 768;
 template <int K>
 constexpr int lds_bytes() { return kTablesBytes + K * kXchWaveBytes + kRedBytes; }
 
+struct WaveCand {   // one wavefront's candidate for the profile maximum
+    float v;
+    int key;
+    float re, im;   // complex correlation value at the candidate
+    double sum;     // sum of the wavefront's magnitudes
+    int cnt;        // elements equal to the wavefront's maximum
+    int pad;
+};
 struct RedScratch {
-    Best best[16];
-    double sum[16];
-    int cnt[16];
-    // track kernels
-    float taps[4];
-    double bcast[4];
-    int ibcast[4];
+    WaveCand cand[16];
+    float taps[4];      // early re/im, late re/im
+    double dstate[4];   // new doppler, new carrier phase
+    int istate[4];      // new code phase, lost flag
 };
 static_assert(sizeof(RedScratch) <= kRedBytes, "reduction scratch too large");
 
@@ -56,17 +61,17 @@ __device__ __forceinline__ Smem carve_smem(char* base, const cf* __restrict__ tw
 // One millisecond of one cell/channel: stage (all waves) -> barrier -> per-wave correlation.
 // Returns c[j]: complex correlation at lag index k = K*(l + 32*(j + 16*h)) + wave.
 template <int K>
-__device__ __forceinline__ void correlate_ms(const cf* __restrict__ block, double u0, double du, const Smem& sm,
-                                             const cf* __restrict__ rep, cf (&c)[16]) {
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
+__device__ __forceinline__ void correlate_ms(const StageRaw<K>& raw, double u0, double du, const Smem& sm,
+                                             const cf* __restrict__ rep_table_sat, cf (&c)[16]) {
+    const int tid = launder(threadIdx.x), wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
+    const cf* rep_column = rep_table_sat + lane;
     cf* y_rows[K];
 #pragma unroll
     for (int r = 0; r < K; ++r) y_rows[r] = sm.xch + r * kXchWave;
-    const cf rot1 = carrier_from_cycles(du);
-    const cf rw = carrier_from_cycles(du * (double)(K * kChips));
-    const cf rot_wrap = make_float2(rw.x, -rw.y);
-    for (int m = tid; m < kChips; m += 64 * K) stage_chip<K>(block, m, u0, du, rot1, rot_wrap, y_rows);
+    stage_compute<K>(raw, u0, du, y_rows, tid);
     if (tid < K) y_rows[tid][kChips] = make_float2(0.f, 0.f);
+    cf rep[32];
+    load_replica(rep, rep_column);   // in flight during the barrier and the forward transform
     __syncthreads();
     cf x[32];
     const cf* yw = y_rows[wave];
@@ -76,66 +81,79 @@ __device__ __forceinline__ void correlate_ms(const cf* __restrict__ block, doubl
     cf* xch_half = sm.xch + wave * kXchWave + h * kXchHalf;
     const LdsTables t{sm.tw1024, sm.tw2048};
     wave_fft_fwd(x, xch_half, t, l, h);
-    spectrum_mul(x, rep);  // rep already points at this lane's column: 32 coalesced 512-B rows, L1/L2 resident
+    spectrum_mul(x, rep);
     wave_fft_inv(x, c, xch_half, t, l, h);
 }
 
 // lag index of output slot j of this lane, or -1 for the one padding slot (q == 1023)
 template <int K>
-__device__ __forceinline__ int lag_index(int j) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ int lag_index(int j, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
     const int q = (lane & 31) + 32 * (j + 16 * (lane >> 5));
     return q < kChips ? K * q + wave : -1;
 }
 
 struct ProfileStats {
-    Best best;   // max value + key
+    Best best;   // max value + key of the winner
+    cf peak;     // complex value at the winner (0 if no complex values were given)
     double sum;
     int n_max;
 };
 
-// Workgroup-wide max / first-argmax (by key) / sum / count-of-max over vals[16] of every lane.
-// key_of(idx) orders ties (lowest key wins); result valid in every thread.
+// Workgroup-wide max / first-argmax (by key) / complex value there / sum / count-of-max over vals[16] of every
+// lane, with ONE workgroup barrier.  key_of(idx) orders ties (lowest key wins).  Result valid in every thread.
 template <int K, typename KeyFn>
-__device__ __forceinline__ ProfileStats profile_stats(const float (&vals)[16], RedScratch* red, KeyFn key_of) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+__device__ __forceinline__ ProfileStats profile_stats(const float (&vals)[16], const cf* cvals, RedScratch* red,
+                                                      KeyFn key_of) {
+    const int tid = launder(threadIdx.x);
+    const int wave = tid >> 6;
     Best b{-1.0f, 0x7fffffff};
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int idx = lag_index<K>(j);
-        if (idx >= 0) b = better(b, Best{vals[j], key_of(idx)});
-    }
-    b = wave_best(b);
-    if (lane == 0) red->best[wave] = b;
-    __syncthreads();
-    Best g = red->best[0];
-#pragma unroll
-    for (int w = 1; w < K; ++w) g = better(g, red->best[w]);
     float part = 0.f;
-    int cnt = 0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        if (lag_index<K>(j) >= 0) {
+        const int idx = lag_index<K>(j, tid);
+        if (idx >= 0) {
+            b = better(b, Best{vals[j], key_of(idx)});
             part += vals[j];
-            cnt += (vals[j] == g.v) ? 1 : 0;
+        }
+    }
+    const Best wb = wave_best(b);
+    int cnt = 0;
+    cf mine = make_float2(0.f, 0.f);
+    bool owner = false;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int idx = lag_index<K>(j, tid);
+        if (idx >= 0) {
+            cnt += (vals[j] == wb.v) ? 1 : 0;
+            if (key_of(idx) == wb.key) {
+                owner = true;
+                if (cvals) mine = cvals[j];
+            }
         }
     }
     const double s = wave_sum((double)part);
     cnt = wave_sum(cnt);
-    if (lane == 0) {
-        red->sum[wave] = s;
-        red->cnt[wave] = cnt;
+    if (owner) {
+        WaveCand wc;
+        wc.v = wb.v; wc.key = wb.key; wc.re = mine.x; wc.im = mine.y; wc.sum = s; wc.cnt = cnt; wc.pad = 0;
+        red->cand[wave] = wc;
     }
     __syncthreads();
     ProfileStats st;
-    st.best = g;
-    st.sum = 0.0;
+    WaveCand g = red->cand[0];
+    st.sum = g.sum;
+#pragma unroll
+    for (int w = 1; w < K; ++w) {
+        const WaveCand o = red->cand[w];
+        st.sum += o.sum;
+        if (o.v > g.v || (o.v == g.v && o.key < g.key)) g = o;
+    }
     st.n_max = 0;
 #pragma unroll
-    for (int w = 0; w < K; ++w) {
-        st.sum += red->sum[w];
-        st.n_max += red->cnt[w];
-    }
+    for (int w = 0; w < K; ++w) st.n_max += (red->cand[w].v == g.v) ? red->cand[w].cnt : 0;
+    st.best = Best{g.v, g.key};
+    st.peak = make_float2(g.re, g.im);
     return st;
 }
 
@@ -165,7 +183,7 @@ __global__ __launch_bounds__(64 * K, 2) void corr_cells_kernel(CellsParams p) {
     for (int cell = blockIdx.x; cell < p.n_cells; cell += gridDim.x) {
         const gyp_cell_desc d = p.cells[cell];
         if (d.sat_id < 1 || d.sat_id > 32) continue;  // padding cell (uniform across the workgroup)
-        const cf* rep = replica_column(p.replica_table, d.sat_id - 1, lane);
+        const cf* rep = replica_column(p.replica_table, d.sat_id - 1, 0);
         const double du = d.doppler_hz * p.inv_fs;
         const cf* stream = p.iq + (int64_t)d.stream * p.stream_stride;
         float mag[16];
@@ -175,48 +193,43 @@ __global__ __launch_bounds__(64 * K, 2) void corr_cells_kernel(CellsParams p) {
             mag[j] = 0.f;
             acc[j] = make_float2(0.f, 0.f);
         }
+        StageRaw<K> raw;
+        stage_load<K>(raw, stream, launder(threadIdx.x));
         for (int ms = 0; ms < p.n_ms; ++ms) {
             // utils.py:92-96: t = arange(N)/fs + (i*N)/fs ; carrier = exp(-1j*tau*f*t)
             const double u0 = d.doppler_hz * ((double)((int64_t)ms * N) * p.inv_fs);
             cf c[16];
-            correlate_ms<K>(stream + (int64_t)ms * N, u0, du, sm, rep, c);
+            correlate_ms<K>(raw, u0, du, sm, rep, c);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 if (COHERENT) acc[j] = cadd(acc[j], c[j]);
                 else mag[j] += sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
             }
+            if (ms + 1 < p.n_ms) stage_load<K>(raw, stream + (int64_t)(ms + 1) * N, launder(threadIdx.x));   // in flight across the barrier
             __syncthreads();  // every wave is done with the exchange tiles before the next block is staged
         }
         if (COHERENT) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) mag[j] = sqrtf(fmaf(acc[j].x, acc[j].x, acc[j].y * acc[j].y));
         }
-        const ProfileStats st = profile_stats<K>(mag, sm.red, [](int idx) { return idx; });
+        const ProfileStats st = profile_stats<K>(mag, nullptr, sm.red, [](int idx) { return idx; });
+        const int tid = launder(threadIdx.x);
         if (threadIdx.x == 0) {
-            gyp_cell o;
-            o.peak = st.best.v;
-            o.argmax = st.best.key;
-            o.sum = st.sum;
-            o.n_max = st.n_max;
-            o.reserved = 0;
-            o.tap_re = 0.f;
-            o.tap_im = 0.f;
-            if (d.tap_index < 0) p.out[cell] = o;
-            else {  // the lane that owns the tap fills tap_re / tap_im below
-                p.out[cell].peak = o.peak;
-                p.out[cell].argmax = o.argmax;
-                p.out[cell].sum = o.sum;
-                p.out[cell].n_max = o.n_max;
-                p.out[cell].reserved = 0;
-            }
+            gyp_cell* o = p.out + cell;
+            o->peak = st.best.v;
+            o->argmax = st.best.key;
+            o->sum = st.sum;
+            o->n_max = st.n_max;
+            o->reserved = 0;
+            if (d.tap_index < 0 || !COHERENT) { o->tap_re = 0.f; o->tap_im = 0.f; }
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const int idx = lag_index<K>(j);
+            const int idx = lag_index<K>(j, tid);
             if (idx >= 0) {
-                if (idx == d.tap_index) {  // complex taps exist for coherent integration only
-                    p.out[cell].tap_re = COHERENT ? acc[j].x : 0.f;
-                    p.out[cell].tap_im = COHERENT ? acc[j].y : 0.f;
+                if (COHERENT && idx == d.tap_index) {  // complex taps exist for coherent integration only
+                    p.out[cell].tap_re = acc[j].x;
+                    p.out[cell].tap_im = acc[j].y;
                 }
                 if (p.profile_out) {
                     if (COHERENT) {  // complex integrated profile, interleaved re,im
@@ -254,40 +267,39 @@ __device__ __forceinline__ int mod_n(int v, int n) {
 
 // E/P/L of one millisecond given the un-rolled correlation c0:
 //   early = c0[(s-1) mod N], late = c0[(s+1) mod N], prompt profile[k] = c0[(s+k) mod N].
-template <int K>
 struct EplResult {
     cf early, late, peak;
-    ProfileStats st;  // best.key = peak offset in the rolled profile
+    Best best;   // best.key = peak offset in the rolled profile, best.v = |peak|
+    double sum;
+    int n_max;
 };
 
 template <int K>
-__device__ __forceinline__ EplResult<K> epl_from_c0(const cf (&c)[16], int code_phase, RedScratch* red,
-                                                   float* profile_row) {
+__device__ __forceinline__ EplResult epl_from_c0(const cf (&c)[16], int code_phase, RedScratch* red,
+                                                float* profile_row) {
     constexpr int N = K * kChips;
     const int s = mod_n(code_phase, N);
     const int ie = mod_n(s - 1, N), il = mod_n(s + 1, N);
+    const int tid = launder(threadIdx.x);
     float mag[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) mag[j] = sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
-    const ProfileStats st = profile_stats<K>(mag, red, [s](int idx) { int k = idx - s; return k < 0 ? k + N : k; });
-    const int ipk = mod_n(st.best.key + s, N);
-    // the owners of the three taps publish them (st's second barrier already separates this from the reads above)
-#pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const int idx = lag_index<K>(j);
-        if (idx >= 0) {
+        mag[j] = sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
+        const int idx = lag_index<K>(j, tid);
+        if (idx >= 0) {   // the owners of the early / late taps publish them ahead of the reduction barrier
             if (idx == ie) { red->taps[0] = c[j].x; red->taps[1] = c[j].y; }
             if (idx == il) { red->taps[2] = c[j].x; red->taps[3] = c[j].y; }
-            if (idx == ipk) { red->bcast[0] = (double)c[j].x; red->bcast[1] = (double)c[j].y; }
             if (profile_row) { int k = idx - s; profile_row[k < 0 ? k + N : k] = mag[j]; }
         }
     }
-    __syncthreads();
-    EplResult<K> r;
+    const ProfileStats st = profile_stats<K>(mag, c, red, [s](int idx) { int k = idx - s; return k < 0 ? k + N : k; });
+    EplResult r;
     r.early = make_float2(red->taps[0], red->taps[1]);
     r.late = make_float2(red->taps[2], red->taps[3]);
-    r.peak = make_float2((float)red->bcast[0], (float)red->bcast[1]);
-    r.st = st;
+    r.peak = st.peak;
+    r.best = st.best;
+    r.sum = st.sum;
+    r.n_max = st.n_max;
     return r;
 }
 
@@ -300,23 +312,25 @@ __global__ __launch_bounds__(64 * K, 2) void track_step_kernel(TrackStepParams p
     __syncthreads();
     for (int ch = blockIdx.x; ch < p.n_chan; ch += gridDim.x) {
         const gyp_chan_in in = p.chans[ch];
-        const cf* rep = replica_column(p.replica_table, in.sat_id - 1, lane);
+        const cf* rep = replica_column(p.replica_table, in.sat_id - 1, 0);
         // tracker.py:271-281: carrier = exp(-1j*(2*pi*f*t + phi)), t = n/fs + chunk.start_time
         const double du = in.doppler_hz * p.inv_fs;
         const double u0 = in.doppler_hz * p.start_time[in.stream] + in.carrier_phase * 0.15915494309189533577;
+        StageRaw<K> raw;
+        stage_load<K>(raw, p.iq + (int64_t)in.stream * p.stream_stride, launder(threadIdx.x));
         cf c[16];
-        correlate_ms<K>(p.iq + (int64_t)in.stream * p.stream_stride, u0, du, sm, rep, c);
-        const EplResult<K> r = epl_from_c0<K>(c, in.code_phase, sm.red,
-                                              p.profile_out ? p.profile_out + (int64_t)ch * N : nullptr);
+        correlate_ms<K>(raw, u0, du, sm, rep, c);
+        const EplResult r = epl_from_c0<K>(c, in.code_phase, sm.red,
+                                           p.profile_out ? p.profile_out + (int64_t)ch * N : nullptr);
         if (threadIdx.x == 0) {
             gyp_chan_out o;
             o.early_re = r.early.x; o.early_im = r.early.y;
             o.late_re = r.late.x; o.late_im = r.late.y;
             o.peak_re = r.peak.x; o.peak_im = r.peak.y;
-            o.peak_mag = r.st.best.v;
-            o.peak_offset = r.st.best.key;
-            o.sum = r.st.sum;
-            o.n_max = r.st.n_max;
+            o.peak_mag = r.best.v;
+            o.peak_offset = r.best.key;
+            o.sum = r.sum;
+            o.n_max = r.n_max;
             o.reserved = 0;
             p.out[ch] = o;
         }
@@ -329,6 +343,17 @@ __global__ __launch_bounds__(64 * K, 2) void track_step_kernel(TrackStepParams p
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kLockWindow = 250;    // config.py:23
 constexpr int kPeakHistory = 1000;  // tracker.py:146 (deque maxlen)
+constexpr int kLockRefresh = 1024;  // exact two-pass recomputation of the sliding sums every this many ms
+
+// Sliding-window sums behind is_locked() (tracker.py:157-203): the last 250 Costas errors and the last 250 prompt
+// peaks split by the sign of I.  Updated in O(1) per millisecond; re-derived exactly (two-pass, like np.var) every
+// kLockRefresh ms and whenever a comparison lands within 1e-9 (relative) of its threshold.
+struct LockSums {
+    double se, see;                  // sum e, sum e^2
+    double nr, ni, nrr;              // negative pole: sum re, sum im, sum re^2
+    double pr, prr;                  // positive pole: sum re, sum re^2
+    int32_t cn, cp;                  // pole populations
+};
 
 struct ChanState {
     int32_t stream, sat_id;
@@ -338,6 +363,7 @@ struct ChanState {
     int64_t n_steps;                 // milliseconds processed (== entries ever appended to the histories)
     int32_t code_phase;              // current_prn_code_phase_shift
     int32_t lost;
+    LockSums sums;
     double err_ring[kLockWindow];    // carrier_wave_phase_errors, last 250
     double peak_re[kPeakHistory];    // correlation_peaks_rolling_buffer
     double peak_im[kPeakHistory];
@@ -350,64 +376,94 @@ __device__ __forceinline__ double pymod(double a, double b) {
     return r;
 }
 
-// tracker.py:157-203 is_locked(), evaluated by wavefront 0 (all 64 lanes participate, result uniform).
-// n_err: number of errors appended so far (window = previous 250); n_peaks: peaks appended so far (including
-// the current one); rings are indexed by (count % size).
-__device__ __forceinline__ bool is_locked_wave(const ChanState* st, int64_t n_err, int64_t n_peaks, int lane) {
-    if (n_err < kLockWindow) return false;
-    const int e_newest = (int)((n_err - 1) % kLockWindow), p_newest = (int)((n_peaks - 1) % kPeakHistory);
+struct LockVerdict {
+    bool locked;
+    bool marginal;   // some comparison was too close to its threshold to trust one-pass arithmetic
+};
+
+__device__ __forceinline__ bool near(double v, double thr) { return fabs(v - thr) <= 1e-9 * thr; }
+
+// is_locked() from the sliding sums (any lane; pure scalar math).
+__device__ __forceinline__ LockVerdict lock_from_sums(const LockSums& s, int64_t n_err) {
+    LockVerdict out{false, false};
+    if (n_err < kLockWindow) return out;                       // tracker.py:164-167
+    const double me = s.se / kLockWindow;
+    const double ve = s.see / kLockWindow - me * me;
+    const double vneg = s.cn >= 2 ? s.nrr / s.cn - (s.nr / s.cn) * (s.nr / s.cn) : 0.0;
+    const double vpos = s.cp >= 2 ? s.prr / s.cp - (s.pr / s.cp) * (s.pr / s.cp) : 0.0;
+    const double iv = (vneg + vpos) / 2.0;
+    const bool var_ok = ve < 900.0, i_ok = iv < 2.0;
+    out.marginal = near(ve, 900.0) || near(iv, 2.0);
+    bool rot_ok = true;
+    if (var_ok && i_ok) {
+        const double mr = s.cn >= 2 ? s.nr / s.cn : 0.0, mi = s.cn >= 2 ? s.ni / s.cn : 0.0;
+        const double ang = 180.0 - pymod((atan2(mi, mr) / 6.283185307179586) * 360.0, 180.0);
+        const double centered = ang < 90.0 ? ang : 180.0 - ang;
+        rot_ok = centered < 6.0;                               // abs(bool) quirk, tracker.py:197
+        out.marginal = out.marginal || near(centered, 6.0);
+    }
+    out.locked = var_ok && i_ok && rot_ok;
+    return out;
+}
+
+// Exact (two-pass) evaluation of tracker.py:157-203 by one whole wavefront; also returns the freshly summed
+// LockSums so the sliding sums can be re-based.  n_err: errors appended so far (window = the last 250 of them);
+// n_peaks: peaks appended so far, the current one included.
+__device__ __forceinline__ bool is_locked_exact_wave(const ChanState* st, int64_t n_err, int64_t n_peaks, int lane,
+                                                     LockSums& fresh) {
+    const int e_newest = (int)((n_err - 1 + kLockWindow) % kLockWindow), p_newest = (int)((n_peaks - 1) % kPeakHistory);
+    const int ne = (int)(n_err < kLockWindow ? n_err : kLockWindow);
+    const int np = (int)(n_peaks < kLockWindow ? n_peaks : kLockWindow);
     double e[4], pr[4], pi[4];
-    bool ev[4];
-    double se = 0.0, sneg_re = 0.0, sneg_im = 0.0, spos_re = 0.0;
-    int cneg = 0, cpos = 0;
+    bool ev[4], pv[4];
+    double se = 0.0, see = 0.0, nr = 0.0, ni = 0.0, nrr = 0.0, prs = 0.0, prr = 0.0;
+    int cn = 0, cp = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = lane + 64 * i;  // k-th most recent (0 = newest)
-        ev[i] = k < kLockWindow;
+        ev[i] = k < ne;
+        pv[i] = k < np;
         const int ie = (e_newest - k + 2 * kLockWindow) % kLockWindow;
         const int ip = (p_newest - k + kPeakHistory) % kPeakHistory;
         e[i] = ev[i] ? st->err_ring[ie] : 0.0;
-        pr[i] = ev[i] ? st->peak_re[ip] : 0.0;
-        pi[i] = ev[i] ? st->peak_im[ip] : 0.0;
+        pr[i] = pv[i] ? st->peak_re[ip] : 0.0;
+        pi[i] = pv[i] ? st->peak_im[ip] : 0.0;
         se += e[i];
-        if (ev[i]) {
-            if (pr[i] < 0.0) { sneg_re += pr[i]; sneg_im += pi[i]; ++cneg; }
-            else { spos_re += pr[i]; ++cpos; }
+        see += e[i] * e[i];
+        if (pv[i]) {
+            if (pr[i] < 0.0) { nr += pr[i]; ni += pi[i]; nrr += pr[i] * pr[i]; ++cn; }
+            else { prs += pr[i]; prr += pr[i] * pr[i]; ++cp; }
         }
     }
-    se = wave_sum(se);
-    sneg_re = wave_sum(sneg_re);
-    sneg_im = wave_sum(sneg_im);
-    spos_re = wave_sum(spos_re);
-    cneg = wave_sum(cneg);
-    cpos = wave_sum(cpos);
-    const double mean_e = se / kLockWindow;
-    const double mneg_re = cneg >= 2 ? sneg_re / cneg : 0.0, mneg_im = cneg >= 2 ? sneg_im / cneg : 0.0;
-    const double mneg_only_re = cneg > 0 ? sneg_re / cneg : 0.0;
-    const double mpos_re = cpos > 0 ? spos_re / cpos : 0.0;
+    fresh.se = wave_sum(se); fresh.see = wave_sum(see);
+    fresh.nr = wave_sum(nr); fresh.ni = wave_sum(ni); fresh.nrr = wave_sum(nrr);
+    fresh.pr = wave_sum(prs); fresh.prr = wave_sum(prr);
+    fresh.cn = wave_sum(cn); fresh.cp = wave_sum(cp);
+    if (n_err < kLockWindow) return false;
+    const double mean_e = fresh.se / kLockWindow;
+    const double mneg = fresh.cn > 0 ? fresh.nr / fresh.cn : 0.0, mpos = fresh.cp > 0 ? fresh.pr / fresh.cp : 0.0;
     double ve = 0.0, vneg = 0.0, vpos = 0.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        if (ev[i]) {
-            const double d = e[i] - mean_e;
-            ve += d * d;
-            if (pr[i] < 0.0) { const double q = pr[i] - mneg_only_re; vneg += q * q; }
-            else { const double q = pr[i] - mpos_re; vpos += q * q; }
+        if (ev[i]) { const double d = e[i] - mean_e; ve += d * d; }
+        if (pv[i]) {
+            if (pr[i] < 0.0) { const double q = pr[i] - mneg; vneg += q * q; }
+            else { const double q = pr[i] - mpos; vpos += q * q; }
         }
     }
     ve = wave_sum(ve) / kLockWindow;
-    vneg = cneg >= 2 ? wave_sum(vneg) / cneg : (wave_sum(vneg), 0.0);
-    vpos = cpos >= 2 ? wave_sum(vpos) / cpos : (wave_sum(vpos), 0.0);
-    const bool var_ok = ve < 900.0;                       // config.py:25
-    const bool i_ok = (vneg + vpos) / 2.0 < 2.0;          // tracker.py:188
-    const double ang = 180.0 - pymod((atan2(mneg_im, mneg_re) / 6.283185307179586) * 360.0, 180.0);
+    vneg = wave_sum(vneg);
+    vpos = wave_sum(vpos);
+    vneg = fresh.cn >= 2 ? vneg / fresh.cn : 0.0;
+    vpos = fresh.cp >= 2 ? vpos / fresh.cp : 0.0;
+    const double mr = fresh.cn >= 2 ? fresh.nr / fresh.cn : 0.0, mi = fresh.cn >= 2 ? fresh.ni / fresh.cn : 0.0;
+    const double ang = 180.0 - pymod((atan2(mi, mr) / 6.283185307179586) * 360.0, 180.0);
     const double centered = ang < 90.0 ? ang : 180.0 - ang;
-    const bool rot_ok = centered < 6.0;                   // abs(bool) quirk, tracker.py:197
-    return var_ok && i_ok && rot_ok;
+    return ve < 900.0 && (vneg + vpos) / 2.0 < 2.0 && centered < 6.0;
 }
 
 // utils.py:134-144 circularity and :119-131 rotation over the last min(n_peaks, 1000) peaks, by wavefront 0.
-// Returns via out[0] = circularity (or -1 if < 2 peaks), out[1] = rotation in degrees, out[2] = 1 if rotation valid.
+// out[0] = circularity (or -1 if < 2 peaks), out[1] = rotation in degrees, out[2] = 1 if rotation valid.
 __device__ __forceinline__ void constellation_stats_wave(const ChanState* st, int64_t n_peaks, int lane, double (&out)[3]) {
     const int n = (int)(n_peaks < kPeakHistory ? n_peaks : kPeakHistory);
     double sr = 0.0, si = 0.0, lr = 0.0, li = 0.0;
@@ -448,7 +504,14 @@ struct TrackBlockParams {
     const cf* tw_tables;
     double inv_fs;
     double fs;
+    long long* prof;           // optional: per-phase cycle counters of workgroup 0 (debug)
 };
+
+__device__ __forceinline__ void workgroup_mem_fence_wave() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 template <int K>
 __global__ __launch_bounds__(64 * K, 2) void track_block_kernel(TrackBlockParams p) {
@@ -460,27 +523,46 @@ __global__ __launch_bounds__(64 * K, 2) void track_block_kernel(TrackBlockParams
     const int ch = blockIdx.x;
     if (ch >= p.n_chan) return;
     ChanState* st = p.states + ch;
-    const cf* rep = replica_column(p.replica_table, st->sat_id - 1, lane);
+    const cf* rep = replica_column(p.replica_table, st->sat_id - 1, 0);
     const cf* stream = p.iq + (int64_t)st->stream * p.stream_stride;
-    // loop state, uniform across the workgroup (re-broadcast through LDS each millisecond)
+    // loop state: uniform across the workgroup, re-broadcast through LDS every millisecond
     double f = st->doppler, phi = st->carrier_phase;
     int code_phase = st->code_phase;
     int lost = st->lost;
-    // wavefront 0 carries the scalar loop state in registers (identical in all its lanes) and writes it back once
+    // wavefront 0 carries the scalar filter state in registers (identical in all its lanes), written back once
     int64_t n_steps = st->n_steps;
     double dll_phase = st->dll_phase, last_watchdog = st->last_watchdog_time;
+    LockSums sums = st->sums;
+    const bool prof = p.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+    long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    StageRaw<K> raw;
+    if (!lost && p.n_ms > 0) stage_load<K>(raw, stream, launder(threadIdx.x));
     for (int ms = 0; ms < p.n_ms; ++ms) {
         gyp_track_rec* rec = p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + ms : nullptr;
         if (lost) {  // a dropped channel stays dropped until the host re-creates it (receiver.py:259-267)
             if (rec && threadIdx.x == 0) { gyp_track_rec z = {}; z.status = 2; z.doppler_hz = f; z.carrier_phase = phi; z.code_phase = code_phase; *rec = z; }
             continue;
         }
+        long long t_a = prof ? (long long)__builtin_readcyclecounter() : 0;
         const double t0 = p.start_time[ms];
         const double du = f * p.inv_fs;
         const double u0 = f * t0 + phi * 0.15915494309189533577;
+        // the ring entries that leave the sliding windows this millisecond: fetched now, used after the FFTs
+        double leave_e = 0.0, leave_pr = 0.0, leave_pi = 0.0;
+        if (wave == 0) {
+            if (n_steps >= kLockWindow) {
+                leave_e = st->err_ring[n_steps % kLockWindow];
+                leave_pr = st->peak_re[(n_steps - kLockWindow) % kPeakHistory];
+                leave_pi = st->peak_im[(n_steps - kLockWindow) % kPeakHistory];
+            }
+        }
         cf c[16];
-        correlate_ms<K>(stream + (int64_t)ms * N, u0, du, sm, rep, c);
-        const EplResult<K> r = epl_from_c0<K>(c, code_phase, sm.red, nullptr);
+        correlate_ms<K>(raw, u0, du, sm, rep, c);
+        long long t_b = prof ? (long long)__builtin_readcyclecounter() : 0;
+        const EplResult r = epl_from_c0<K>(c, code_phase, sm.red, nullptr);
+        // the next millisecond's raw samples do not depend on the loop filters: fetch them under the update
+        if (ms + 1 < p.n_ms) stage_load<K>(raw, stream + (int64_t)(ms + 1) * N, launder(threadIdx.x));
+        long long t_c = prof ? (long long)__builtin_readcyclecounter() : 0;
         if (wave == 0) {
             const int64_t n = n_steps;
             // ---- code loop, tracker.py:297-303
@@ -490,30 +572,41 @@ __global__ __launch_bounds__(64 * K, 2) void track_block_kernel(TrackBlockParams
             const int new_code_phase = (int)dll;           // int() truncates toward zero, before the wrap
             dll = pymod(dll, 2046.0);
             if (dll < 0.0) dll += 2046.0;
-            // ---- histories, tracker.py:346-347
+            // ---- histories, tracker.py:346-347 (the peak joins the window before is_locked() looks at it)
             const double pr = (double)r.peak.x, pim = (double)r.peak.y;
             if (lane == 0) { st->peak_re[n % kPeakHistory] = pr; st->peak_im[n % kPeakHistory] = pim; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (n >= kLockWindow) {
+                if (leave_pr < 0.0) { sums.nr -= leave_pr; sums.ni -= leave_pi; sums.nrr -= leave_pr * leave_pr; --sums.cn; }
+                else { sums.pr -= leave_pr; sums.prr -= leave_pr * leave_pr; --sums.cp; }
+            }
+            if (pr < 0.0) { sums.nr += pr; sums.ni += pim; sums.nrr += pr * pr; ++sums.cn; }
+            else { sums.pr += pr; sums.prr += pr * pr; ++sums.cp; }
             // ---- Costas loop, tracker.py:246-262
             const double err = pr * pim;
-            const bool locked = is_locked_wave(st, n, n + 1, lane);
+            LockVerdict lv = lock_from_sums(sums, n);
+            bool locked = lv.locked;
+            if (lv.marginal || (n % kLockRefresh) == kLockRefresh - 1) {
+                workgroup_mem_fence_wave();                 // lane 0's ring stores -> every lane of this wavefront
+                LockSums fresh;
+                locked = is_locked_exact_wave(st, n, n + 1, lane, fresh);
+                sums = fresh;
+            }
             const double bw = locked ? 3.0 : 6.0;
             const double tps = 1.0 / p.fs;
             const double alpha = 4.0 * (1.0 / sqrt(2.0)) * bw * tps;
             const double beta = 4.0 * (bw * bw) * tps;
             double nphi = pymod(phi + err * alpha, 6.283185307179586);
             double nf = f + err * beta;
+            // the error joins its window after is_locked() has been evaluated (tracker.py:251,261)
+            if (n >= kLockWindow) { sums.se -= leave_e; sums.see -= leave_e * leave_e; }
+            sums.se += err; sums.see += err * err;
             if (lane == 0) st->err_ring[n % kLockWindow] = err;
-            const float mean_excl = (float)((r.st.sum - (double)r.st.n_max * (double)r.st.best.v) / (double)(N - r.st.n_max));
+            const float mean_excl = (float)((r.sum - (double)r.n_max * (double)r.best.v) / (double)(N - r.n_max));
             const double rec_f = nf, rec_phi = nphi;
             // ---- circularity watchdog, tracker.py:370-387
             int status = 0, nudged = 0;
             if (t0 - last_watchdog >= 6.0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                workgroup_mem_fence_wave();
                 double cs[3];
                 constellation_stats_wave(st, n + 1, lane, cs);
                 last_watchdog = t0;
@@ -530,15 +623,15 @@ __global__ __launch_bounds__(64 * K, 2) void track_block_kernel(TrackBlockParams
             dll_phase = dll;
             n_steps = n + 1;
             if (lane == 0) {
-                sm.red->bcast[2] = nf; sm.red->bcast[3] = nphi;
-                sm.red->ibcast[0] = new_code_phase; sm.red->ibcast[1] = lost;
+                sm.red->dstate[0] = nf; sm.red->dstate[1] = nphi;
+                sm.red->istate[0] = new_code_phase; sm.red->istate[1] = lost;
                 if (rec) {
                     gyp_track_rec o;
                     o.peak_re = r.peak.x; o.peak_im = r.peak.y;
-                    o.strength = r.st.best.v / mean_excl;
+                    o.strength = r.best.v / mean_excl;
                     o.discriminator = (float)disc;
                     o.doppler_hz = rec_f; o.carrier_phase = rec_phi; o.error = err;
-                    o.code_phase = new_code_phase; o.peak_offset = r.st.best.key;
+                    o.code_phase = new_code_phase; o.peak_offset = r.best.key;
                     o.pseudosymbol = (int8_t)(pr > 0.0 ? 1 : (pr < 0.0 ? -1 : 0));
                     o.locked = locked ? 1 : 0; o.status = (int8_t)status; o.nudged = (int8_t)nudged;
                     o.reserved = 0;
@@ -546,14 +639,20 @@ __global__ __launch_bounds__(64 * K, 2) void track_block_kernel(TrackBlockParams
                 }
             }
         }
+        long long t_d = prof ? (long long)__builtin_readcyclecounter() : 0;
         __syncthreads();
-        f = sm.red->bcast[2]; phi = sm.red->bcast[3];
-        code_phase = sm.red->ibcast[0]; lost = sm.red->ibcast[1];
-        __syncthreads();
+        f = sm.red->dstate[0]; phi = sm.red->dstate[1];
+        code_phase = sm.red->istate[0]; lost = sm.red->istate[1];
+        if (prof) {
+            const long long t_e = (long long)__builtin_readcyclecounter();
+            tp[0] += t_b - t_a; tp[1] += t_c - t_b; tp[2] += t_d - t_c; tp[3] += t_e - t_d; tp[4] += 1;
+        }
     }
     if (threadIdx.x == 0) {
         st->doppler = f; st->carrier_phase = phi; st->code_phase = code_phase; st->lost = lost;
         st->dll_phase = dll_phase; st->n_steps = n_steps; st->last_watchdog_time = last_watchdog;
+        st->sums = sums;
+        if (prof) for (int i = 0; i < 8; ++i) p.prof[i] = tp[i];
     }
 }
 
@@ -569,6 +668,7 @@ __global__ void bank_reset_kernel(ChanState* states, const gyp_chan_init* inits,
     s->n_steps = 0;
     s->code_phase = in.code_phase;
     s->lost = 0;
+    s->sums = LockSums{};
 }
 
 // ---------------------------------------------------------------------------------------------------------

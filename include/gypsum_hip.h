@@ -98,8 +98,8 @@ typedef struct gyp_cell {
     double sum;         /* sum(profile) */
     int32_t n_max;      /* number of elements equal to the maximum */
     int32_t reserved;
-    float tap_re;       /* integrated complex correlation at desc.tap_index (coherent: sum_i c_i[tap]; */
-    float tap_im;       /*  non-coherent: c of the LAST block), 0 if tap_index < 0 */
+    float tap_re;       /* coherent integration only: sum_i c_i[desc.tap_index]; 0 otherwise */
+    float tap_im;
 } gyp_cell;
 
 double gyp_cell_strength(const gyp_cell* c, int32_t samples_per_ms);
@@ -239,6 +239,10 @@ int gyp_synth_iq_dev(gyp_ctx* ctx, float* out_dev, int32_t n_streams, int64_t st
                      const gyp_synth_sat* sats_host, int32_t n_sats, float noise_sigma, uint64_t seed);
 /* +-1 data bit satellite `sat_id` of stream `stream` carries during millisecond `ms` (host mirror of the kernel). */
 int gyp_synth_nav_bit(uint64_t seed, int32_t stream, int32_t sat_id, int32_t nav_bit_offset_ms, int64_t ms);
+
+/* Debug: per-phase shader-cycle counters of workgroup 0 of gyp_track_block_dev (correlate, reduce, loop update,
+ * barrier, ms count).  enable != 0 arms it; out8 (may be NULL) receives the counters of the last launch. */
+int gyp_debug_track_profile(gyp_ctx* ctx, int enable, long long* out8);
 
 #ifdef __cplusplus
 }
