@@ -39,7 +39,7 @@ EXPORTS = (
     "gyp_timer_stop gyp_set_stream_format gyp_prn_chips gyp_prn_spectrum_lane_layout gyp_malloc gyp_free "
     "gyp_memcpy_h2d gyp_memcpy_d2h gyp_cell_strength gyp_correlate_cells_dev gyp_correlate_cells gyp_acquire_dev "
     "gyp_acquire gyp_track_step_dev gyp_track_step gyp_bank_create gyp_bank_destroy gyp_bank_size "
-    "gyp_track_block_dev gyp_track_block gyp_bank_get_state gyp_synth_iq_dev gyp_synth_nav_bit gyp_bank_reset_dev gyp_debug_track_profile"
+    "gyp_track_block_dev gyp_track_block gyp_bank_get_state gyp_synth_iq_dev gyp_synth_nav_bit gyp_bank_reset_dev gyp_debug_track_profile gyp_debug_fft_bench"
 ).split()
 
 
@@ -95,6 +95,7 @@ def load() -> C.CDLL:
         "gyp_bank_get_state": (C.c_int, [vp, vp, vp, vp, vp]),
         "gyp_bank_reset_dev": (C.c_int, [vp, vp]),
         "gyp_debug_track_profile": (C.c_int, [vp, C.c_int, vp]),
+        "gyp_debug_fft_bench": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
         "gyp_synth_iq_dev": (C.c_int, [vp, vp, i32, i64, i32, vp, i32, C.c_float, u64]),
         "gyp_synth_nav_bit": (C.c_int, [u64, i32, i32, i32, i64]),
     }

@@ -692,6 +692,33 @@ int gyp_debug_track_profile(gyp_ctx* ctx, int enable, long long* out8) {
     return GYP_OK;
 }
 
+int gyp_debug_fft_bench(gyp_ctx* ctx, int waves_per_wg, int wgs, int iters, float* ms_out) {
+    if (!ctx || !ms_out) return GYP_E_BAD_ARG;
+    if (!ctx->k) return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
+    int rc;
+    if ((rc = ensure_scratch(ctx, 3, (size_t)wgs * 1024 * 4))) return rc;
+    float* sink = (float*)ctx->scratch[3];
+    for (int rep = 0; rep < 2; ++rep) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        switch (waves_per_wg) {
+            case 1: hipFuncSetAttribute(reinterpret_cast<const void*>(fft_bench_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<1>());
+                    hipLaunchKernelGGL(fft_bench_kernel<1>, dim3(wgs), dim3(64), lds_bytes<1>(), ctx->stream, ctx->d_tw, ctx->d_replicas, iters, sink); break;
+            case 2: hipFuncSetAttribute(reinterpret_cast<const void*>(fft_bench_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<2>());
+                    hipLaunchKernelGGL(fft_bench_kernel<2>, dim3(wgs), dim3(128), lds_bytes<2>(), ctx->stream, ctx->d_tw, ctx->d_replicas, iters, sink); break;
+            case 4: hipFuncSetAttribute(reinterpret_cast<const void*>(fft_bench_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<4>());
+                    hipLaunchKernelGGL(fft_bench_kernel<4>, dim3(wgs), dim3(256), lds_bytes<4>(), ctx->stream, ctx->d_tw, ctx->d_replicas, iters, sink); break;
+            case 8: hipFuncSetAttribute(reinterpret_cast<const void*>(fft_bench_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<8>());
+                    hipLaunchKernelGGL(fft_bench_kernel<8>, dim3(wgs), dim3(512), lds_bytes<8>(), ctx->stream, ctx->d_tw, ctx->d_replicas, iters, sink); break;
+            default: return fail(ctx, GYP_E_BAD_ARG, "waves_per_wg must be 1, 2, 4 or 8");
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+        HIP_TRY(ctx, hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));
+    }
+    return GYP_OK;
+}
+
 int gyp_synth_nav_bit(uint64_t seed, int32_t stream, int32_t sat_id, int32_t nav_bit_offset_ms, int64_t ms) {
     return synth_nav_bit(seed, stream, sat_id, nav_bit_offset_ms, ms);
 }

@@ -813,4 +813,38 @@ __global__ __launch_bounds__(256) void synth_iq_kernel(SynthParams p) {
     p.out[(int64_t)stream * p.stream_stride + gn] = make_float2(re + r * cs, im + r * sn);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// micro-benchmark of the wavefront transform pair (debug): every wavefront runs `iters` forward + inverse
+// 2048-point transforms back to back on LDS-resident data, no global traffic, no workgroup barriers.
+// ---------------------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(64 * W, 2) void fft_bench_kernel(const cf* __restrict__ tw_tables, const cf* __restrict__ rep_table,
+                                                               int iters, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const Smem sm = carve_smem<W>(smem_raw, tw_tables);
+    __syncthreads();
+    const int tid = launder(threadIdx.x), wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
+    cf* xch_half = sm.xch + wave * kXchWave + h * kXchHalf;
+    const LdsTables t{sm.tw1024, sm.tw2048};
+    cf x[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) x[j] = make_float2(0.001f * (float)(lane + j), 0.002f * (float)(j - lane));
+    float acc = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        wave_fft_fwd(x, xch_half, t, l, h);
+        cf rep[32];
+        load_replica(rep, rep_table + lane);
+        spectrum_mul(x, rep);
+        cf c[16];
+        wave_fft_inv(x, c, xch_half, t, l, h);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            acc += c[j].x;
+            x[2 * j] = c[j];
+            x[2 * j + 1] = make_float2(c[j].y, c[j].x);
+        }
+    }
+    if (acc == 123.456f) sink[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
 }  // namespace gyp

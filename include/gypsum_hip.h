@@ -243,6 +243,9 @@ int gyp_synth_nav_bit(uint64_t seed, int32_t stream, int32_t sat_id, int32_t nav
 /* Debug: per-phase shader-cycle counters of workgroup 0 of gyp_track_block_dev (correlate, reduce, loop update,
  * barrier, ms count).  enable != 0 arms it; out8 (may be NULL) receives the counters of the last launch. */
 int gyp_debug_track_profile(gyp_ctx* ctx, int enable, long long* out8);
+/* Debug: time `iters` forward+inverse wavefront transform pairs per wavefront, `wgs` workgroups of `waves_per_wg`
+ * wavefronts (LDS-resident data, no global traffic): the floor the correlator kernels are measured against. */
+int gyp_debug_fft_bench(gyp_ctx* ctx, int waves_per_wg, int wgs, int iters, float* ms_out);
 
 #ifdef __cplusplus
 }
