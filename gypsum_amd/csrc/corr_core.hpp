@@ -45,6 +45,14 @@ __device__ __forceinline__ cf cmulc(cf a, cf b) {
     return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
 }
 
+// Workgroup b is observed to run on XCD (b % 8), each XCD with its own L2.  Map the b-th unit of work to the
+// index that gives every XCD one CONTIGUOUS eighth of the n units, so that neighbours in the work list (the 12
+// channels of a stream, the Doppler bins of a satellite) share an L2.  Bijective for any n; speed only.
+__device__ __forceinline__ int xcd_contiguous(int b, int n) {
+    const int x = b & 7, slot = b >> 3, q = n >> 3, r = n & 7;
+    return x * q + (x < r ? x : r) + slot;
+}
+
 __host__ __device__ constexpr int bitrev5(int v) {
     return ((v & 1) << 4) | ((v & 2) << 2) | (v & 4) | ((v & 8) >> 2) | ((v & 16) >> 4);
 }

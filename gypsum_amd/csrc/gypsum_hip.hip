@@ -330,7 +330,7 @@ static int launch_k(gyp_ctx* ctx, KernelT kernel, int k, int grid, const ParamsT
 }
 
 static int launch_cells(gyp_ctx* ctx, const CellsParams& p, int integration) {
-    const int grid = std::max(1, std::min(p.n_cells, ctx->n_cus * blocks_per_cu(ctx->k)));
+    const int grid = std::max(1, std::min(p.n_cells, ctx->n_cus * blocks_per_cu(ctx->k)) & ~7) ;
     const bool coh = integration == GYP_COHERENT;
     switch (ctx->k) {
         case 1: return coh ? launch_k(ctx, corr_cells_kernel<1, true>, 1, grid, p, lds_bytes<1>()) : launch_k(ctx, corr_cells_kernel<1, false>, 1, grid, p, lds_bytes<1>());
@@ -342,7 +342,7 @@ static int launch_cells(gyp_ctx* ctx, const CellsParams& p, int integration) {
 }
 
 static int launch_track_step(gyp_ctx* ctx, const TrackStepParams& p) {
-    const int grid = std::max(1, std::min(p.n_chan, ctx->n_cus * blocks_per_cu(ctx->k)));
+    const int grid = std::max(1, std::min(p.n_chan, ctx->n_cus * blocks_per_cu(ctx->k)) & ~7);
     switch (ctx->k) {
         case 1: return launch_k(ctx, track_step_kernel<1>, 1, grid, p, lds_bytes<1>());
         case 2: return launch_k(ctx, track_step_kernel<2>, 2, grid, p, lds_bytes<2>());
@@ -352,15 +352,19 @@ static int launch_track_step(gyp_ctx* ctx, const TrackStepParams& p) {
     return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
 }
 
-static int launch_track_block(gyp_ctx* ctx, const TrackBlockParams& p) {
+template <bool PROF>
+static int launch_track_block_t(gyp_ctx* ctx, const TrackBlockParams& p) {
     const int grid = p.n_chan;
     switch (ctx->k) {
-        case 1: return launch_k(ctx, track_block_kernel<1>, 1, grid, p, lds_bytes<1>());
-        case 2: return launch_k(ctx, track_block_kernel<2>, 2, grid, p, lds_bytes<2>());
-        case 4: return launch_k(ctx, track_block_kernel<4>, 4, grid, p, lds_bytes<4>());
-        case 8: return launch_k(ctx, track_block_kernel<8>, 8, grid, p, lds_bytes<8>());
+        case 1: return launch_k(ctx, track_block_kernel<1, PROF>, 1, grid, p, lds_bytes<1>());
+        case 2: return launch_k(ctx, track_block_kernel<2, PROF>, 2, grid, p, lds_bytes<2>());
+        case 4: return launch_k(ctx, track_block_kernel<4, PROF>, 4, grid, p, lds_bytes<4>());
+        case 8: return launch_k(ctx, track_block_kernel<8, PROF>, 8, grid, p, lds_bytes<8>());
     }
     return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
+}
+static int launch_track_block(gyp_ctx* ctx, const TrackBlockParams& p) {
+    return p.prof ? launch_track_block_t<true>(ctx, p) : launch_track_block_t<false>(ctx, p);
 }
 
 extern "C" {

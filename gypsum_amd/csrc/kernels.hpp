@@ -180,7 +180,8 @@ __global__ __launch_bounds__(64 * K, 2) void corr_cells_kernel(CellsParams p) {
     const Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
     const int lane = threadIdx.x & 63;
     __syncthreads();
-    for (int cell = blockIdx.x; cell < p.n_cells; cell += gridDim.x) {
+    for (int v = blockIdx.x; v < p.n_cells; v += gridDim.x) {
+        const int cell = xcd_contiguous(v, p.n_cells);
         const gyp_cell_desc d = p.cells[cell];
         if (d.sat_id < 1 || d.sat_id > 32) continue;  // padding cell (uniform across the workgroup)
         const cf* rep = replica_column(p.replica_table, d.sat_id - 1, 0);
@@ -310,7 +311,8 @@ __global__ __launch_bounds__(64 * K, 2) void track_step_kernel(TrackStepParams p
     const Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
     const int lane = threadIdx.x & 63;
     __syncthreads();
-    for (int ch = blockIdx.x; ch < p.n_chan; ch += gridDim.x) {
+    for (int v = blockIdx.x; v < p.n_chan; v += gridDim.x) {
+        const int ch = xcd_contiguous(v, p.n_chan);
         const gyp_chan_in in = p.chans[ch];
         const cf* rep = replica_column(p.replica_table, in.sat_id - 1, 0);
         // tracker.py:271-281: carrier = exp(-1j*(2*pi*f*t + phi)), t = n/fs + chunk.start_time
@@ -513,15 +515,15 @@ __device__ __forceinline__ void workgroup_mem_fence_wave() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <int K>
+template <int K, bool PROF>
 __global__ __launch_bounds__(64 * K, 2) void track_block_kernel(TrackBlockParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int N = K * kChips;
     const Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
-    const int ch = blockIdx.x;
-    if (ch >= p.n_chan) return;
+    if ((int)blockIdx.x >= p.n_chan) return;
+    const int ch = xcd_contiguous(blockIdx.x, p.n_chan);
     ChanState* st = p.states + ch;
     const cf* rep = replica_column(p.replica_table, st->sat_id - 1, 0);
     const cf* stream = p.iq + (int64_t)st->stream * p.stream_stride;
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(64 * K, 2) void track_block_kernel(TrackBlockParams
     int64_t n_steps = st->n_steps;
     double dll_phase = st->dll_phase, last_watchdog = st->last_watchdog_time;
     LockSums sums = st->sums;
-    const bool prof = p.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+    const bool prof = PROF && p.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
     long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     StageRaw<K> raw;
     if (!lost && p.n_ms > 0) stage_load<K>(raw, stream, launder(threadIdx.x));
@@ -560,8 +562,6 @@ __global__ __launch_bounds__(64 * K, 2) void track_block_kernel(TrackBlockParams
         correlate_ms<K>(raw, u0, du, sm, rep, c);
         long long t_b = prof ? (long long)__builtin_readcyclecounter() : 0;
         const EplResult r = epl_from_c0<K>(c, code_phase, sm.red, nullptr);
-        // the next millisecond's raw samples do not depend on the loop filters: fetch them under the update
-        if (ms + 1 < p.n_ms) stage_load<K>(raw, stream + (int64_t)(ms + 1) * N, launder(threadIdx.x));
         long long t_c = prof ? (long long)__builtin_readcyclecounter() : 0;
         if (wave == 0) {
             const int64_t n = n_steps;
@@ -640,6 +640,8 @@ __global__ __launch_bounds__(64 * K, 2) void track_block_kernel(TrackBlockParams
             }
         }
         long long t_d = prof ? (long long)__builtin_readcyclecounter() : 0;
+        // the next millisecond's raw samples do not depend on the loop filters: in flight across the barrier
+        if (ms + 1 < p.n_ms) stage_load<K>(raw, stream + (int64_t)(ms + 1) * N, launder(threadIdx.x));
         __syncthreads();
         f = sm.red->dstate[0]; phi = sm.red->dstate[1];
         code_phase = sm.red->istate[0]; lost = sm.red->istate[1];
