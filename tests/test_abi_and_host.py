@@ -1,0 +1,162 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol the header declares,
+its record layouts match the ctypes/numpy mirrors, and its host-only entry points (PRN codes, replica spectra)
+agree with the oracle.  No compute call needs a GPU here."""
+import ctypes as C
+import hashlib
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+import lane_model
+from gypsum_amd import _lib, gps_ca_prn_codes, synth
+from oracle import gypsum_oracle as orc
+
+REPO = Path(__file__).resolve().parents[1]
+HEADER = REPO / "include" / "gypsum_hip.h"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from gypsum_amd import build
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    text = HEADER.read_text()
+    declared = set(re.findall(r"^\s*(?:int|void|double|const char\*)\s+(gyp_\w+)\s*\(", text, flags=re.M))
+    assert declared, "no declarations parsed from the header"
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        getattr(lib, name)
+    assert lib.gyp_version() == int(re.search(r"#define GYP_VERSION (\d+)", text).group(1))
+
+
+def test_record_layouts_match_the_header(tmp_path):
+    structs = {"gyp_cell_desc": _lib.CELL_DESC, "gyp_cell": _lib.CELL, "gyp_acq_result": _lib.ACQ_RESULT,
+               "gyp_chan_in": _lib.CHAN_IN, "gyp_chan_out": _lib.CHAN_OUT, "gyp_chan_init": _lib.CHAN_INIT,
+               "gyp_track_rec": _lib.TRACK_REC, "gyp_synth_sat": _lib.SYNTH_SAT}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
+    for name, dt in structs.items():
+        lines.append(f'printf("{name} size %zu\\n", sizeof({name}));')
+        for field in dt.names:
+            lines.append(f'printf("{name} {field} %zu\\n", offsetof({name}, {field}));')
+    lines.append("return 0;}")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    got = {tuple(l.split()[:2]): int(l.split()[2]) for l in out.strip().splitlines()}
+    for name, dt in structs.items():
+        assert got[(name, "size")] == dt.itemsize, name
+        for field in dt.names:
+            assert got[(name, field)] == dt.fields[field][1], (name, field)
+
+
+def test_no_device_fails_loudly_not_silently(lib):
+    """On a box without a GPU the product path must refuse to run (there is no CPU fallback)."""
+    h = C.c_void_p()
+    rc = lib.gyp_create(0, C.byref(h))
+    if rc == 0:   # a GPU is present: nothing to check here
+        lib.gyp_destroy(h)
+        pytest.skip("HIP device present")
+    assert rc == _lib.GYP_E_NO_DEVICE
+    assert b"no CPU fallback" in lib.gyp_last_error(None)
+    from gypsum_amd.engine import GypsumEngine
+    with pytest.raises(_lib.GypsumHipError):
+        GypsumEngine(0)
+
+
+def test_prn_chips_from_library_host_mirror_and_reference(lib):
+    out = np.zeros((32, 1023), dtype=np.uint8)
+    assert lib.gyp_prn_chips(_lib.ptr(out)) == 0
+    ref = gu.load("prn_chips.npz")["chips"]
+    assert np.array_equal(out, ref)
+    assert np.array_equal(gps_ca_prn_codes.generate_ca_code_table(), ref)
+    assert hashlib.sha256(out.tobytes()).hexdigest() == str(gu.load("prn_chips.npz")["sha256"])
+    sigs = gps_ca_prn_codes.generate_replica_prn_signals()
+    assert np.array_equal(sigs[gps_ca_prn_codes.GpsSatelliteId(7)].inner, ref[6])
+
+
+def test_replica_spectrum_table_matches_numpy(lib):
+    chips = orc.generate_ca_codes()
+    for sv in (1, 17, 32):
+        out = np.zeros((32, 64, 2), dtype=np.float32)
+        assert lib.gyp_prn_spectrum_lane_layout(sv, _lib.ptr(out)) == 0
+        model = lane_model.prn_spectrum_lane_layout(chips[sv - 1])      # [natural reg g2][lane]
+        phys = np.array([lane_model_bitrev5(i) for i in range(32)])
+        want = model[phys]                                               # physical register i holds g2 = bitrev5(i)
+        got = out[..., 0] + 1j * out[..., 1]
+        assert np.abs(got - want).max() <= 1e-7 * np.abs(want).max()
+    assert lib.gyp_prn_spectrum_lane_layout(0, _lib.ptr(out)) == _lib.GYP_E_BAD_ARG
+
+
+def lane_model_bitrev5(v):
+    return int(f"{v:05b}"[::-1], 2)
+
+
+@pytest.mark.parametrize("k", [1, 2, 4, 8])
+def test_lane_model_equals_reference_correlation(k):
+    """The polyphase / 32x32 wavefront decomposition the kernel implements is exact (float64 model)."""
+    rng = np.random.default_rng(k)
+    chips = orc.generate_ca_codes()
+    n = 1023 * k
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    ref = orc.frequency_domain_correlation(x, orc.prn_as_complex(chips[k], n))
+    got = lane_model.correlate_lane_model(x, chips[k], k)
+    assert np.abs(ref - got).max() <= 1e-11 * np.abs(ref).max()
+
+
+def test_early_late_taps_are_taps_of_the_unrolled_correlation():
+    """E/L of tracker.py:284-295 are c0[(s-1)%N], c0[(s+1)%N]; the rolled prompt profile is roll(c0,-s)."""
+    rng = np.random.default_rng(9)
+    chips = orc.generate_ca_codes()
+    n, s = 2046, 777
+    prn = orc.prn_as_complex(chips[4], n)
+    xw = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    c0 = orc.frequency_domain_correlation(xw, prn)
+    assert abs(np.correlate(xw, np.roll(prn, s - 1))[0] - c0[(s - 1) % n]) < 1e-10
+    assert abs(np.correlate(xw, np.roll(prn, s + 1))[0] - c0[(s + 1) % n]) < 1e-10
+    assert np.abs(orc.frequency_domain_correlation(xw, np.roll(prn, s)) - np.roll(c0, -s)).max() < 1e-10
+
+
+def test_synthetic_scene_is_deterministic_and_matches_kat():
+    iq, fs, n = synth.kat_grid_scene()
+    assert np.array_equal(iq, gu.load("grid_kat_2046.npz")["iq"])
+    a = synth.render(synth.random_scene(2_046_000, 12, 3, 5))
+    b = synth.render(synth.random_scene(2_046_000, 12, 3, 5))
+    assert np.array_equal(a, b) and a.dtype == np.complex64 and len(a) == 12 * 2046
+    with pytest.raises(ValueError):
+        synth.SyntheticScene(fs=2_048_000, n_ms=1, sats=[], noise_sigma=0.0, seed=0)
+
+
+def test_nav_bit_hash_is_the_same_on_host_and_in_the_header_contract(lib):
+    vals = [lib.gyp_synth_nav_bit(1234, s, sv, off, ms) for s in (0, 3) for sv in (1, 32) for off in (0, 19) for ms in (0, 19, 20, 12345)]
+    assert set(vals) <= {-1, 1}
+    # bits change only at 20-ms boundaries (offset shifts the boundary)
+    assert lib.gyp_synth_nav_bit(7, 0, 5, 0, 0) == lib.gyp_synth_nav_bit(7, 0, 5, 0, 19)
+    assert lib.gyp_synth_nav_bit(7, 0, 5, 3, 0) == lib.gyp_synth_nav_bit(7, 0, 5, 3, 16)
+
+
+def test_file_provider_reads_gnuradio_float32_like_the_reference(tmp_path):
+    from gypsum_amd.antenna_sample_provider import (AntennaSampleProviderBackedByArray, AntennaSampleProviderBackedByFile,
+                                                    NoMoreSamplesError)
+    rng = np.random.default_rng(1)
+    iq = (rng.standard_normal(5 * 2046) + 1j * rng.standard_normal(5 * 2046)).astype(np.complex64)
+    path = tmp_path / "rec"
+    iq.view(np.float32).tofile(path)
+    fp = AntennaSampleProviderBackedByFile(path, 2_046_000)
+    ap = AntennaSampleProviderBackedByArray(iq, 2_046_000)
+    assert fp.get_attributes().samples_per_prn_transmission == 2046
+    for ms in range(4):
+        a, b = fp.get_samples(2046), ap.get_samples(2046)
+        assert np.array_equal(a.samples, b.samples)
+        assert (a.start_time, a.end_time) == (b.start_time, b.end_time) == orc.chunk_times(ms * 2046, 2046, 2_046_000)
+    with pytest.raises(NoMoreSamplesError):   # the reference's bound is `>=`: the final full chunk is not served
+        fp.get_samples(2046)

@@ -1,0 +1,90 @@
+"""Oracle and reference side by side.  Only runs where /root/reference exists (the build container)."""
+import sys
+import warnings
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REF = Path("/root/reference")
+pytestmark = pytest.mark.skipif(not (REF / "gypsum" / "utils.py").exists(), reason="reference not present on this box")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    sys.path.insert(0, str(REF))
+    warnings.filterwarnings("ignore", category=DeprecationWarning)
+    import gypsum.acquisition as acq
+    import gypsum.antenna_sample_provider as asp
+    import gypsum.gps_ca_prn_codes as codes
+    import gypsum.satellite as sat
+    import gypsum.tracker as trk
+    import gypsum.utils as utils
+    yield {"acq": acq, "asp": asp, "codes": codes, "sat": sat, "trk": trk, "utils": utils}
+    sys.path.remove(str(REF))
+
+
+def test_correlator_math(ref):
+    from gypsum_amd import synth
+    from oracle import gypsum_oracle as orc
+
+    rng = np.random.default_rng(3)
+    chips = orc.generate_ca_codes()
+    codes = ref["codes"].generate_replica_prn_signals()
+    for fs in (2_046_000, 8_184_000):
+        n = fs // 1000
+        ref["sat"].GpsSatellite.prn_as_complex.fget.cache_clear()
+        sv = int(rng.integers(1, 33))
+        s = ref["sat"].GpsSatellite(ref["codes"].GpsSatelliteId(sv), codes[ref["codes"].GpsSatelliteId(sv)], n // 1023)
+        prn = orc.prn_as_complex(chips[sv - 1], n)
+        assert np.array_equal(prn, s.prn_as_complex)
+        iq = (rng.standard_normal(3 * n + 17) + 1j * rng.standard_normal(3 * n + 17)).astype(np.complex64)
+        attrs = ref["asp"].SampleProviderAttributes(fs, n)
+        for kind, rk in ((orc.COHERENT, ref["utils"].IntegrationType.Coherent), (orc.NON_COHERENT, ref["utils"].IntegrationType.NonCoherent)):
+            a = orc.integrate_correlation(kind, iq, fs, n, 1234.5, prn)
+            b = ref["utils"].integrate_correlation_with_doppler_shifted_prn(rk, iq, attrs, 1234.5, s.prn_as_complex)
+            assert np.array_equal(a, b)
+        prof = np.abs(a)
+        assert orc.peak_strength(prof) == ref["utils"].get_normalized_correlation_peak_strength(prof)
+        peaks = rng.standard_normal(300) * 20 + 1j * rng.standard_normal(300)
+        assert orc.constellation_rotation(peaks) == ref["utils"].get_iq_constellation_rotation(peaks)
+        assert orc.constellation_circularity(peaks) == ref["utils"].get_iq_constellation_circularity(peaks)
+
+
+def test_acquisition_and_tracking_closed_loop(ref):
+    from gypsum_amd import synth
+    from oracle import gypsum_oracle as orc
+
+    fs, n = 2_046_000, 2046
+    scene = synth.random_scene(fs, 320, 4, 77, noise_sigma=0.02)
+    iq = synth.render(scene)
+    chips = orc.generate_ca_codes()
+    codes = ref["codes"].generate_replica_prn_signals()
+    ref["sat"].GpsSatellite.prn_as_complex.fget.cache_clear()
+    sats = {sid: ref["sat"].GpsSatellite(sid, code, n // 1023) for sid, code in codes.items()}
+    det = ref["acq"].GpsSatelliteDetector(sats)
+    attrs = ref["asp"].SampleProviderAttributes(fs, n)
+    sv = scene.sats[0].sat_id
+    sid = ref["codes"].GpsSatelliteId(sv)
+    ra = det._attempt_acquisition_for_satellite_id(sid, iq[:10 * n], attrs)
+    oa = orc.acquire_satellite(sv, iq[:10 * n], fs, n, orc.prn_as_complex(chips[sv - 1], n))
+    assert (oa.doppler_shift, oa.prn_phase_shift, oa.correlation_strength, oa.carrier_wave_phase_shift) == \
+           (ra.doppler_shift, ra.prn_phase_shift, ra.correlation_strength, ra.carrier_wave_phase_shift)
+    params = ref["trk"].GpsSatelliteTrackingParameters(satellite=sats[sid], current_doppler_shift=ra.doppler_shift,
+                                                       current_carrier_wave_phase_shift=ra.carrier_wave_phase_shift,
+                                                       current_prn_code_phase_shift=ra.prn_phase_shift, doppler_shifts=[])
+    rt = ref["trk"].GpsSatelliteTracker(params, attrs)
+    ot = orc.Tracker(orc.TrackingState(oa.doppler_shift, oa.carrier_wave_phase_shift, oa.prn_phase_shift),
+                     orc.prn_as_complex(chips[sv - 1], n), fs, n)
+    for ms in range(9, 320):
+        t0, t1 = orc.chunk_times(ms * n, n, fs)
+        chunk = ref["asp"].AntennaSampleChunk(t0, t1, iq[ms * n:(ms + 1) * n])
+        ps = rt.process_samples(chunk)
+        rec = ot.process_samples(iq[ms * n:(ms + 1) * n], t0, t1)
+        assert rec.peak == params.correlation_peaks_rolling_buffer[-1]
+        assert rec.doppler_after == params.current_doppler_shift
+        assert rec.carrier_phase_after == params.current_carrier_wave_phase_shift
+        assert rec.code_phase_after == params.current_prn_code_phase_shift
+        assert rec.pseudosymbol == ps.pseudosymbol.as_val()
+        assert rec.start_of_pseudosymbol == ps.start_of_pseudosymbol
+        assert ot.s.is_locked() == params.is_locked()
