@@ -1,0 +1,50 @@
+"""Per-satellite pipeline shim (`gypsum/satellite_signal_processing_pipeline.py:35-158`).
+
+The reference's module needs Python 3.11 and pulls in the navigation-message decoder and the matplotlib
+visualizer, which are outside this engine's scope.  This shim keeps the constructor and
+`process_samples(chunk) -> list[Event]` contract around the GPU tracker; the bit integrator / message decoder are
+plug-ins: anything with the reference's `process_pseudosymbol(receiver_timestamp, pseudosymbol) -> list[Event]`
+(e.g. the reference's own NavigationBitIntegrator) can be passed in, and its events are returned unchanged.
+"""
+from __future__ import annotations
+
+from enum import Enum, auto
+from typing import Any, Callable, List, Optional
+
+from .acquisition import SatelliteAcquisitionAttemptResult
+from .antenna_sample_provider import AntennaSampleChunk, SampleProviderAttributes
+from .tracker import EmittedPseudosymbol, GpsSatelliteTracker, GpsSatelliteTrackingParameters, LostSatelliteLockError  # noqa: F401
+
+
+class TrackingState(Enum):
+    PROVISIONAL_PROBE = auto()
+    LOCKED = auto()
+
+
+class GpsSatelliteSignalProcessingPipeline:
+    def __init__(self, satellite: Any, acquisition_result: SatelliteAcquisitionAttemptResult,
+                 stream_attributes: SampleProviderAttributes, should_present_matplotlib_satellite_tracker: bool = False,
+                 should_present_web_ui: bool = False, pseudosymbol_integrator: Any = None,
+                 tracker_factory: Optional[Callable[..., Any]] = None) -> None:
+        self.satellite = satellite
+        self.state = TrackingState.PROVISIONAL_PROBE
+        tracking_params = GpsSatelliteTrackingParameters(          # pipeline.py:56-62
+            satellite=satellite,
+            current_doppler_shift=acquisition_result.doppler_shift,
+            current_carrier_wave_phase_shift=acquisition_result.carrier_wave_phase_shift,
+            current_prn_code_phase_shift=acquisition_result.prn_phase_shift,
+            doppler_shifts=[],
+        )
+        self.tracker = (tracker_factory or GpsSatelliteTracker)(tracking_params, stream_attributes)
+        self.pseudosymbol_integrator = pseudosymbol_integrator
+        self.emitted_pseudosymbols: List[EmittedPseudosymbol] = []
+
+    def process_samples(self, receiver_samples_chunk: AntennaSampleChunk) -> List[Any]:
+        pseudosymbol = self.tracker.process_samples(receiver_samples_chunk)     # may raise LostSatelliteLockError
+        self.emitted_pseudosymbols.append(pseudosymbol)
+        if self.pseudosymbol_integrator is None:
+            return []
+        return list(self.pseudosymbol_integrator.process_pseudosymbol(receiver_samples_chunk.start_time, pseudosymbol) or [])
+
+    def handle_satellite_dropped(self) -> None:
+        pass

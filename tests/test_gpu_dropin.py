@@ -138,3 +138,35 @@ def test_tracker_bank_replays_history_and_reports_lost_lock():
         if lost_at >= 0:
             assert len(params[i].doppler_shifts) == lost_at - 9 + 1     # the failing ms was still appended upstream
     bank.close()
+
+
+def test_receiver_shim_acquires_then_tracks_like_the_reference_pipeline():
+    """receiver.step() end to end on a synthetic provider: the acquisition result that seeds each pipeline and the
+    first tracked milliseconds equal what the oracle computes from the same buffer (receiver.py:100-106 order)."""
+    from gypsum_amd import synth
+    from gypsum_amd.antenna_sample_provider import AntennaSampleProviderBackedByArray, NoMoreSamplesError
+    from gypsum_amd.receiver import GpsReceiver
+
+    fs, n = 2_046_000, 2046
+    scene = synth.random_scene(fs, 60, 4, 4321, noise_sigma=0.02)
+    iq = synth.render(scene)
+    want = sorted(s.sat_id for s in scene.sats)
+    search = [GpsSatelliteId(s) for s in sorted(set(want + [1, 2]))]
+    rx = GpsReceiver(AntennaSampleProviderBackedByArray(iq, fs), only_acquire_satellite_ids=search)
+    with pytest.raises(NoMoreSamplesError):
+        while True:
+            rx.step()
+    assert sorted(s.id for s in rx.tracked_satellite_ids_to_processing_pipelines) == want
+    chips = orc.generate_ca_codes()
+    for sid, pipe in rx.tracked_satellite_ids_to_processing_pipelines.items():
+        prn = orc.prn_as_complex(chips[sid.id - 1], n)
+        a = orc.acquire_satellite(sid.id, iq[:10 * n], fs, n, prn)
+        trk = orc.Tracker(orc.TrackingState(a.doppler_shift, a.carrier_wave_phase_shift, a.prn_phase_shift), prn, fs, n)
+        assert len(pipe.emitted_pseudosymbols) == 60 - 9          # tracking started with the chunk that filled the buffer
+        for i, ms in enumerate(range(9, 60)):
+            t0, t1 = orc.chunk_times(ms * n, n, fs)
+            rec = trk.process_samples(iq[ms * n:(ms + 1) * n], t0, t1)
+            got = pipe.emitted_pseudosymbols[i]
+            assert got.pseudosymbol.as_val() == rec.pseudosymbol
+            assert got.start_of_pseudosymbol == pytest.approx(rec.start_of_pseudosymbol, abs=1e-12)
+        assert pipe.tracker.tracking_params.current_doppler_shift == pytest.approx(trk.s.current_doppler_shift, abs=1e-3)
