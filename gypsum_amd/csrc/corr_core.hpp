@@ -19,10 +19,11 @@
 namespace gyp {
 
 constexpr int kChips = 1023;
-constexpr int kXchRow = 34;                  // padded row: 272 B keeps rows 16-B aligned and ds_read_b128 conflict-free
-constexpr int kXchHalf = 32 * kXchRow;       // padded 32x32 transpose tile (complex elements)
-constexpr int kXchWave = 2 * kXchHalf;       // both half-waves
-constexpr int kXchWaveBytes = kXchWave * 8;  // 17408 B per wavefront
+constexpr int kXchRow = 34;                  // padded row of 34 floats: conflict-free ds_write_b32 columns / ds_read_b64 rows
+constexpr int kXchTile = 32 * kXchRow;       // one padded 32x32 FLOAT tile per half-wave
+constexpr int kXchWaveFloats = 2 * kXchTile; // both half-waves; real and imaginary parts go through it one after the other
+constexpr int kXchWave = kXchWaveFloats / 2; // in complex elements: 1088 >= the 1024 staged inputs that alias it
+constexpr int kXchWaveBytes = kXchWaveFloats * 4;  // 8704 B per wavefront: 16 wavefronts (4 per SIMD) fit a CU's LDS
 
 typedef float2 cf;
 
@@ -138,62 +139,96 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Lane l reads row l of the transpose tile: 16 x ds_read_b128 (two complex values each).
-__device__ __forceinline__ void read_transposed(cf (&x)[32], const cf* xch_half, int l) {
-    const float4* row = reinterpret_cast<const float4*>(xch_half + kXchRow * l);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const float4 v = row[j];
-        x[2 * j] = make_float2(v.x, v.y);
-        x[2 * j + 1] = make_float2(v.z, v.w);
-    }
-}
-
 // LDS-resident tables shared by the wavefronts of a workgroup.
 struct LdsTables {
-    const cf* tw1024;  // [32][32]: exp(-2*pi*i * g*n / 1024)
-    const cf* tw2048;  // [1024]  : exp(-2*pi*i * n / 2048)
+    const cf* tw1024;  // LDS   [32][32]: exp(-2*pi*i * g*n / 1024)
+    const cf* tw2048;  // global [1024] : exp(-2*pi*i * n / 2048), L1-resident; only the odd half-wave reads it
 };
+
+// 32x32 transpose inside each half-wave: lane l, register g  ->  lane g, register l.  The real parts of all 64
+// lanes go through the wavefront's float tile pair first, then the imaginary parts: no extra registers, no
+// divergence, half the LDS footprint of a complex tile.  perm(g) names the physical register holding row g.
+template <typename Perm>
+__device__ __forceinline__ void transpose32(cf (&x)[32], float* tile_half, int l, Perm perm) {
+    const float2* row = reinterpret_cast<const float2*>(tile_half + kXchRow * l);
+#pragma unroll
+    for (int g = 0; g < 32; ++g) tile_half[kXchRow * g + l] = x[perm(g)].x;
+    wave_lds_fence();
+    float re[32];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float2 v = row[j];
+        re[2 * j] = v.x;
+        re[2 * j + 1] = v.y;
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int g = 0; g < 32; ++g) tile_half[kXchRow * g + l] = x[perm(g)].y;
+    wave_lds_fence();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float2 v = row[j];
+        x[2 * j] = make_float2(re[2 * j], v.x);
+        x[2 * j + 1] = make_float2(re[2 * j + 1], v.y);
+    }
+    wave_lds_fence();
+}
 
 // Forward transform.  In: x[j] = y[32*j + l] (identical in both half-waves; y[1023] must be 0).
 // Out: physical register i holds bin f = 2*(l + 32*bitrev5(i)) + h.
-__device__ __forceinline__ void wave_fft_fwd(cf (&x)[32], cf* xch_half, const LdsTables& t, int l, int h) {
+__device__ __forceinline__ void wave_fft_fwd(cf (&x)[32], float* tile_half, const LdsTables& t, int l, int h) {
     if (h) {
 #pragma unroll
-        for (int j = 0; j < 32; ++j) x[j] = cmul(x[j], t.tw2048[32 * j + l]);
-    }
-    fft32_dif<-1>(x);
+        for (int b = 0; b < 32; b += 8) {
+            const cf* row = t.tw2048 + 32 * b + launder(l);
 #pragma unroll
-    for (int g = 0; g < 32; ++g) {
-        cf v = x[bitrev5(g)];
-        if (g) v = cmul(v, t.tw1024[32 * g + l]);
-        xch_half[kXchRow * g + l] = v;
+            for (int j = 0; j < 8; ++j) x[b + j] = cmul(x[b + j], row[32 * j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
-    wave_lds_fence();
-    read_transposed(x, xch_half, l);
-    wave_lds_fence();
+    __builtin_amdgcn_sched_barrier(0);
     fft32_dif<-1>(x);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int b = 0; b < 32; b += 8) {
+#pragma unroll
+        for (int g = b; g < b + 8; ++g)
+            if (g) x[bitrev5(g)] = cmul(x[bitrev5(g)], t.tw1024[32 * g + l]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    transpose32(x, tile_half, l, [](int g) { return bitrev5(g); });
+    __builtin_amdgcn_sched_barrier(0);
+    fft32_dif<-1>(x);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // Inverse transform (un-normalised; the 1/2048 lives in the PRN spectrum table) + half-wave combine.
 // In: physical register i holds bin f = 2*(l + 32*bitrev5(i)) + h.
 // Out: c[j], j = 0..15: lag q = l + 32*(j + 16*h).
-__device__ __forceinline__ void wave_fft_inv(cf (&x)[32], cf (&c)[16], cf* xch_half, const LdsTables& t, int l, int h) {
+__device__ __forceinline__ void wave_fft_inv(cf (&x)[32], cf (&c)[16], float* tile_half, const LdsTables& t, int l, int h) {
+    __builtin_amdgcn_sched_barrier(0);
     fft32_dit<+1>(x);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q = 0; q < 32; ++q) {
-        cf v = x[q];
-        if (q) v = cmulc(v, t.tw1024[32 * q + l]);
-        xch_half[kXchRow * q + l] = v;
+    for (int b = 0; b < 32; b += 8) {
+#pragma unroll
+        for (int q = b; q < b + 8; ++q)
+            if (q) x[q] = cmulc(x[q], t.tw1024[32 * q + l]);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    wave_lds_fence();
-    read_transposed(x, xch_half, l);
-    wave_lds_fence();
+    transpose32(x, tile_half, l, [](int q) { return q; });
+    __builtin_amdgcn_sched_barrier(0);
     fft32_dif<+1>(x);
+    __builtin_amdgcn_sched_barrier(0);
     // lag q = l + 32*qb sits in x[bitrev5(qb)]; the odd half carries exp(+2*pi*i*q/2048)
     if (h) {
 #pragma unroll
-        for (int qb = 0; qb < 32; ++qb) x[bitrev5(qb)] = cmulc(x[bitrev5(qb)], t.tw2048[32 * qb + l]);
+        for (int b = 0; b < 32; b += 8) {
+            const cf* row = t.tw2048 + 32 * b + launder(l);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[bitrev5(b + j)] = cmulc(x[bitrev5(b + j)], row[32 * j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     // c[q] = even[q] + odd[q].  Registers bitrev5(qb) and bitrev5(qb+16) = bitrev5(qb)+1 are swapped across the
     // half-waves so the low half finishes qb = 0..15 and the high half qb = 16..31.
@@ -216,6 +251,21 @@ __device__ __forceinline__ const cf* replica_column(const cf* __restrict__ table
 __device__ __forceinline__ void load_replica(cf (&p)[32], const cf* __restrict__ rep_column) {
 #pragma unroll
     for (int i = 0; i < 32; ++i) p[i] = rep_column[64 * i];
+}
+// Multiply by the replica straight from L1/L2 in four batches of eight loads (bounded register footprint; the
+// other wavefronts of the SIMD cover the latency).  `rep_sat` is the wave-uniform base of this satellite's
+// [32][64] table: uniform base + lane offset + immediate keeps the 32 addresses out of the register file.
+__device__ __forceinline__ void spectrum_mul_from(cf (&x)[32], const cf* __restrict__ rep_sat, int lane) {
+#pragma unroll
+    for (int b = 0; b < 32; b += 8) {
+        cf p[8];
+        const cf* row = rep_sat + 64 * b + launder(lane);   // re-derived per batch: 8 loads share it via immediates
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p[i] = row[64 * i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[b + i] = cmul(x[b + i], p[i]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 __device__ __forceinline__ void spectrum_mul(cf (&x)[32], const cf (&p)[32]) {
 #pragma unroll
@@ -250,56 +300,46 @@ __device__ __forceinline__ void load_samples(const cf* __restrict__ p, cf* dst) 
     if (C & 1) dst[C - 1] = p[C - 1];
 }
 
+// One millisecond block -> the K polyphase rows in LDS.  u0: carrier cycles at sample 0 of the block; du: cycles
+// per sample (f / fs).  The other wavefronts resident on the SIMD cover the load latency of each chip.
 template <int K>
-struct StageRaw {
-    static constexpr int T = 64 * K;
-    static constexpr int CH = (kChips + T - 1) / T;
-    cf own[CH][K];
-    cf nxt[CH][K > 1 ? K - 1 : 1];
-};
-
-template <int K>
-__device__ __forceinline__ void stage_load(StageRaw<K>& raw, const cf* __restrict__ block, int tid) {
-#pragma unroll
-    for (int c = 0; c < StageRaw<K>::CH; ++c) {
-        const int m = tid + c * StageRaw<K>::T;
-        if (m < kChips) {
-            load_samples<K>(block + K * m, raw.own[c]);
-            const int mn = (m + 1 == kChips) ? 0 : m + 1;
-            if (K > 1) load_samples<K - 1>(block + K * mn, raw.nxt[c]);
-        }
-    }
-}
-
-// u0: carrier cycles at sample 0 of the block; du: cycles per sample (f / fs).
-template <int K>
-__device__ __forceinline__ void stage_compute(const StageRaw<K>& raw, double u0, double du, cf* (&y_rows)[K], int tid) {
-    constexpr int S = 2 * K - 1;
+__device__ __forceinline__ void stage_ms(const cf* __restrict__ block, double u0, double du, cf* (&y_rows)[K], int tid) {
+    constexpr int T = 64 * K;
+    constexpr int CH = (kChips + T - 1) / T;
     const cf rot1 = carrier_from_cycles(du);                          // exp(-2*pi*i*du)
     const cf rwc = carrier_from_cycles(du * (double)(K * kChips));
     const cf rot_wrap = make_float2(rwc.x, -rwc.y);                   // exp(+2*pi*i*du*N): samples that wrapped
-#pragma unroll
-    for (int c = 0; c < StageRaw<K>::CH; ++c) {
-        const int m = tid + c * StageRaw<K>::T;
+#pragma unroll 1
+    for (int c = 0; c < CH; ++c) {
+        const int m = tid + c * T;
         if (m < kChips) {
+            cf w[2 * K - 1];                                          // samples K*m .. K*m + 2K-2, then wiped in place
+            load_samples<K>(block + K * m, w);
+            const int mn = (m + 1 == kChips) ? 0 : m + 1;
+            if (K > 1) load_samples<K - 1>(block + K * mn, w + K);
             cf car = carrier_from_cycles(u0 + du * (double)(K * m));
-            cf pre[S + 1];
-            pre[0] = make_float2(0.f, 0.f);
 #pragma unroll
             for (int i = 0; i < K; ++i) {
-                pre[i + 1] = cadd(pre[i], cmul(raw.own[c][i], car));
+                w[i] = cmul(w[i], car);
                 car = cmul(car, rot1);
             }
             if (K > 1) {
                 if (m + 1 == kChips) car = cmul(car, rot_wrap);
 #pragma unroll
                 for (int i = 0; i < K - 1; ++i) {
-                    pre[K + i + 1] = cadd(pre[K + i], cmul(raw.nxt[c][i], car));
+                    w[K + i] = cmul(w[K + i], car);
                     car = cmul(car, rot1);
                 }
             }
+            cf acc = w[0];                                            // sliding window of K wiped samples
 #pragma unroll
-            for (int r = 0; r < K; ++r) y_rows[r][m] = csub(pre[r + K], pre[r]);
+            for (int i = 1; i < K; ++i) acc = cadd(acc, w[i]);
+            y_rows[0][m] = acc;
+#pragma unroll
+            for (int r = 1; r < K; ++r) {
+                acc = cadd(csub(acc, w[r - 1]), w[r + K - 1]);
+                y_rows[r][m] = acc;
+            }
         }
     }
 }

@@ -319,7 +319,7 @@ double gyp_cell_strength(const gyp_cell* c, int32_t samples_per_ms) {
 // ---------------------------------------------------------------------------------------------------------
 // launches
 // ---------------------------------------------------------------------------------------------------------
-static int blocks_per_cu(int k) { return k >= 4 ? 1 : (k == 2 ? 3 : 4); }
+static int blocks_per_cu(int k) { return 16 / k; }   // 16 wavefronts per CU (4 per SIMD): LDS and VGPR budgets are sized for it
 
 template <typename KernelT, typename ParamsT>
 static int launch_k(gyp_ctx* ctx, KernelT kernel, int k, int grid, const ParamsT& p, size_t lds) {

@@ -19,7 +19,7 @@ namespace gyp {
 // ---------------------------------------------------------------------------------------------------------
 // shared-memory carve (dynamic LDS, 16-byte aligned base, all offsets multiples of 16)
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kTablesBytes = 2 * 1024 * 8;  // tw1024 + tw2048
+constexpr int kTablesBytes = 1024 * 8;  // tw1024 (tw2048 stays in global memory / L1)
 constexpr int kRedBytes = 768;
 template <int K>
 constexpr int lds_bytes() { return kTablesBytes + K * kXchWaveBytes + kRedBytes; }
@@ -42,7 +42,7 @@ static_assert(sizeof(RedScratch) <= kRedBytes, "reduction scratch too large");
 
 struct Smem {
     cf* tw1024;
-    cf* tw2048;
+    const cf* tw2048;   // global
     cf* xch;
     RedScratch* red;
 };
@@ -51,38 +51,35 @@ template <int K>
 __device__ __forceinline__ Smem carve_smem(char* base, const cf* __restrict__ tw_global) {
     Smem s;
     s.tw1024 = reinterpret_cast<cf*>(base);
-    s.tw2048 = s.tw1024 + 1024;
-    s.xch = s.tw2048 + 1024;
+    s.tw2048 = tw_global + 1024;
+    s.xch = s.tw1024 + 1024;
     s.red = reinterpret_cast<RedScratch*>(base + kTablesBytes + K * kXchWaveBytes);
-    for (int i = threadIdx.x; i < 2048; i += 64 * K) s.tw1024[i] = tw_global[i];
+    for (int i = threadIdx.x; i < 1024; i += 64 * K) s.tw1024[i] = tw_global[i];
     return s;
 }
 
 // One millisecond of one cell/channel: stage (all waves) -> barrier -> per-wave correlation.
 // Returns c[j]: complex correlation at lag index k = K*(l + 32*(j + 16*h)) + wave.
 template <int K>
-__device__ __forceinline__ void correlate_ms(const StageRaw<K>& raw, double u0, double du, const Smem& sm,
+__device__ __forceinline__ void correlate_ms(const cf* __restrict__ block, double u0, double du, const Smem& sm,
                                              const cf* __restrict__ rep_table_sat, cf (&c)[16]) {
     const int tid = launder(threadIdx.x), wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
-    const cf* rep_column = rep_table_sat + lane;
     cf* y_rows[K];
 #pragma unroll
     for (int r = 0; r < K; ++r) y_rows[r] = sm.xch + r * kXchWave;
-    stage_compute<K>(raw, u0, du, y_rows, tid);
+    stage_ms<K>(block, u0, du, y_rows, tid);
     if (tid < K) y_rows[tid][kChips] = make_float2(0.f, 0.f);
-    cf rep[32];
-    load_replica(rep, rep_column);   // in flight during the barrier and the forward transform
     __syncthreads();
     cf x[32];
     const cf* yw = y_rows[wave];
 #pragma unroll
     for (int j = 0; j < 32; ++j) x[j] = yw[32 * j + l];
     wave_lds_fence();
-    cf* xch_half = sm.xch + wave * kXchWave + h * kXchHalf;
+    float* tile_half = reinterpret_cast<float*>(sm.xch + wave * kXchWave) + h * kXchTile;
     const LdsTables t{sm.tw1024, sm.tw2048};
-    wave_fft_fwd(x, xch_half, t, l, h);
-    spectrum_mul(x, rep);
-    wave_fft_inv(x, c, xch_half, t, l, h);
+    wave_fft_fwd(x, tile_half, t, l, h);
+    spectrum_mul_from(x, rep_table_sat, lane);
+    wave_fft_inv(x, c, tile_half, t, l, h);
 }
 
 // lag index of output slot j of this lane, or -1 for the one padding slot (q == 1023)
@@ -174,7 +171,7 @@ struct CellsParams {
 };
 
 template <int K, bool COHERENT>
-__global__ __launch_bounds__(64 * K, 2) void corr_cells_kernel(CellsParams p) {
+__global__ __launch_bounds__(64 * K, 4) void corr_cells_kernel(CellsParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int N = K * kChips;
     const Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
@@ -194,19 +191,16 @@ __global__ __launch_bounds__(64 * K, 2) void corr_cells_kernel(CellsParams p) {
             mag[j] = 0.f;
             acc[j] = make_float2(0.f, 0.f);
         }
-        StageRaw<K> raw;
-        stage_load<K>(raw, stream, launder(threadIdx.x));
         for (int ms = 0; ms < p.n_ms; ++ms) {
             // utils.py:92-96: t = arange(N)/fs + (i*N)/fs ; carrier = exp(-1j*tau*f*t)
             const double u0 = d.doppler_hz * ((double)((int64_t)ms * N) * p.inv_fs);
             cf c[16];
-            correlate_ms<K>(raw, u0, du, sm, rep, c);
+            correlate_ms<K>(stream + (int64_t)ms * N, u0, du, sm, rep, c);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 if (COHERENT) acc[j] = cadd(acc[j], c[j]);
                 else mag[j] += sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
             }
-            if (ms + 1 < p.n_ms) stage_load<K>(raw, stream + (int64_t)(ms + 1) * N, launder(threadIdx.x));   // in flight across the barrier
             __syncthreads();  // every wave is done with the exchange tiles before the next block is staged
         }
         if (COHERENT) {
@@ -305,7 +299,7 @@ __device__ __forceinline__ EplResult epl_from_c0(const cf (&c)[16], int code_pha
 }
 
 template <int K>
-__global__ __launch_bounds__(64 * K, 2) void track_step_kernel(TrackStepParams p) {
+__global__ __launch_bounds__(64 * K, 4) void track_step_kernel(TrackStepParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int N = K * kChips;
     const Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
@@ -318,10 +312,8 @@ __global__ __launch_bounds__(64 * K, 2) void track_step_kernel(TrackStepParams p
         // tracker.py:271-281: carrier = exp(-1j*(2*pi*f*t + phi)), t = n/fs + chunk.start_time
         const double du = in.doppler_hz * p.inv_fs;
         const double u0 = in.doppler_hz * p.start_time[in.stream] + in.carrier_phase * 0.15915494309189533577;
-        StageRaw<K> raw;
-        stage_load<K>(raw, p.iq + (int64_t)in.stream * p.stream_stride, launder(threadIdx.x));
         cf c[16];
-        correlate_ms<K>(raw, u0, du, sm, rep, c);
+        correlate_ms<K>(p.iq + (int64_t)in.stream * p.stream_stride, u0, du, sm, rep, c);
         const EplResult r = epl_from_c0<K>(c, in.code_phase, sm.red,
                                            p.profile_out ? p.profile_out + (int64_t)ch * N : nullptr);
         if (threadIdx.x == 0) {
@@ -516,7 +508,7 @@ __device__ __forceinline__ void workgroup_mem_fence_wave() {
 }
 
 template <int K, bool PROF>
-__global__ __launch_bounds__(64 * K, 2) void track_block_kernel(TrackBlockParams p) {
+__global__ __launch_bounds__(64 * K, 4) void track_block_kernel(TrackBlockParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int N = K * kChips;
     const Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
@@ -537,8 +529,6 @@ __global__ __launch_bounds__(64 * K, 2) void track_block_kernel(TrackBlockParams
     LockSums sums = st->sums;
     const bool prof = PROF && p.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
     long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    StageRaw<K> raw;
-    if (!lost && p.n_ms > 0) stage_load<K>(raw, stream, launder(threadIdx.x));
     for (int ms = 0; ms < p.n_ms; ++ms) {
         gyp_track_rec* rec = p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + ms : nullptr;
         if (lost) {  // a dropped channel stays dropped until the host re-creates it (receiver.py:259-267)
@@ -559,7 +549,7 @@ __global__ __launch_bounds__(64 * K, 2) void track_block_kernel(TrackBlockParams
             }
         }
         cf c[16];
-        correlate_ms<K>(raw, u0, du, sm, rep, c);
+        correlate_ms<K>(stream + (int64_t)ms * N, u0, du, sm, rep, c);
         long long t_b = prof ? (long long)__builtin_readcyclecounter() : 0;
         const EplResult r = epl_from_c0<K>(c, code_phase, sm.red, nullptr);
         long long t_c = prof ? (long long)__builtin_readcyclecounter() : 0;
@@ -640,8 +630,6 @@ __global__ __launch_bounds__(64 * K, 2) void track_block_kernel(TrackBlockParams
             }
         }
         long long t_d = prof ? (long long)__builtin_readcyclecounter() : 0;
-        // the next millisecond's raw samples do not depend on the loop filters: in flight across the barrier
-        if (ms + 1 < p.n_ms) stage_load<K>(raw, stream + (int64_t)(ms + 1) * N, launder(threadIdx.x));
         __syncthreads();
         f = sm.red->dstate[0]; phi = sm.red->dstate[1];
         code_phase = sm.red->istate[0]; lost = sm.red->istate[1];
@@ -820,13 +808,13 @@ __global__ __launch_bounds__(256) void synth_iq_kernel(SynthParams p) {
 // 2048-point transforms back to back on LDS-resident data, no global traffic, no workgroup barriers.
 // ---------------------------------------------------------------------------------------------------------
 template <int W>
-__global__ __launch_bounds__(64 * W, 2) void fft_bench_kernel(const cf* __restrict__ tw_tables, const cf* __restrict__ rep_table,
+__global__ __launch_bounds__(64 * W, 4) void fft_bench_kernel(const cf* __restrict__ tw_tables, const cf* __restrict__ rep_table,
                                                                int iters, float* sink) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const Smem sm = carve_smem<W>(smem_raw, tw_tables);
     __syncthreads();
     const int tid = launder(threadIdx.x), wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
-    cf* xch_half = sm.xch + wave * kXchWave + h * kXchHalf;
+    float* xch_half = reinterpret_cast<float*>(sm.xch + wave * kXchWave) + h * kXchTile;
     const LdsTables t{sm.tw1024, sm.tw2048};
     cf x[32];
 #pragma unroll
@@ -834,9 +822,7 @@ __global__ __launch_bounds__(64 * W, 2) void fft_bench_kernel(const cf* __restri
     float acc = 0.f;
     for (int it = 0; it < iters; ++it) {
         wave_fft_fwd(x, xch_half, t, l, h);
-        cf rep[32];
-        load_replica(rep, rep_table + lane);
-        spectrum_mul(x, rep);
+        spectrum_mul_from(x, rep_table, lane);
         cf c[16];
         wave_fft_inv(x, c, xch_half, t, l, h);
 #pragma unroll

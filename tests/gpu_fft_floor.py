@@ -9,7 +9,7 @@ from gypsum_amd.engine import GypsumEngine  # noqa: E402
 eng = GypsumEngine(0)
 eng.set_stream_format(8_184_000, 8184)
 iters = 400
-for waves, wgs_per_cu in ((1, 1), (2, 1), (4, 1), (8, 1), (1, 4), (2, 3), (2, 2), (4, 2)):
+for waves, wgs_per_cu in ((1, 1), (4, 1), (8, 1), (8, 2), (4, 3), (4, 4), (2, 8), (1, 16)):
     ms = C.c_float()
     wgs = 256 * wgs_per_cu
     eng._check(eng.lib.gyp_debug_fft_bench(eng.ctx, waves, wgs, iters, C.byref(ms)))
