@@ -281,6 +281,41 @@ __device__ __forceinline__ cf carrier_from_cycles(double u) {
     sincospif(2.0f * (float)fr, &s, &c);
     return make_float2(c, -s);
 }
+// Same for the per-chip anchors, without the library call's generality: the argument is already reduced to
+// [-0.5, 0.5] revolutions, so fold to the nearest quarter turn and evaluate odd/even Taylor polynomials of
+// t = 2*pi*r, |t| <= pi/4 (truncation < 2e-9, i.e. float32 rounding dominates) -- ~25 instructions.
+__device__ __forceinline__ cf carrier_from_cycles_fast(double u) {
+    const float x = (float)(u - rint(u));
+    const float q = rintf(4.0f * x);                     // -2 .. 2
+    const float t = 6.28318530717958647692f * fmaf(q, -0.25f, x);
+    const float t2 = t * t;
+    float sn = fmaf(t2, 2.7557319e-6f, -1.9841270e-4f);  // t^9/9! ... t^7/7!
+    sn = fmaf(sn, t2, 8.3333333e-3f);
+    sn = fmaf(sn, t2, -1.6666667e-1f);
+    sn = fmaf(sn * t2, t, t);
+    float cs = fmaf(t2, -2.7557319e-7f, 2.4801587e-5f);  // t^10/10! ... t^8/8!
+    cs = fmaf(cs, t2, -1.3888889e-3f);
+    cs = fmaf(cs, t2, 4.1666667e-2f);
+    cs = fmaf(cs, t2, -0.5f);
+    cs = fmaf(cs, t2, 1.0f);
+    const int qi = (int)q & 3;                           // quarter turns, two's complement handles negatives
+    const float c1 = (qi & 1) ? -sn : cs, s1 = (qi & 1) ? cs : sn;   // rotate by 90 degrees if odd
+    const float c = (qi & 2) ? -c1 : c1, s = (qi & 2) ? -s1 : s1;    // and by 180 if bit 1 set
+    return make_float2(c, -s);
+}
+// The two per-millisecond rotation constants of the wipe-off recurrence.
+struct CarrierSteps {
+    cf rot1;      // exp(-2*pi*i*du): one sample
+    cf rot_wrap;  // exp(+2*pi*i*du*N): samples that wrapped to the start of the block
+};
+template <int K>
+__device__ __forceinline__ CarrierSteps carrier_steps(double du) {
+    CarrierSteps cs;
+    cs.rot1 = carrier_from_cycles(du);
+    const cf w = carrier_from_cycles(du * (double)(K * kChips));
+    cs.rot_wrap = make_float2(w.x, -w.y);
+    return cs;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // staging: carrier wipe-off + polyphase pre-sum,  global IQ -> LDS rows y_r[0..1022]
@@ -303,42 +338,51 @@ __device__ __forceinline__ void load_samples(const cf* __restrict__ p, cf* dst) 
 // One millisecond block -> the K polyphase rows in LDS.  u0: carrier cycles at sample 0 of the block; du: cycles
 // per sample (f / fs).  The other wavefronts resident on the SIMD cover the load latency of each chip.
 template <int K>
-__device__ __forceinline__ void stage_ms(const cf* __restrict__ block, double u0, double du, cf* (&y_rows)[K], int tid) {
+__device__ __forceinline__ void stage_ms(const cf* __restrict__ block, double u0, double du, const CarrierSteps& cs,
+                                         cf* (&y_rows)[K], int tid) {
     constexpr int T = 64 * K;
     constexpr int CH = (kChips + T - 1) / T;
-    const cf rot1 = carrier_from_cycles(du);                          // exp(-2*pi*i*du)
-    const cf rwc = carrier_from_cycles(du * (double)(K * kChips));
-    const cf rot_wrap = make_float2(rwc.x, -rwc.y);                   // exp(+2*pi*i*du*N): samples that wrapped
+    const cf rot1 = cs.rot1, rot_wrap = cs.rot_wrap;
+    constexpr int U = K >= 8 ? 1 : (K == 4 ? 2 : 4);               // chips whose loads are issued together
 #pragma unroll 1
-    for (int c = 0; c < CH; ++c) {
-        const int m = tid + c * T;
-        if (m < kChips) {
-            cf w[2 * K - 1];                                          // samples K*m .. K*m + 2K-2, then wiped in place
-            load_samples<K>(block + K * m, w);
-            const int mn = (m + 1 == kChips) ? 0 : m + 1;
-            if (K > 1) load_samples<K - 1>(block + K * mn, w + K);
-            cf car = carrier_from_cycles(u0 + du * (double)(K * m));
+    for (int c0 = 0; c0 < CH; c0 += U) {
+        cf w[U][2 * K - 1];                                          // samples K*m .. K*m + 2K-2, then wiped in place
 #pragma unroll
-            for (int i = 0; i < K; ++i) {
-                w[i] = cmul(w[i], car);
-                car = cmul(car, rot1);
+        for (int u = 0; u < U; ++u) {
+            const int m = tid + (c0 + u) * T;
+            if (m < kChips) {
+                load_samples<K>(block + K * m, w[u]);
+                const int mn = (m + 1 == kChips) ? 0 : m + 1;
+                if (K > 1) load_samples<K - 1>(block + K * mn, w[u] + K);
             }
-            if (K > 1) {
-                if (m + 1 == kChips) car = cmul(car, rot_wrap);
+        }
 #pragma unroll
-                for (int i = 0; i < K - 1; ++i) {
-                    w[K + i] = cmul(w[K + i], car);
+        for (int u = 0; u < U; ++u) {
+            const int m = tid + (c0 + u) * T;
+            if (m < kChips) {
+                cf car = carrier_from_cycles_fast(u0 + du * (double)(K * m));
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    w[u][i] = cmul(w[u][i], car);
                     car = cmul(car, rot1);
                 }
-            }
-            cf acc = w[0];                                            // sliding window of K wiped samples
+                if (K > 1) {
+                    if (m + 1 == kChips) car = cmul(car, rot_wrap);
 #pragma unroll
-            for (int i = 1; i < K; ++i) acc = cadd(acc, w[i]);
-            y_rows[0][m] = acc;
+                    for (int i = 0; i < K - 1; ++i) {
+                        w[u][K + i] = cmul(w[u][K + i], car);
+                        car = cmul(car, rot1);
+                    }
+                }
+                cf acc = w[u][0];                                    // sliding window of K wiped samples
 #pragma unroll
-            for (int r = 1; r < K; ++r) {
-                acc = cadd(csub(acc, w[r - 1]), w[r + K - 1]);
-                y_rows[r][m] = acc;
+                for (int i = 1; i < K; ++i) acc = cadd(acc, w[u][i]);
+                y_rows[0][m] = acc;
+#pragma unroll
+                for (int r = 1; r < K; ++r) {
+                    acc = cadd(csub(acc, w[u][r - 1]), w[u][r + K - 1]);
+                    y_rows[r][m] = acc;
+                }
             }
         }
     }

@@ -449,6 +449,8 @@ int gyp_acquire_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_
     if ((rc = ensure_scratch(ctx, 4, (size_t)n_states * sizeof(AcqSearchState)))) return rc;
     if ((rc = ensure_scratch(ctx, 1, n_cells * sizeof(gyp_cell_desc)))) return rc;
     if ((rc = ensure_scratch(ctx, 2, n_cells * sizeof(gyp_cell)))) return rc;
+    if ((rc = ensure_scratch(ctx, 3, n_cells * sizeof(double)))) return rc;
+    double* d_refined = (double*)ctx->scratch[3];
     AcqSearchState* d_states = (AcqSearchState*)ctx->scratch[4];
     gyp_cell_desc* d_cells = (gyp_cell_desc*)ctx->scratch[1];
     gyp_cell* d_out = (gyp_cell*)ctx->scratch[2];
@@ -460,7 +462,20 @@ int gyp_acquire_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_
         hipLaunchKernelGGL(acq_plan_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_cells);
         rc = gyp_correlate_cells_dev(ctx, iq_dev, stream_stride_samples, n_ms, d_cells, (int32_t)n_cells, GYP_NON_COHERENT, d_out, nullptr);
         if (rc) return rc;
-        hipLaunchKernelGGL(acq_reduce_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_out, ctx->n);
+        RefineParams rp;
+        rp.iq = reinterpret_cast<const cf*>(iq_dev);
+        rp.stream_stride = stream_stride_samples;
+        rp.n_ms = n_ms;
+        rp.n_per_ms = ctx->n;
+        rp.k = ctx->k;
+        rp.states = d_states;
+        rp.cells = d_cells;
+        rp.out = d_out;
+        rp.refined = d_refined;
+        rp.chips = ctx->d_chips;
+        rp.inv_fs = 1.0 / (double)ctx->fs;
+        hipLaunchKernelGGL(acq_refine_kernel, dim3((unsigned)n_cells), dim3(256), 0, ctx->stream, rp);
+        hipLaunchKernelGGL(acq_reduce_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_out, d_refined, ctx->n);
     }
     hipLaunchKernelGGL(acq_plan_coherent_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_cells);
     rc = gyp_correlate_cells_dev(ctx, iq_dev, stream_stride_samples, n_ms, d_cells, n_states, GYP_COHERENT, d_out, nullptr);

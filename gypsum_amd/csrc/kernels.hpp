@@ -37,6 +37,7 @@ struct RedScratch {
     float taps[4];      // early re/im, late re/im
     double dstate[4];   // new doppler, new carrier phase
     int istate[4];      // new code phase, lost flag
+    CarrierSteps steps; // rotation constants of the next millisecond's wipe-off
 };
 static_assert(sizeof(RedScratch) <= kRedBytes, "reduction scratch too large");
 
@@ -61,13 +62,13 @@ __device__ __forceinline__ Smem carve_smem(char* base, const cf* __restrict__ tw
 // One millisecond of one cell/channel: stage (all waves) -> barrier -> per-wave correlation.
 // Returns c[j]: complex correlation at lag index k = K*(l + 32*(j + 16*h)) + wave.
 template <int K>
-__device__ __forceinline__ void correlate_ms(const cf* __restrict__ block, double u0, double du, const Smem& sm,
-                                             const cf* __restrict__ rep_table_sat, cf (&c)[16]) {
+__device__ __forceinline__ void correlate_ms(const cf* __restrict__ block, double u0, double du, const CarrierSteps& cs,
+                                             const Smem& sm, const cf* __restrict__ rep_table_sat, cf (&c)[16]) {
     const int tid = launder(threadIdx.x), wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
     cf* y_rows[K];
 #pragma unroll
     for (int r = 0; r < K; ++r) y_rows[r] = sm.xch + r * kXchWave;
-    stage_ms<K>(block, u0, du, y_rows, tid);
+    stage_ms<K>(block, u0, du, cs, y_rows, tid);
     if (tid < K) y_rows[tid][kChips] = make_float2(0.f, 0.f);
     __syncthreads();
     cf x[32];
@@ -82,12 +83,17 @@ __device__ __forceinline__ void correlate_ms(const cf* __restrict__ block, doubl
     wave_fft_inv(x, c, tile_half, t, l, h);
 }
 
-// lag index of output slot j of this lane, or -1 for the one padding slot (q == 1023)
+// Output slot j of a lane holds lag index  K*(l + 32*(j + 16*h)) + wave  =  lag_base + 32*K*j.  The single padding
+// slot (q == 1023) is slot 15 of lane 63.
+template <int K>
+__device__ __forceinline__ int lag_base(int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    return K * ((lane & 31) + 512 * (lane >> 5)) + wave;
+}
+__device__ __forceinline__ bool slot_valid(int j, int tid) { return j != 15 || (tid & 63) != 63; }
 template <int K>
 __device__ __forceinline__ int lag_index(int j, int tid) {
-    const int lane = tid & 63, wave = tid >> 6;
-    const int q = (lane & 31) + 32 * (j + 16 * (lane >> 5));
-    return q < kChips ? K * q + wave : -1;
+    return slot_valid(j, tid) ? lag_base<K>(tid) + 32 * K * j : -1;
 }
 
 struct ProfileStats {
@@ -104,13 +110,13 @@ __device__ __forceinline__ ProfileStats profile_stats(const float (&vals)[16], c
                                                       KeyFn key_of) {
     const int tid = launder(threadIdx.x);
     const int wave = tid >> 6;
+    const int base = lag_base<K>(tid);
     Best b{-1.0f, 0x7fffffff};
     float part = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const int idx = lag_index<K>(j, tid);
-        if (idx >= 0) {
-            b = better(b, Best{vals[j], key_of(idx)});
+        if (slot_valid(j, tid)) {
+            b = better(b, Best{vals[j], key_of(base + 32 * K * j)});
             part += vals[j];
         }
     }
@@ -120,10 +126,9 @@ __device__ __forceinline__ ProfileStats profile_stats(const float (&vals)[16], c
     bool owner = false;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const int idx = lag_index<K>(j, tid);
-        if (idx >= 0) {
+        if (slot_valid(j, tid)) {
             cnt += (vals[j] == wb.v) ? 1 : 0;
-            if (key_of(idx) == wb.key) {
+            if (vals[j] == wb.v && key_of(base + 32 * K * j) == wb.key) {
                 owner = true;
                 if (cvals) mine = cvals[j];
             }
@@ -183,6 +188,7 @@ __global__ __launch_bounds__(64 * K, 4) void corr_cells_kernel(CellsParams p) {
         if (d.sat_id < 1 || d.sat_id > 32) continue;  // padding cell (uniform across the workgroup)
         const cf* rep = replica_column(p.replica_table, d.sat_id - 1, 0);
         const double du = d.doppler_hz * p.inv_fs;
+        const CarrierSteps cs = carrier_steps<K>(du);
         const cf* stream = p.iq + (int64_t)d.stream * p.stream_stride;
         float mag[16];
         cf acc[16];
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(64 * K, 4) void corr_cells_kernel(CellsParams p) {
             // utils.py:92-96: t = arange(N)/fs + (i*N)/fs ; carrier = exp(-1j*tau*f*t)
             const double u0 = d.doppler_hz * ((double)((int64_t)ms * N) * p.inv_fs);
             cf c[16];
-            correlate_ms<K>(stream + (int64_t)ms * N, u0, du, sm, rep, c);
+            correlate_ms<K>(stream + (int64_t)ms * N, u0, du, cs, sm, rep, c);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 if (COHERENT) acc[j] = cadd(acc[j], c[j]);
@@ -278,14 +284,24 @@ __device__ __forceinline__ EplResult epl_from_c0(const cf (&c)[16], int code_pha
     const int tid = launder(threadIdx.x);
     float mag[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        mag[j] = sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
-        const int idx = lag_index<K>(j, tid);
-        if (idx >= 0) {   // the owners of the early / late taps publish them ahead of the reduction barrier
-            if (idx == ie) { red->taps[0] = c[j].x; red->taps[1] = c[j].y; }
-            if (idx == il) { red->taps[2] = c[j].x; red->taps[3] = c[j].y; }
-            if (profile_row) { int k = idx - s; profile_row[k < 0 ? k + N : k] = mag[j]; }
+    for (int j = 0; j < 16; ++j) mag[j] = sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
+    // The owners of the early / late taps publish them ahead of the reduction barrier.  Lag index idx lives in
+    // wavefront idx % K, lane (q & 31) + 32*(q >> 9), slot (q >> 5) & 15 with q = idx / K: all wave-uniform.
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int idx = t ? il : ie, q = idx / K;
+        if ((tid >> 6) == idx % K && (tid & 63) == (q & 31) + 32 * (q >> 9)) {
+            const int slot = (q >> 5) & 15;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j == slot) { red->taps[2 * t] = c[j].x; red->taps[2 * t + 1] = c[j].y; }
         }
+    }
+    if (profile_row) {
+        const int base = lag_base<K>(tid);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (slot_valid(j, tid)) { int k = base + 32 * K * j - s; profile_row[k < 0 ? k + N : k] = mag[j]; }
     }
     const ProfileStats st = profile_stats<K>(mag, c, red, [s](int idx) { int k = idx - s; return k < 0 ? k + N : k; });
     EplResult r;
@@ -313,7 +329,7 @@ __global__ __launch_bounds__(64 * K, 4) void track_step_kernel(TrackStepParams p
         const double du = in.doppler_hz * p.inv_fs;
         const double u0 = in.doppler_hz * p.start_time[in.stream] + in.carrier_phase * 0.15915494309189533577;
         cf c[16];
-        correlate_ms<K>(p.iq + (int64_t)in.stream * p.stream_stride, u0, du, sm, rep, c);
+        correlate_ms<K>(p.iq + (int64_t)in.stream * p.stream_stride, u0, du, carrier_steps<K>(du), sm, rep, c);
         const EplResult r = epl_from_c0<K>(c, in.code_phase, sm.red,
                                            p.profile_out ? p.profile_out + (int64_t)ch * N : nullptr);
         if (threadIdx.x == 0) {
@@ -381,17 +397,20 @@ __device__ __forceinline__ bool near(double v, double thr) { return fabs(v - thr
 __device__ __forceinline__ LockVerdict lock_from_sums(const LockSums& s, int64_t n_err) {
     LockVerdict out{false, false};
     if (n_err < kLockWindow) return out;                       // tracker.py:164-167
-    const double me = s.se / kLockWindow;
-    const double ve = s.see / kLockWindow - me * me;
-    const double vneg = s.cn >= 2 ? s.nrr / s.cn - (s.nr / s.cn) * (s.nr / s.cn) : 0.0;
-    const double vpos = s.cp >= 2 ? s.prr / s.cp - (s.pr / s.cp) * (s.pr / s.cp) : 0.0;
+    // one-pass moments with reciprocal multiplies (no float64 divides on the per-ms path); anything within 1e-9 of
+    // a threshold is re-decided by the exact two-pass evaluation
+    const double rw = 1.0 / kLockWindow;
+    const double me = s.se * rw;
+    const double ve = s.see * rw - me * me;
+    const double rn = s.cn >= 2 ? 1.0 / (double)s.cn : 0.0, rp = s.cp >= 2 ? 1.0 / (double)s.cp : 0.0;
+    const double vneg = s.nrr * rn - (s.nr * rn) * (s.nr * rn);
+    const double vpos = s.prr * rp - (s.pr * rp) * (s.pr * rp);
     const double iv = (vneg + vpos) / 2.0;
     const bool var_ok = ve < 900.0, i_ok = iv < 2.0;
     out.marginal = near(ve, 900.0) || near(iv, 2.0);
     bool rot_ok = true;
     if (var_ok && i_ok) {
-        const double mr = s.cn >= 2 ? s.nr / s.cn : 0.0, mi = s.cn >= 2 ? s.ni / s.cn : 0.0;
-        const double ang = 180.0 - pymod((atan2(mi, mr) / 6.283185307179586) * 360.0, 180.0);
+        const double ang = 180.0 - pymod((atan2(s.ni * rn, s.nr * rn) / 6.283185307179586) * 360.0, 180.0);
         const double centered = ang < 90.0 ? ang : 180.0 - ang;
         rot_ok = centered < 6.0;                               // abs(bool) quirk, tracker.py:197
         out.marginal = out.marginal || near(centered, 6.0);
@@ -527,6 +546,7 @@ __global__ __launch_bounds__(64 * K, 4) void track_block_kernel(TrackBlockParams
     int64_t n_steps = st->n_steps;
     double dll_phase = st->dll_phase, last_watchdog = st->last_watchdog_time;
     LockSums sums = st->sums;
+    CarrierSteps cs = carrier_steps<K>(f * p.inv_fs);
     const bool prof = PROF && p.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
     long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int ms = 0; ms < p.n_ms; ++ms) {
@@ -549,7 +569,7 @@ __global__ __launch_bounds__(64 * K, 4) void track_block_kernel(TrackBlockParams
             }
         }
         cf c[16];
-        correlate_ms<K>(stream + (int64_t)ms * N, u0, du, sm, rep, c);
+        correlate_ms<K>(stream + (int64_t)ms * N, u0, du, cs, sm, rep, c);
         long long t_b = prof ? (long long)__builtin_readcyclecounter() : 0;
         const EplResult r = epl_from_c0<K>(c, code_phase, sm.red, nullptr);
         long long t_c = prof ? (long long)__builtin_readcyclecounter() : 0;
@@ -615,6 +635,7 @@ __global__ __launch_bounds__(64 * K, 4) void track_block_kernel(TrackBlockParams
             if (lane == 0) {
                 sm.red->dstate[0] = nf; sm.red->dstate[1] = nphi;
                 sm.red->istate[0] = new_code_phase; sm.red->istate[1] = lost;
+                sm.red->steps = carrier_steps<K>(nf * p.inv_fs);
                 if (rec) {
                     gyp_track_rec o;
                     o.peak_re = r.peak.x; o.peak_im = r.peak.y;
@@ -633,6 +654,7 @@ __global__ __launch_bounds__(64 * K, 4) void track_block_kernel(TrackBlockParams
         __syncthreads();
         f = sm.red->dstate[0]; phi = sm.red->dstate[1];
         code_phase = sm.red->istate[0]; lost = sm.red->istate[1];
+        cs = sm.red->steps;
         if (prof) {
             const long long t_e = (long long)__builtin_readcyclecounter();
             tp[0] += t_b - t_a; tp[1] += t_c - t_b; tp[2] += t_d - t_c; tp[3] += t_e - t_d; tp[4] += 1;
@@ -700,18 +722,104 @@ __device__ __forceinline__ double cell_strength(const gyp_cell& c, int n) {
     return pk / ((c.sum - (double)c.n_max * pk) / (double)(n - c.n_max));
 }
 
+// ---- float64 tie-break --------------------------------------------------------------------------------------
+// Near the top of its lobe the non-coherent peak changes by ~1e-6 (relative) per Hz of Doppler, the same order as
+// float32 rounding, so "which bin holds the largest maximum" (acquisition.py:180-182) cannot always be decided from
+// the float32 cells.  Bins whose peak is within kTieBand of the level's maximum are therefore re-evaluated in
+// float64, directly in the time domain, at their own arg-max lag:
+//     V = sum_ms | sum_n x[ms, n] * exp(-2*pi*i*f*t(ms, n)) * code[(n - lag) mod N] |
+// which is exactly the profile value the float64 reference compares.  Usually only the finest levels have ties.
+constexpr float kTieBand = 2e-5f;
+
+struct RefineParams {
+    const cf* iq;
+    int64_t stream_stride;
+    int32_t n_ms, n_per_ms, k;
+    const AcqSearchState* states;
+    const gyp_cell_desc* cells;     // [n_states][kMaxBins]
+    const gyp_cell* out;            // [n_states][kMaxBins]
+    double* refined;                // [n_states][kMaxBins], < 0 where not a candidate
+    const uint8_t* chips;           // [32][1023]
+    double inv_fs;
+};
+
+__global__ __launch_bounds__(256) void acq_refine_kernel(RefineParams p) {
+    __shared__ double red_re[4], red_im[4];
+    __shared__ float level_max;
+    const int state = blockIdx.x / kMaxBins, bin = blockIdx.x % kMaxBins;
+    const AcqSearchState st = p.states[state];
+    if (bin >= st.n_bins) return;
+    if (threadIdx.x == 0) {
+        float m = -1.f;
+        int n_close = 0;
+        for (int b = 0; b < st.n_bins; ++b) m = fmaxf(m, p.out[state * kMaxBins + b].peak);
+        for (int b = 0; b < st.n_bins; ++b) n_close += p.out[state * kMaxBins + b].peak >= m * (1.0f - kTieBand) ? 1 : 0;
+        level_max = n_close > 1 ? m : -1.f;     // a lone maximum needs no tie-break
+    }
+    __syncthreads();
+    const gyp_cell cell = p.out[blockIdx.x];
+    if (level_max < 0.f || cell.peak < level_max * (1.0f - kTieBand)) {
+        if (threadIdx.x == 0) p.refined[blockIdx.x] = -1.0;
+        return;
+    }
+    const gyp_cell_desc d = p.cells[blockIdx.x];
+    const int n = p.n_per_ms, lag = cell.argmax;
+    const uint8_t* code = p.chips + (d.sat_id - 1) * kChips;
+    const cf* stream = p.iq + (int64_t)d.stream * p.stream_stride;
+    const double du = d.doppler_hz * p.inv_fs;
+    double s_step, c_step;
+    sincospi(2.0 * (du * 256.0 - rint(du * 256.0)), &s_step, &c_step);     // exp(-2*pi*i*du*256) = (c, -s)
+    double total = 0.0;
+    for (int ms = 0; ms < p.n_ms; ++ms) {
+        const cf* block = stream + (int64_t)ms * n;
+        const double u = d.doppler_hz * (((double)((int64_t)ms * n) + (double)threadIdx.x) * p.inv_fs);
+        double sn, cs;
+        sincospi(2.0 * (u - rint(u)), &sn, &cs);
+        double car_re = cs, car_im = -sn, acc_re = 0.0, acc_im = 0.0;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            int ci = i - lag;
+            ci = ci < 0 ? ci + n : ci;
+            const double sgn = code[ci / p.k] ? 1.0 : -1.0;
+            const cf x = block[i];
+            acc_re += sgn * ((double)x.x * car_re - (double)x.y * car_im);
+            acc_im += sgn * ((double)x.x * car_im + (double)x.y * car_re);
+            const double nr = car_re * c_step + car_im * s_step;             // car *= (c_step - i*s_step)
+            car_im = car_im * c_step - car_re * s_step;
+            car_re = nr;
+        }
+        acc_re = wave_sum(acc_re);
+        acc_im = wave_sum(acc_im);
+        if ((threadIdx.x & 63) == 0) { red_re[threadIdx.x >> 6] = acc_re; red_im[threadIdx.x >> 6] = acc_im; }
+        __syncthreads();
+        const double re = (red_re[0] + red_re[1]) + (red_re[2] + red_re[3]);
+        const double im = (red_im[0] + red_im[1]) + (red_im[2] + red_im[3]);
+        total += sqrt(re * re + im * im);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) p.refined[blockIdx.x] = total;
+}
+
 // Fold one level's cells into the search state: best bin = first bin holding the largest maximum
-// (acquisition.py:180-182), centre <- its Doppler, spread halves, overall best replaced on strictly greater
-// strength (:92-101).
-__global__ void acq_reduce_kernel(AcqSearchState* states, int n_states, const gyp_cell* cells, int n_samples) {
+// (acquisition.py:180-182; float64 tie-break values where present), centre <- its Doppler, spread halves, overall
+// best replaced on strictly greater strength (:92-101).
+__global__ void acq_reduce_kernel(AcqSearchState* states, int n_states, const gyp_cell* cells, const double* refined,
+                                  int n_samples) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_states) return;
     AcqSearchState s = states[i];
     int best_b = 0;
     float best_peak = -1.f;
+    double best_ref = -1.0;
+    bool any_ref = false;
+    for (int b = 0; b < s.n_bins; ++b) any_ref = any_ref || refined[i * kMaxBins + b] >= 0.0;
     for (int b = 0; b < s.n_bins; ++b) {
-        const float pk = cells[i * kMaxBins + b].peak;
-        if (pk > best_peak) { best_peak = pk; best_b = b; }
+        if (any_ref) {
+            const double v = refined[i * kMaxBins + b];
+            if (v > best_ref) { best_ref = v; best_b = b; }
+        } else {
+            const float pk = cells[i * kMaxBins + b].peak;
+            if (pk > best_peak) { best_peak = pk; best_b = b; }
+        }
     }
     const gyp_cell c = cells[i * kMaxBins + best_b];
     const double strength = cell_strength(c, n_samples);
