@@ -121,7 +121,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"])
-    ap.add_argument("--streams", type=int, default=64, help="IQ streams per GPU")
+    ap.add_argument("--streams", type=int, default=128, help="IQ streams per GPU")
     ap.add_argument("--track-ms", type=int, default=1000, help="ms of signal per stream per step (cfg3)")
     ap.add_argument("--grid-ms", type=int, default=64, help="ms of signal per stream per step (cfg2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -311,8 +311,8 @@ struct CarrierSteps {
 template <int K>
 __device__ __forceinline__ CarrierSteps carrier_steps(double du) {
     CarrierSteps cs;
-    cs.rot1 = carrier_from_cycles(du);
-    const cf w = carrier_from_cycles(du * (double)(K * kChips));
+    cs.rot1 = carrier_from_cycles_fast(du);
+    const cf w = carrier_from_cycles_fast(du * (double)(K * kChips));
     cs.rot_wrap = make_float2(w.x, -w.y);
     return cs;
 }

@@ -176,7 +176,7 @@ struct CellsParams {
 };
 
 template <int K, bool COHERENT>
-__global__ __launch_bounds__(64 * K, 4) void corr_cells_kernel(CellsParams p) {
+__global__ __launch_bounds__(64 * K, K >= 8 ? 4 : 3) void corr_cells_kernel(CellsParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int N = K * kChips;
     const Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
@@ -315,7 +315,7 @@ __device__ __forceinline__ EplResult epl_from_c0(const cf (&c)[16], int code_pha
 }
 
 template <int K>
-__global__ __launch_bounds__(64 * K, 4) void track_step_kernel(TrackStepParams p) {
+__global__ __launch_bounds__(64 * K, K >= 8 ? 4 : 3) void track_step_kernel(TrackStepParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int N = K * kChips;
     const Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
@@ -379,10 +379,16 @@ struct ChanState {
     double peak_im[kPeakHistory];
 };
 
-// Python's float % positive-int
+// Python's float % for b > 0: fmod() (exact) then the sign fix-up of CPython's float_rem.  The loop filters only
+// ever step a little outside [0, b), where fmod(a, b) is a itself or a - b (exact, Sterbenz), so the library
+// fmod (a long-division loop) is kept for the general case only.
 __device__ __forceinline__ double pymod(double a, double b) {
-    double r = fmod(a, b);
-    if (r != 0.0 && ((r < 0.0) != (b < 0.0))) r += b;
+    double r;
+    if (a >= 0.0 && a < b) r = a;
+    else if (a >= b && a < 2.0 * b) r = a - b;
+    else if (a < 0.0 && a > -b) r = a;
+    else r = fmod(a, b);
+    if (r != 0.0 && r < 0.0) r += b;
     return r;
 }
 
@@ -527,7 +533,7 @@ __device__ __forceinline__ void workgroup_mem_fence_wave() {
 }
 
 template <int K, bool PROF>
-__global__ __launch_bounds__(64 * K, 4) void track_block_kernel(TrackBlockParams p) {
+__global__ __launch_bounds__(64 * K, K >= 8 ? 4 : 3) void track_block_kernel(TrackBlockParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int N = K * kChips;
     const Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
@@ -546,6 +552,7 @@ __global__ __launch_bounds__(64 * K, 4) void track_block_kernel(TrackBlockParams
     int64_t n_steps = st->n_steps;
     double dll_phase = st->dll_phase, last_watchdog = st->last_watchdog_time;
     LockSums sums = st->sums;
+    int pos_e = (int)(n_steps % kLockWindow), pos_p = (int)(n_steps % kPeakHistory), pos_refresh = (int)(n_steps % kLockRefresh);
     CarrierSteps cs = carrier_steps<K>(f * p.inv_fs);
     const bool prof = PROF && p.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
     long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -563,9 +570,10 @@ __global__ __launch_bounds__(64 * K, 4) void track_block_kernel(TrackBlockParams
         double leave_e = 0.0, leave_pr = 0.0, leave_pi = 0.0;
         if (wave == 0) {
             if (n_steps >= kLockWindow) {
-                leave_e = st->err_ring[n_steps % kLockWindow];
-                leave_pr = st->peak_re[(n_steps - kLockWindow) % kPeakHistory];
-                leave_pi = st->peak_im[(n_steps - kLockWindow) % kPeakHistory];
+                const int pos_leave = pos_p >= kLockWindow ? pos_p - kLockWindow : pos_p - kLockWindow + kPeakHistory;
+                leave_e = st->err_ring[pos_e];
+                leave_pr = st->peak_re[pos_leave];
+                leave_pi = st->peak_im[pos_leave];
             }
         }
         cf c[16];
@@ -584,7 +592,7 @@ __global__ __launch_bounds__(64 * K, 4) void track_block_kernel(TrackBlockParams
             if (dll < 0.0) dll += 2046.0;
             // ---- histories, tracker.py:346-347 (the peak joins the window before is_locked() looks at it)
             const double pr = (double)r.peak.x, pim = (double)r.peak.y;
-            if (lane == 0) { st->peak_re[n % kPeakHistory] = pr; st->peak_im[n % kPeakHistory] = pim; }
+            if (lane == 0) { st->peak_re[pos_p] = pr; st->peak_im[pos_p] = pim; }
             if (n >= kLockWindow) {
                 if (leave_pr < 0.0) { sums.nr -= leave_pr; sums.ni -= leave_pi; sums.nrr -= leave_pr * leave_pr; --sums.cn; }
                 else { sums.pr -= leave_pr; sums.prr -= leave_pr * leave_pr; --sums.cp; }
@@ -595,14 +603,14 @@ __global__ __launch_bounds__(64 * K, 4) void track_block_kernel(TrackBlockParams
             const double err = pr * pim;
             LockVerdict lv = lock_from_sums(sums, n);
             bool locked = lv.locked;
-            if (lv.marginal || (n % kLockRefresh) == kLockRefresh - 1) {
+            if (lv.marginal || pos_refresh == kLockRefresh - 1) {
                 workgroup_mem_fence_wave();                 // lane 0's ring stores -> every lane of this wavefront
                 LockSums fresh;
                 locked = is_locked_exact_wave(st, n, n + 1, lane, fresh);
                 sums = fresh;
             }
             const double bw = locked ? 3.0 : 6.0;
-            const double tps = 1.0 / p.fs;
+            const double tps = p.inv_fs;                // == 1.0 / samples_per_second, formed on the host
             const double alpha = 4.0 * (1.0 / sqrt(2.0)) * bw * tps;
             const double beta = 4.0 * (bw * bw) * tps;
             double nphi = pymod(phi + err * alpha, 6.283185307179586);
@@ -610,7 +618,10 @@ __global__ __launch_bounds__(64 * K, 4) void track_block_kernel(TrackBlockParams
             // the error joins its window after is_locked() has been evaluated (tracker.py:251,261)
             if (n >= kLockWindow) { sums.se -= leave_e; sums.see -= leave_e * leave_e; }
             sums.se += err; sums.see += err * err;
-            if (lane == 0) st->err_ring[n % kLockWindow] = err;
+            if (lane == 0) st->err_ring[pos_e] = err;
+            pos_e = pos_e + 1 == kLockWindow ? 0 : pos_e + 1;
+            pos_p = pos_p + 1 == kPeakHistory ? 0 : pos_p + 1;
+            pos_refresh = pos_refresh + 1 == kLockRefresh ? 0 : pos_refresh + 1;
             const float mean_excl = (float)((r.sum - (double)r.n_max * (double)r.best.v) / (double)(N - r.n_max));
             const double rec_f = nf, rec_phi = nphi;
             // ---- circularity watchdog, tracker.py:370-387
