@@ -26,6 +26,7 @@ constexpr int kXchWave = kXchWaveFloats / 2; // in complex elements: 1088 >= the
 constexpr int kXchWaveBytes = kXchWaveFloats * 4;  // 8704 B per wavefront: 16 wavefronts (4 per SIMD) fit a CU's LDS
 
 typedef float2 cf;
+constexpr int kTwBatch = 8;   // twiddle / replica values fetched per scheduling group (bounds their register footprint)
 
 // Hide a thread-id-derived value from the optimiser so that everything computed from it is re-derived where it
 // is used (a handful of integer instructions) instead of being hoisted out of the per-millisecond loop as a
@@ -179,10 +180,10 @@ __device__ __forceinline__ void transpose32(cf (&x)[32], float* tile_half, int l
 __device__ __forceinline__ void wave_fft_fwd(cf (&x)[32], float* tile_half, const LdsTables& t, int l, int h) {
     if (h) {
 #pragma unroll
-        for (int b = 0; b < 32; b += 8) {
+        for (int b = 0; b < 32; b += kTwBatch) {
             const cf* row = t.tw2048 + 32 * b + launder(l);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[b + j] = cmul(x[b + j], row[32 * j]);
+            for (int j = 0; j < kTwBatch; ++j) x[b + j] = cmul(x[b + j], row[32 * j]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -190,9 +191,9 @@ __device__ __forceinline__ void wave_fft_fwd(cf (&x)[32], float* tile_half, cons
     fft32_dif<-1>(x);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int b = 0; b < 32; b += 8) {
+    for (int b = 0; b < 32; b += kTwBatch) {
 #pragma unroll
-        for (int g = b; g < b + 8; ++g)
+        for (int g = b; g < b + kTwBatch; ++g)
             if (g) x[bitrev5(g)] = cmul(x[bitrev5(g)], t.tw1024[32 * g + l]);
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -210,9 +211,9 @@ __device__ __forceinline__ void wave_fft_inv(cf (&x)[32], cf (&c)[16], float* ti
     fft32_dit<+1>(x);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int b = 0; b < 32; b += 8) {
+    for (int b = 0; b < 32; b += kTwBatch) {
 #pragma unroll
-        for (int q = b; q < b + 8; ++q)
+        for (int q = b; q < b + kTwBatch; ++q)
             if (q) x[q] = cmulc(x[q], t.tw1024[32 * q + l]);
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -223,10 +224,10 @@ __device__ __forceinline__ void wave_fft_inv(cf (&x)[32], cf (&c)[16], float* ti
     // lag q = l + 32*qb sits in x[bitrev5(qb)]; the odd half carries exp(+2*pi*i*q/2048)
     if (h) {
 #pragma unroll
-        for (int b = 0; b < 32; b += 8) {
+        for (int b = 0; b < 32; b += kTwBatch) {
             const cf* row = t.tw2048 + 32 * b + launder(l);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[bitrev5(b + j)] = cmulc(x[bitrev5(b + j)], row[32 * j]);
+            for (int j = 0; j < kTwBatch; ++j) x[bitrev5(b + j)] = cmulc(x[bitrev5(b + j)], row[32 * j]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -257,13 +258,13 @@ __device__ __forceinline__ void load_replica(cf (&p)[32], const cf* __restrict__
 // [32][64] table: uniform base + lane offset + immediate keeps the 32 addresses out of the register file.
 __device__ __forceinline__ void spectrum_mul_from(cf (&x)[32], const cf* __restrict__ rep_sat, int lane) {
 #pragma unroll
-    for (int b = 0; b < 32; b += 8) {
-        cf p[8];
+    for (int b = 0; b < 32; b += kTwBatch) {
+        cf p[kTwBatch];
         const cf* row = rep_sat + 64 * b + launder(lane);   // re-derived per batch: 8 loads share it via immediates
 #pragma unroll
-        for (int i = 0; i < 8; ++i) p[i] = row[64 * i];
+        for (int i = 0; i < kTwBatch; ++i) p[i] = row[64 * i];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) x[b + i] = cmul(x[b + i], p[i]);
+        for (int i = 0; i < kTwBatch; ++i) x[b + i] = cmul(x[b + i], p[i]);
         __builtin_amdgcn_sched_barrier(0);
     }
 }

@@ -19,8 +19,11 @@ namespace gyp {
 // ---------------------------------------------------------------------------------------------------------
 // shared-memory carve (dynamic LDS, 16-byte aligned base, all offsets multiples of 16)
 // ---------------------------------------------------------------------------------------------------------
+constexpr int kLockWindow = 250;    // config.py:23
+constexpr int kPeakHistory = 1000;  // tracker.py:146 (deque maxlen)
+constexpr int kLockRefresh = 1024;  // exact two-pass recomputation of the sliding sums every this many ms
 constexpr int kTablesBytes = 1024 * 8;  // tw1024 (tw2048 stays in global memory / L1)
-constexpr int kRedBytes = 768;
+constexpr int kRedBytes = 1024;
 template <int K>
 constexpr int lds_bytes() { return kTablesBytes + K * kXchWaveBytes + kRedBytes; }
 
@@ -32,12 +35,32 @@ struct WaveCand {   // one wavefront's candidate for the profile maximum
     int cnt;        // elements equal to the wavefront's maximum
     int pad;
 };
+// Sliding-window sums behind is_locked() (tracker.py:157-203): the last 250 Costas errors and the last 250 prompt
+// peaks split by the sign of I.  Updated in O(1) per millisecond; re-derived exactly (two-pass, like np.var) every
+// kLockRefresh ms and whenever a comparison lands within 1e-9 (relative) of its threshold.
+struct LockSums {
+    double se, see;                  // sum e, sum e^2
+    double nr, ni, nrr;              // negative pole: sum re, sum im, sum re^2
+    double pr, prr;                  // positive pole: sum re, sum re^2
+    int32_t cn, cp;                  // pole populations
+};
+
+// Scalar loop-filter state of a device-resident channel.  It lives in LDS between milliseconds (only wavefront 0
+// touches it, inside the update section), so no wavefront carries it in registers across the transforms.
+struct LoopState {
+    double dll_phase, last_watchdog;
+    int64_t n_steps;
+    LockSums sums;
+    int32_t pos_e, pos_p, pos_refresh, pad;
+};
+
 struct RedScratch {
     WaveCand cand[16];
     float taps[4];      // early re/im, late re/im
     double dstate[4];   // new doppler, new carrier phase
     int istate[4];      // new code phase, lost flag
     CarrierSteps steps; // rotation constants of the next millisecond's wipe-off
+    LoopState loop;
 };
 static_assert(sizeof(RedScratch) <= kRedBytes, "reduction scratch too large");
 
@@ -351,19 +374,6 @@ __global__ __launch_bounds__(64 * K, K >= 8 ? 4 : 3) void track_step_kernel(Trac
 // ---------------------------------------------------------------------------------------------------------
 // tracking, device-resident loops
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kLockWindow = 250;    // config.py:23
-constexpr int kPeakHistory = 1000;  // tracker.py:146 (deque maxlen)
-constexpr int kLockRefresh = 1024;  // exact two-pass recomputation of the sliding sums every this many ms
-
-// Sliding-window sums behind is_locked() (tracker.py:157-203): the last 250 Costas errors and the last 250 prompt
-// peaks split by the sign of I.  Updated in O(1) per millisecond; re-derived exactly (two-pass, like np.var) every
-// kLockRefresh ms and whenever a comparison lands within 1e-9 (relative) of its threshold.
-struct LockSums {
-    double se, see;                  // sum e, sum e^2
-    double nr, ni, nrr;              // negative pole: sum re, sum im, sum re^2
-    double pr, prr;                  // positive pole: sum re, sum re^2
-    int32_t cn, cp;                  // pole populations
-};
 
 struct ChanState {
     int32_t stream, sat_id;
@@ -544,45 +554,58 @@ __global__ __launch_bounds__(64 * K, K >= 8 ? 4 : 3) void track_block_kernel(Tra
     ChanState* st = p.states + ch;
     const cf* rep = replica_column(p.replica_table, st->sat_id - 1, 0);
     const cf* stream = p.iq + (int64_t)st->stream * p.stream_stride;
-    // loop state: uniform across the workgroup, re-broadcast through LDS every millisecond
-    double f = st->doppler, phi = st->carrier_phase;
-    int code_phase = st->code_phase;
-    int lost = st->lost;
-    // wavefront 0 carries the scalar filter state in registers (identical in all its lanes), written back once
-    int64_t n_steps = st->n_steps;
-    double dll_phase = st->dll_phase, last_watchdog = st->last_watchdog_time;
-    LockSums sums = st->sums;
-    int pos_e = (int)(n_steps % kLockWindow), pos_p = (int)(n_steps % kPeakHistory), pos_refresh = (int)(n_steps % kLockRefresh);
-    CarrierSteps cs = carrier_steps<K>(f * p.inv_fs);
+    // Loop state lives in LDS between milliseconds (RedScratch::dstate / istate / steps / loop) and is re-read where
+    // it is needed, so that no wavefront carries it in registers across the transforms.
+    if (threadIdx.x == 0) {
+        LoopState ls;
+        ls.dll_phase = st->dll_phase; ls.last_watchdog = st->last_watchdog_time; ls.n_steps = st->n_steps; ls.sums = st->sums;
+        ls.pos_e = (int)(ls.n_steps % kLockWindow); ls.pos_p = (int)(ls.n_steps % kPeakHistory);
+        ls.pos_refresh = (int)(ls.n_steps % kLockRefresh); ls.pad = 0;
+        sm.red->loop = ls;
+        sm.red->dstate[0] = st->doppler; sm.red->dstate[1] = st->carrier_phase;
+        sm.red->istate[0] = st->code_phase; sm.red->istate[1] = st->lost;
+        sm.red->steps = carrier_steps<K>(st->doppler * p.inv_fs);
+    }
+    __syncthreads();
     const bool prof = PROF && p.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
     long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int ms = 0; ms < p.n_ms; ++ms) {
         gyp_track_rec* rec = p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + ms : nullptr;
-        if (lost) {  // a dropped channel stays dropped until the host re-creates it (receiver.py:259-267)
-            if (rec && threadIdx.x == 0) { gyp_track_rec z = {}; z.status = 2; z.doppler_hz = f; z.carrier_phase = phi; z.code_phase = code_phase; *rec = z; }
+        if (sm.red->istate[1]) {  // a dropped channel stays dropped until the host re-creates it (receiver.py:259-267)
+            if (rec && threadIdx.x == 0) {
+                gyp_track_rec z = {};
+                z.status = 2; z.doppler_hz = sm.red->dstate[0]; z.carrier_phase = sm.red->dstate[1]; z.code_phase = sm.red->istate[0];
+                *rec = z;
+            }
             continue;
         }
         long long t_a = prof ? (long long)__builtin_readcyclecounter() : 0;
         const double t0 = p.start_time[ms];
-        const double du = f * p.inv_fs;
-        const double u0 = f * t0 + phi * 0.15915494309189533577;
-        // the ring entries that leave the sliding windows this millisecond: fetched now, used after the FFTs
-        double leave_e = 0.0, leave_pr = 0.0, leave_pi = 0.0;
+        cf c[16];
+        {
+            const double f = sm.red->dstate[0], phi = sm.red->dstate[1];
+            const CarrierSteps cs = sm.red->steps;
+            correlate_ms<K>(stream + (int64_t)ms * N, f * t0 + phi * 0.15915494309189533577, f * p.inv_fs, cs, sm, rep, c);
+        }
+        long long t_b = prof ? (long long)__builtin_readcyclecounter() : 0;
+        const EplResult r = epl_from_c0<K>(c, sm.red->istate[0], sm.red, nullptr);
+        long long t_c = prof ? (long long)__builtin_readcyclecounter() : 0;
         if (wave == 0) {
-            if (n_steps >= kLockWindow) {
+            const double f = sm.red->dstate[0], phi = sm.red->dstate[1];
+            int lost = 0;
+            LoopState ls = sm.red->loop;                       // uniform: every lane reads the same words
+            const int64_t n = ls.n_steps;
+            double dll_phase = ls.dll_phase, last_watchdog = ls.last_watchdog;
+            LockSums sums = ls.sums;
+            int pos_e = ls.pos_e, pos_p = ls.pos_p, pos_refresh = ls.pos_refresh;
+            // the ring entries that leave the sliding windows this millisecond
+            double leave_e = 0.0, leave_pr = 0.0, leave_pi = 0.0;
+            if (n >= kLockWindow) {
                 const int pos_leave = pos_p >= kLockWindow ? pos_p - kLockWindow : pos_p - kLockWindow + kPeakHistory;
                 leave_e = st->err_ring[pos_e];
                 leave_pr = st->peak_re[pos_leave];
                 leave_pi = st->peak_im[pos_leave];
             }
-        }
-        cf c[16];
-        correlate_ms<K>(stream + (int64_t)ms * N, u0, du, cs, sm, rep, c);
-        long long t_b = prof ? (long long)__builtin_readcyclecounter() : 0;
-        const EplResult r = epl_from_c0<K>(c, code_phase, sm.red, nullptr);
-        long long t_c = prof ? (long long)__builtin_readcyclecounter() : 0;
-        if (wave == 0) {
-            const int64_t n = n_steps;
             // ---- code loop, tracker.py:297-303
             const double er = r.early.x, ei = r.early.y, lr = r.late.x, li = r.late.y;
             const double disc = ((er * er + ei * ei) - (lr * lr + li * li)) / 2.0;
@@ -641,9 +664,10 @@ __global__ __launch_bounds__(64 * K, K >= 8 ? 4 : 3) void track_block_kernel(Tra
                     }
                 }
             }
-            dll_phase = dll;
-            n_steps = n + 1;
             if (lane == 0) {
+                ls.dll_phase = dll; ls.last_watchdog = last_watchdog; ls.n_steps = n + 1; ls.sums = sums;
+                ls.pos_e = pos_e; ls.pos_p = pos_p; ls.pos_refresh = pos_refresh;
+                sm.red->loop = ls;
                 sm.red->dstate[0] = nf; sm.red->dstate[1] = nphi;
                 sm.red->istate[0] = new_code_phase; sm.red->istate[1] = lost;
                 sm.red->steps = carrier_steps<K>(nf * p.inv_fs);
@@ -663,18 +687,17 @@ __global__ __launch_bounds__(64 * K, K >= 8 ? 4 : 3) void track_block_kernel(Tra
         }
         long long t_d = prof ? (long long)__builtin_readcyclecounter() : 0;
         __syncthreads();
-        f = sm.red->dstate[0]; phi = sm.red->dstate[1];
-        code_phase = sm.red->istate[0]; lost = sm.red->istate[1];
-        cs = sm.red->steps;
         if (prof) {
             const long long t_e = (long long)__builtin_readcyclecounter();
             tp[0] += t_b - t_a; tp[1] += t_c - t_b; tp[2] += t_d - t_c; tp[3] += t_e - t_d; tp[4] += 1;
         }
     }
     if (threadIdx.x == 0) {
-        st->doppler = f; st->carrier_phase = phi; st->code_phase = code_phase; st->lost = lost;
-        st->dll_phase = dll_phase; st->n_steps = n_steps; st->last_watchdog_time = last_watchdog;
-        st->sums = sums;
+        st->doppler = sm.red->dstate[0]; st->carrier_phase = sm.red->dstate[1];
+        st->code_phase = sm.red->istate[0]; st->lost = sm.red->istate[1];
+        const LoopState ls = sm.red->loop;
+        st->dll_phase = ls.dll_phase; st->n_steps = ls.n_steps; st->last_watchdog_time = ls.last_watchdog;
+        st->sums = ls.sums;
         if (prof) for (int i = 0; i < 8; ++i) p.prof[i] = tp[i];
     }
 }
