@@ -580,9 +580,9 @@ __global__ __launch_bounds__(64 * K, K >= 8 ? 4 : 3) void track_block_kernel(Tra
             continue;
         }
         long long t_a = prof ? (long long)__builtin_readcyclecounter() : 0;
-        const double t0 = p.start_time[ms];
         cf c[16];
         {
+            const double t0 = p.start_time[ms];
             const double f = sm.red->dstate[0], phi = sm.red->dstate[1];
             const CarrierSteps cs = sm.red->steps;
             correlate_ms<K>(stream + (int64_t)ms * N, f * t0 + phi * 0.15915494309189533577, f * p.inv_fs, cs, sm, rep, c);
@@ -592,6 +592,7 @@ __global__ __launch_bounds__(64 * K, K >= 8 ? 4 : 3) void track_block_kernel(Tra
         long long t_c = prof ? (long long)__builtin_readcyclecounter() : 0;
         if (wave == 0) {
             const double f = sm.red->dstate[0], phi = sm.red->dstate[1];
+            const double t0 = p.start_time[launder(ms)];   // re-read here rather than held across the transforms
             int lost = 0;
             LoopState ls = sm.red->loop;                       // uniform: every lane reads the same words
             const int64_t n = ls.n_steps;
