@@ -135,7 +135,7 @@ def main() -> None:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     dist = torch = None
-    if world > 1:
+    if world > 1 or os.environ.get("GYP_BENCH_FORCE_DIST"):   # the env switch exercises the RCCL path on a 1-GPU box
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)

@@ -389,6 +389,61 @@ __device__ __forceinline__ void stage_ms(const cf* __restrict__ block, double u0
     }
 }
 
+// General staging: the W branches r = rho*W .. rho*W + W-1 of a K-samples-per-chip stream (K a multiple of W),
+// optionally pre-folded over n_blocks consecutive millisecond blocks (coherent integration is linear, so
+// sum_b IFFT(FFT(x_b) * P) = IFFT(FFT(sum_b x_b) * P): one transform instead of n_blocks).  Block b starts at
+// `stream + b*N` with carrier cycles u0_first + b*u0_step at its first sample.  Scalar 8-byte loads and a running
+// window; used for K > 8 (branch rounds) and for coherent cells -- the per-millisecond K <= 8 path is stage_ms.
+template <int K, int W>
+__device__ __forceinline__ void stage_general(const cf* __restrict__ stream, int n_blocks, int rho, double u0_first,
+                                              double u0_step, double du, const CarrierSteps& cs, cf* (&y_rows)[W], int tid) {
+    constexpr int N = K * kChips;
+    constexpr int T = 64 * W;
+    constexpr int CH = (kChips + T - 1) / T;
+#pragma unroll 1
+    for (int c = 0; c < CH; ++c) {
+        const int m = tid + c * T;
+        if (m < kChips) {
+            cf acc[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) acc[w] = make_float2(0.f, 0.f);
+            const int idx0 = K * m + rho * W;                         // < N
+#pragma unroll 1
+            for (int b = 0; b < n_blocks; ++b) {
+                const cf* block = stream + (int64_t)b * N;
+                cf car = carrier_from_cycles_fast(u0_first + u0_step * (double)b + du * (double)idx0);
+                cf first[W > 1 ? W - 1 : 1];
+                cf win = make_float2(0.f, 0.f);
+                int idx = idx0;
+#pragma unroll
+                for (int i = 0; i < W - 1; ++i) {                     // the W-1 samples that later leave the window
+                    const cf s = cmul(block[idx], car);
+                    first[i] = s;
+                    win = cadd(win, s);
+                    car = cmul(car, cs.rot1);
+                    if (++idx == N) { idx = 0; car = cmul(car, cs.rot_wrap); }
+                }
+#pragma unroll 4
+                for (int i = W - 1; i < K; ++i) {
+                    win = cadd(win, cmul(block[idx], car));
+                    car = cmul(car, cs.rot1);
+                    if (++idx == N) { idx = 0; car = cmul(car, cs.rot_wrap); }
+                }
+                acc[0] = cadd(acc[0], win);
+#pragma unroll
+                for (int r = 1; r < W; ++r) {
+                    win = cadd(csub(win, first[r - 1]), cmul(block[idx], car));
+                    car = cmul(car, cs.rot1);
+                    if (++idx == N) { idx = 0; car = cmul(car, cs.rot_wrap); }
+                    acc[r] = cadd(acc[r], win);
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < W; ++w) y_rows[w][m] = acc[w];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // wavefront reductions on the DPP network (no LDS traffic): all-reduce inside each row of 16 lanes with
 // quad_perm / row_half_mirror / row_mirror, then the four row results are combined through v_readlane.

@@ -249,8 +249,8 @@ int gyp_set_stream_format(gyp_ctx* ctx, int64_t fs_hz, int32_t samples_per_ms) {
     if (samples_per_ms % kChips != 0)
         return fail(ctx, GYP_E_BAD_RATE, "sample rate must be an integer multiple of 1.023 MHz (the replica is np.repeat(chips, N // 1023))");
     const int k = samples_per_ms / kChips;
-    if (k != 1 && k != 2 && k != 4 && k != 8)
-        return fail(ctx, GYP_E_BAD_RATE, "supported rates this release: 1.023, 2.046, 4.092, 8.184 Msps");
+    if (k != 1 && k != 2 && k != 4 && k != 8 && k != 16 && k != 48)
+        return fail(ctx, GYP_E_BAD_RATE, "supported rates this release: 1.023, 2.046, 4.092, 8.184, 16.368, 49.104 Msps");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->d_replicas) {
         std::vector<uint8_t> chips(32 * kChips);
@@ -319,24 +319,28 @@ double gyp_cell_strength(const gyp_cell* c, int32_t samples_per_ms) {
 // ---------------------------------------------------------------------------------------------------------
 // launches
 // ---------------------------------------------------------------------------------------------------------
-static int blocks_per_cu(int k) { return 16 / k; }   // 16 wavefronts per CU (4 per SIMD): LDS and VGPR budgets are sized for it
+// wavefronts a CU hosts for this rate (LDS tiles and VGPR budgets are sized for it), in workgroups
+static int blocks_per_cu(int k) { return k > 8 ? 1 : 16 / k; }
+static int threads_for(int k) { return 64 * (k < 8 ? k : 8); }
 
 template <typename KernelT, typename ParamsT>
 static int launch_k(gyp_ctx* ctx, KernelT kernel, int k, int grid, const ParamsT& p, size_t lds) {
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * k), lds, ctx->stream, p);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads_for(k)), lds, ctx->stream, p);
     HIP_TRY(ctx, hipGetLastError());
     return GYP_OK;
 }
 
+#define GYP_FOR_EACH_RATE(X) X(1) X(2) X(4) X(8) X(16) X(48)
+
 static int launch_cells(gyp_ctx* ctx, const CellsParams& p, int integration) {
-    const int grid = std::max(1, std::min(p.n_cells, ctx->n_cus * blocks_per_cu(ctx->k)) & ~7) ;
+    const int grid = std::max(1, std::min(p.n_cells, ctx->n_cus * blocks_per_cu(ctx->k)) & ~7);
     const bool coh = integration == GYP_COHERENT;
     switch (ctx->k) {
-        case 1: return coh ? launch_k(ctx, corr_cells_kernel<1, true>, 1, grid, p, lds_bytes<1>()) : launch_k(ctx, corr_cells_kernel<1, false>, 1, grid, p, lds_bytes<1>());
-        case 2: return coh ? launch_k(ctx, corr_cells_kernel<2, true>, 2, grid, p, lds_bytes<2>()) : launch_k(ctx, corr_cells_kernel<2, false>, 2, grid, p, lds_bytes<2>());
-        case 4: return coh ? launch_k(ctx, corr_cells_kernel<4, true>, 4, grid, p, lds_bytes<4>()) : launch_k(ctx, corr_cells_kernel<4, false>, 4, grid, p, lds_bytes<4>());
-        case 8: return coh ? launch_k(ctx, corr_cells_kernel<8, true>, 8, grid, p, lds_bytes<8>()) : launch_k(ctx, corr_cells_kernel<8, false>, 8, grid, p, lds_bytes<8>());
+#define X(K) case K: return coh ? launch_k(ctx, corr_cells_kernel<K, true>, K, grid, p, lds_bytes<K>()) \
+                                : launch_k(ctx, corr_cells_kernel<K, false>, K, grid, p, lds_bytes<K>());
+        GYP_FOR_EACH_RATE(X)
+#undef X
     }
     return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
 }
@@ -344,10 +348,9 @@ static int launch_cells(gyp_ctx* ctx, const CellsParams& p, int integration) {
 static int launch_track_step(gyp_ctx* ctx, const TrackStepParams& p) {
     const int grid = std::max(1, std::min(p.n_chan, ctx->n_cus * blocks_per_cu(ctx->k)) & ~7);
     switch (ctx->k) {
-        case 1: return launch_k(ctx, track_step_kernel<1>, 1, grid, p, lds_bytes<1>());
-        case 2: return launch_k(ctx, track_step_kernel<2>, 2, grid, p, lds_bytes<2>());
-        case 4: return launch_k(ctx, track_step_kernel<4>, 4, grid, p, lds_bytes<4>());
-        case 8: return launch_k(ctx, track_step_kernel<8>, 8, grid, p, lds_bytes<8>());
+#define X(K) case K: return launch_k(ctx, track_step_kernel<K>, K, grid, p, lds_bytes<K>());
+        GYP_FOR_EACH_RATE(X)
+#undef X
     }
     return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
 }
@@ -356,10 +359,9 @@ template <bool PROF>
 static int launch_track_block_t(gyp_ctx* ctx, const TrackBlockParams& p) {
     const int grid = p.n_chan;
     switch (ctx->k) {
-        case 1: return launch_k(ctx, track_block_kernel<1, PROF>, 1, grid, p, lds_bytes<1>());
-        case 2: return launch_k(ctx, track_block_kernel<2, PROF>, 2, grid, p, lds_bytes<2>());
-        case 4: return launch_k(ctx, track_block_kernel<4, PROF>, 4, grid, p, lds_bytes<4>());
-        case 8: return launch_k(ctx, track_block_kernel<8, PROF>, 8, grid, p, lds_bytes<8>());
+#define X(K) case K: return launch_k(ctx, track_block_kernel<K, PROF>, K, grid, p, lds_bytes<K>());
+        GYP_FOR_EACH_RATE(X)
+#undef X
     }
     return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
 }

@@ -24,8 +24,19 @@ constexpr int kPeakHistory = 1000;  // tracker.py:146 (deque maxlen)
 constexpr int kLockRefresh = 1024;  // exact two-pass recomputation of the sliding sums every this many ms
 constexpr int kTablesBytes = 1024 * 8;  // tw1024 (tw2048 stays in global memory / L1)
 constexpr int kRedBytes = 1024;
+// K = samples per chip.  A workgroup has W = min(K, 8) wavefronts; K > 8 is processed in R = K / W rounds of W
+// polyphase branches (branch r = rho*W + wavefront).
 template <int K>
-constexpr int lds_bytes() { return kTablesBytes + K * kXchWaveBytes + kRedBytes; }
+struct Geom {
+    static constexpr int W = K < 8 ? K : 8;
+    static constexpr int R = K / W;
+    static_assert(K % W == 0, "samples per chip must be 1, 2, 4, 8 or a multiple of 8");
+    static constexpr int kThreads = 64 * W;
+    // 16 wavefronts per CU (4 per SIMD, 128 VGPRs) for K == 8, 12 (168 VGPRs) below, 8 (256 VGPRs) for branch rounds
+    static constexpr int kMinWavesPerSimd = K > 8 ? 2 : (K == 8 ? 4 : 3);
+};
+template <int K>
+constexpr int lds_bytes() { return kTablesBytes + Geom<K>::W * kXchWaveBytes + kRedBytes; }
 
 struct WaveCand {   // one wavefront's candidate for the profile maximum
     float v;
@@ -77,25 +88,20 @@ __device__ __forceinline__ Smem carve_smem(char* base, const cf* __restrict__ tw
     s.tw1024 = reinterpret_cast<cf*>(base);
     s.tw2048 = tw_global + 1024;
     s.xch = s.tw1024 + 1024;
-    s.red = reinterpret_cast<RedScratch*>(base + kTablesBytes + K * kXchWaveBytes);
-    for (int i = threadIdx.x; i < 1024; i += 64 * K) s.tw1024[i] = tw_global[i];
+    s.red = reinterpret_cast<RedScratch*>(base + kTablesBytes + Geom<K>::W * kXchWaveBytes);
+    for (int i = threadIdx.x; i < 1024; i += Geom<K>::kThreads) s.tw1024[i] = tw_global[i];
     return s;
 }
 
-// One millisecond of one cell/channel: stage (all waves) -> barrier -> per-wave correlation.
-// Returns c[j]: complex correlation at lag index k = K*(l + 32*(j + 16*h)) + wave.
+// The transform pair of one branch per wavefront on inputs already staged in LDS.
+// c[j]: complex correlation at lag index K*(l + 32*(j + 16*h)) + rho*W + wavefront.
 template <int K>
-__device__ __forceinline__ void correlate_ms(const cf* __restrict__ block, double u0, double du, const CarrierSteps& cs,
-                                             const Smem& sm, const cf* __restrict__ rep_table_sat, cf (&c)[16]) {
-    const int tid = launder(threadIdx.x), wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
-    cf* y_rows[K];
-#pragma unroll
-    for (int r = 0; r < K; ++r) y_rows[r] = sm.xch + r * kXchWave;
-    stage_ms<K>(block, u0, du, cs, y_rows, tid);
-    if (tid < K) y_rows[tid][kChips] = make_float2(0.f, 0.f);
+__device__ __forceinline__ void transform_staged(const Smem& sm, const cf* __restrict__ rep_table_sat, cf (&c)[16], int tid) {
+    const int wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
+    if (tid < Geom<K>::W) sm.xch[tid * kXchWave + kChips] = make_float2(0.f, 0.f);
     __syncthreads();
     cf x[32];
-    const cf* yw = y_rows[wave];
+    const cf* yw = sm.xch + wave * kXchWave;
 #pragma unroll
     for (int j = 0; j < 32; ++j) x[j] = yw[32 * j + l];
     wave_lds_fence();
@@ -106,18 +112,44 @@ __device__ __forceinline__ void correlate_ms(const cf* __restrict__ block, doubl
     wave_fft_inv(x, c, tile_half, t, l, h);
 }
 
-// Output slot j of a lane holds lag index  K*(l + 32*(j + 16*h)) + wave  =  lag_base + 32*K*j.  The single padding
-// slot (q == 1023) is slot 15 of lane 63.
+// One millisecond block, round rho: stage (all wavefronts) -> barrier -> per-wavefront correlation.
 template <int K>
-__device__ __forceinline__ int lag_base(int tid) {
+__device__ __forceinline__ void correlate_round(const cf* __restrict__ block, int rho, double u0, double du,
+                                                const CarrierSteps& cs, const Smem& sm,
+                                                const cf* __restrict__ rep_table_sat, cf (&c)[16]) {
+    constexpr int W = Geom<K>::W;
+    const int tid = launder(threadIdx.x);
+    cf* y_rows[W];
+#pragma unroll
+    for (int r = 0; r < W; ++r) y_rows[r] = sm.xch + r * kXchWave;
+    if (Geom<K>::R == 1) stage_ms<W>(block, u0, du, cs, y_rows, tid);
+    else stage_general<K, W>(block, 1, rho, u0, 0.0, du, cs, y_rows, tid);
+    transform_staged<K>(sm, rep_table_sat, c, tid);
+}
+
+// Coherent integration of n_blocks millisecond blocks, round rho, with ONE transform (pre-folded inputs).
+template <int K>
+__device__ __forceinline__ void correlate_round_prefolded(const cf* __restrict__ stream, int n_blocks, int rho,
+                                                          double u0_step, double du, const CarrierSteps& cs, const Smem& sm,
+                                                          const cf* __restrict__ rep_table_sat, cf (&c)[16]) {
+    constexpr int W = Geom<K>::W;
+    const int tid = launder(threadIdx.x);
+    cf* y_rows[W];
+#pragma unroll
+    for (int r = 0; r < W; ++r) y_rows[r] = sm.xch + r * kXchWave;
+    stage_general<K, W>(stream, n_blocks, rho, 0.0, u0_step, du, cs, y_rows, tid);
+    transform_staged<K>(sm, rep_table_sat, c, tid);
+}
+
+// Output slot j of a lane in round rho holds lag index
+//     K*(l + 32*(j + 16*h)) + rho*W + wavefront  =  lag_base + 32*K*j.
+// The single padding slot (q == 1023) is slot 15 of lane 63.
+template <int K>
+__device__ __forceinline__ int lag_base(int tid, int rho) {
     const int lane = tid & 63, wave = tid >> 6;
-    return K * ((lane & 31) + 512 * (lane >> 5)) + wave;
+    return K * ((lane & 31) + 512 * (lane >> 5)) + rho * Geom<K>::W + wave;
 }
 __device__ __forceinline__ bool slot_valid(int j, int tid) { return j != 15 || (tid & 63) != 63; }
-template <int K>
-__device__ __forceinline__ int lag_index(int j, int tid) {
-    return slot_valid(j, tid) ? lag_base<K>(tid) + 32 * K * j : -1;
-}
 
 struct ProfileStats {
     Best best;   // max value + key of the winner
@@ -126,42 +158,43 @@ struct ProfileStats {
     int n_max;
 };
 
-// Workgroup-wide max / first-argmax (by key) / complex value there / sum / count-of-max over vals[16] of every
-// lane, with ONE workgroup barrier.  key_of(idx) orders ties (lowest key wins).  Result valid in every thread.
+// Per-lane running maximum / first-argmax (by key) / complex value there / sum / count over the slots a lane sees,
+// fed once per round and finished with ONE workgroup barrier.
+struct LaneStats {
+    Best b;      // best value and its key (lowest key wins ties)
+    cf val;      // complex value at the best
+    float sum;
+    int cnt;     // slots equal to b.v
+};
+__device__ __forceinline__ LaneStats lane_stats_init() {
+    return LaneStats{Best{-1.0f, 0x7fffffff}, make_float2(0.f, 0.f), 0.f, 0};
+}
 template <int K, typename KeyFn>
-__device__ __forceinline__ ProfileStats profile_stats(const float (&vals)[16], const cf* cvals, RedScratch* red,
-                                                      KeyFn key_of) {
-    const int tid = launder(threadIdx.x);
+__device__ __forceinline__ void lane_stats_update(LaneStats& ls, const float (&vals)[16], const cf* cvals, int rho, int tid,
+                                                  KeyFn key_of) {
+    const int base = lag_base<K>(tid, rho);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (slot_valid(j, tid)) {
+            const float v = vals[j];
+            const int key = key_of(base + 32 * K * j);
+            ls.sum += v;
+            if (v > ls.b.v) { ls.b = Best{v, key}; ls.cnt = 1; if (cvals) ls.val = cvals[j]; }
+            else if (v == ls.b.v) { ++ls.cnt; if (key < ls.b.key) { ls.b.key = key; if (cvals) ls.val = cvals[j]; } }
+        }
+    }
+}
+// Result valid in every thread of the workgroup.
+template <int K>
+__device__ __forceinline__ ProfileStats lane_stats_finish(const LaneStats& ls, RedScratch* red, int tid) {
+    constexpr int W = Geom<K>::W;
     const int wave = tid >> 6;
-    const int base = lag_base<K>(tid);
-    Best b{-1.0f, 0x7fffffff};
-    float part = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        if (slot_valid(j, tid)) {
-            b = better(b, Best{vals[j], key_of(base + 32 * K * j)});
-            part += vals[j];
-        }
-    }
-    const Best wb = wave_best(b);
-    int cnt = 0;
-    cf mine = make_float2(0.f, 0.f);
-    bool owner = false;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        if (slot_valid(j, tid)) {
-            cnt += (vals[j] == wb.v) ? 1 : 0;
-            if (vals[j] == wb.v && key_of(base + 32 * K * j) == wb.key) {
-                owner = true;
-                if (cvals) mine = cvals[j];
-            }
-        }
-    }
-    const double s = wave_sum((double)part);
-    cnt = wave_sum(cnt);
-    if (owner) {
+    const Best wb = wave_best(ls.b);
+    const int cnt = wave_sum(ls.b.v == wb.v ? ls.cnt : 0);
+    const double s = wave_sum((double)ls.sum);
+    if (ls.b.v == wb.v && ls.b.key == wb.key) {
         WaveCand wc;
-        wc.v = wb.v; wc.key = wb.key; wc.re = mine.x; wc.im = mine.y; wc.sum = s; wc.cnt = cnt; wc.pad = 0;
+        wc.v = wb.v; wc.key = wb.key; wc.re = ls.val.x; wc.im = ls.val.y; wc.sum = s; wc.cnt = cnt; wc.pad = 0;
         red->cand[wave] = wc;
     }
     __syncthreads();
@@ -169,14 +202,14 @@ __device__ __forceinline__ ProfileStats profile_stats(const float (&vals)[16], c
     WaveCand g = red->cand[0];
     st.sum = g.sum;
 #pragma unroll
-    for (int w = 1; w < K; ++w) {
+    for (int w = 1; w < W; ++w) {
         const WaveCand o = red->cand[w];
         st.sum += o.sum;
         if (o.v > g.v || (o.v == g.v && o.key < g.key)) g = o;
     }
     st.n_max = 0;
 #pragma unroll
-    for (int w = 0; w < K; ++w) st.n_max += (red->cand[w].v == g.v) ? red->cand[w].cnt : 0;
+    for (int w = 0; w < W; ++w) st.n_max += (red->cand[w].v == g.v) ? red->cand[w].cnt : 0;
     st.best = Best{g.v, g.key};
     st.peak = make_float2(g.re, g.im);
     return st;
@@ -199,11 +232,11 @@ struct CellsParams {
 };
 
 template <int K, bool COHERENT>
-__global__ __launch_bounds__(64 * K, K >= 8 ? 4 : 3) void corr_cells_kernel(CellsParams p) {
+__global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void corr_cells_kernel(CellsParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int N = K * kChips;
+    constexpr int R = Geom<K>::R;
     const Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
-    const int lane = threadIdx.x & 63;
     __syncthreads();
     for (int v = blockIdx.x; v < p.n_cells; v += gridDim.x) {
         const int cell = xcd_contiguous(v, p.n_cells);
@@ -213,31 +246,58 @@ __global__ __launch_bounds__(64 * K, K >= 8 ? 4 : 3) void corr_cells_kernel(Cell
         const double du = d.doppler_hz * p.inv_fs;
         const CarrierSteps cs = carrier_steps<K>(du);
         const cf* stream = p.iq + (int64_t)d.stream * p.stream_stride;
-        float mag[16];
-        cf acc[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            mag[j] = 0.f;
-            acc[j] = make_float2(0.f, 0.f);
-        }
-        for (int ms = 0; ms < p.n_ms; ++ms) {
-            // utils.py:92-96: t = arange(N)/fs + (i*N)/fs ; carrier = exp(-1j*tau*f*t)
-            const double u0 = d.doppler_hz * ((double)((int64_t)ms * N) * p.inv_fs);
-            cf c[16];
-            correlate_ms<K>(stream + (int64_t)ms * N, u0, du, cs, sm, rep, c);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                if (COHERENT) acc[j] = cadd(acc[j], c[j]);
-                else mag[j] += sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
-            }
-            __syncthreads();  // every wave is done with the exchange tiles before the next block is staged
-        }
+        // utils.py:92-96: t = arange(N)/fs + (i*N)/fs ; carrier = exp(-1j*tau*f*t): block i starts at f*i*N/fs cycles
+        const double u0_step = d.doppler_hz * ((double)N * p.inv_fs);
+        LaneStats ls = lane_stats_init();
         if (COHERENT) {
+            // sum_i c_i = correlation of the sum of the wiped blocks: one transform per round
+            for (int rho = 0; rho < R; ++rho) {
+                cf c[16];
+                correlate_round_prefolded<K>(stream, p.n_ms, rho, u0_step, du, cs, sm, rep, c);
+                const int tid = launder(threadIdx.x);
+                const int base = lag_base<K>(tid, rho);
+                float mag[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) mag[j] = sqrtf(fmaf(acc[j].x, acc[j].x, acc[j].y * acc[j].y));
+                for (int j = 0; j < 16; ++j) {
+                    mag[j] = sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
+                    if (slot_valid(j, tid)) {
+                        const int idx = base + 32 * K * j;
+                        if (idx == d.tap_index) { p.out[cell].tap_re = c[j].x; p.out[cell].tap_im = c[j].y; }
+                        if (p.profile_out) reinterpret_cast<float2*>(p.profile_out)[(int64_t)cell * N + idx] = c[j];
+                    }
+                }
+                lane_stats_update<K>(ls, mag, nullptr, rho, tid, [](int idx) { return idx; });
+                __syncthreads();  // every wavefront is done with the tiles before the next round is staged
+            }
+        } else {
+            float mag[R][16];
+#pragma unroll
+            for (int rho = 0; rho < R; ++rho)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) mag[rho][j] = 0.f;
+            for (int ms = 0; ms < p.n_ms; ++ms) {
+#pragma unroll
+                for (int rho = 0; rho < R; ++rho) {
+                    cf c[16];
+                    correlate_round<K>(stream + (int64_t)ms * N, rho, u0_step * (double)ms, du, cs, sm, rep, c);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) mag[rho][j] += sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
+                    __syncthreads();
+                }
+            }
+            const int tid = launder(threadIdx.x);
+#pragma unroll
+            for (int rho = 0; rho < R; ++rho) {
+                lane_stats_update<K>(ls, mag[rho], nullptr, rho, tid, [](int idx) { return idx; });
+                if (p.profile_out) {
+                    const int base = lag_base<K>(tid, rho);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if (slot_valid(j, tid)) p.profile_out[(int64_t)cell * N + base + 32 * K * j] = mag[rho][j];
+                }
+            }
         }
-        const ProfileStats st = profile_stats<K>(mag, nullptr, sm.red, [](int idx) { return idx; });
-        const int tid = launder(threadIdx.x);
+        const ProfileStats st = lane_stats_finish<K>(ls, sm.red, launder(threadIdx.x));
         if (threadIdx.x == 0) {
             gyp_cell* o = p.out + cell;
             o->peak = st.best.v;
@@ -246,24 +306,6 @@ __global__ __launch_bounds__(64 * K, K >= 8 ? 4 : 3) void corr_cells_kernel(Cell
             o->n_max = st.n_max;
             o->reserved = 0;
             if (d.tap_index < 0 || !COHERENT) { o->tap_re = 0.f; o->tap_im = 0.f; }
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int idx = lag_index<K>(j, tid);
-            if (idx >= 0) {
-                if (COHERENT && idx == d.tap_index) {  // complex taps exist for coherent integration only
-                    p.out[cell].tap_re = acc[j].x;
-                    p.out[cell].tap_im = acc[j].y;
-                }
-                if (p.profile_out) {
-                    if (COHERENT) {  // complex integrated profile, interleaved re,im
-                        float2* prof = reinterpret_cast<float2*>(p.profile_out) + (int64_t)cell * N;
-                        prof[idx] = acc[j];
-                    } else {
-                        p.profile_out[(int64_t)cell * N + idx] = mag[j];
-                    }
-                }
-            }
         }
     }
 }
@@ -298,22 +340,23 @@ struct EplResult {
     int n_max;
 };
 
+// One round's 16 lags per lane: publish the early / late taps if this lane owns them, feed the running profile
+// statistics (keys = index in the profile of the PRN rolled by s, so ties resolve like np.argmax on that profile).
 template <int K>
-__device__ __forceinline__ EplResult epl_from_c0(const cf (&c)[16], int code_phase, RedScratch* red,
-                                                float* profile_row) {
+__device__ __forceinline__ void epl_round(const cf (&c)[16], int rho, int s, LaneStats& ls, RedScratch* red,
+                                          float* profile_row, int tid) {
     constexpr int N = K * kChips;
-    const int s = mod_n(code_phase, N);
+    constexpr int W = Geom<K>::W;
     const int ie = mod_n(s - 1, N), il = mod_n(s + 1, N);
-    const int tid = launder(threadIdx.x);
     float mag[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) mag[j] = sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
-    // The owners of the early / late taps publish them ahead of the reduction barrier.  Lag index idx lives in
-    // wavefront idx % K, lane (q & 31) + 32*(q >> 9), slot (q >> 5) & 15 with q = idx / K: all wave-uniform.
+    // Lag index idx lives in round (idx % K) / W, wavefront (idx % K) % W, lane (q & 31) + 32*(q >> 9),
+    // slot (q >> 5) & 15 with q = idx / K: all wave-uniform.
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int idx = t ? il : ie, q = idx / K;
-        if ((tid >> 6) == idx % K && (tid & 63) == (q & 31) + 32 * (q >> 9)) {
+        const int idx = t ? il : ie, q = idx / K, r = idx % K;
+        if (r / W == rho && (tid >> 6) == r % W && (tid & 63) == (q & 31) + 32 * (q >> 9)) {
             const int slot = (q >> 5) & 15;
 #pragma unroll
             for (int j = 0; j < 16; ++j)
@@ -321,12 +364,17 @@ __device__ __forceinline__ EplResult epl_from_c0(const cf (&c)[16], int code_pha
         }
     }
     if (profile_row) {
-        const int base = lag_base<K>(tid);
+        const int base = lag_base<K>(tid, rho);
 #pragma unroll
         for (int j = 0; j < 16; ++j)
             if (slot_valid(j, tid)) { int k = base + 32 * K * j - s; profile_row[k < 0 ? k + N : k] = mag[j]; }
     }
-    const ProfileStats st = profile_stats<K>(mag, c, red, [s](int idx) { int k = idx - s; return k < 0 ? k + N : k; });
+    lane_stats_update<K>(ls, mag, c, rho, tid, [s](int idx) { int k = idx - s; return k < 0 ? k + N : k; });
+}
+
+template <int K>
+__device__ __forceinline__ EplResult epl_finish(const LaneStats& ls, RedScratch* red, int tid) {
+    const ProfileStats st = lane_stats_finish<K>(ls, red, tid);   // its barrier also publishes the taps
     EplResult r;
     r.early = make_float2(red->taps[0], red->taps[1]);
     r.late = make_float2(red->taps[2], red->taps[3]);
@@ -337,12 +385,28 @@ __device__ __forceinline__ EplResult epl_from_c0(const cf (&c)[16], int code_pha
     return r;
 }
 
+// One tracking millisecond of one channel: all rounds, then the reductions.
 template <int K>
-__global__ __launch_bounds__(64 * K, K >= 8 ? 4 : 3) void track_step_kernel(TrackStepParams p) {
+__device__ __forceinline__ EplResult track_ms(const cf* __restrict__ block, double u0, double du, const CarrierSteps& cs,
+                                              int code_phase, const Smem& sm, const cf* __restrict__ rep, float* profile_row) {
+    constexpr int N = K * kChips;
+    const int s = mod_n(code_phase, N);
+    LaneStats ls = lane_stats_init();
+#pragma unroll 1
+    for (int rho = 0; rho < Geom<K>::R; ++rho) {
+        cf c[16];
+        correlate_round<K>(block, rho, u0, du, cs, sm, rep, c);
+        epl_round<K>(c, rho, s, ls, sm.red, profile_row, launder(threadIdx.x));
+        if (Geom<K>::R > 1) __syncthreads();   // tiles are re-staged by the next round
+    }
+    return epl_finish<K>(ls, sm.red, launder(threadIdx.x));
+}
+
+template <int K>
+__global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void track_step_kernel(TrackStepParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int N = K * kChips;
     const Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
-    const int lane = threadIdx.x & 63;
     __syncthreads();
     for (int v = blockIdx.x; v < p.n_chan; v += gridDim.x) {
         const int ch = xcd_contiguous(v, p.n_chan);
@@ -351,10 +415,8 @@ __global__ __launch_bounds__(64 * K, K >= 8 ? 4 : 3) void track_step_kernel(Trac
         // tracker.py:271-281: carrier = exp(-1j*(2*pi*f*t + phi)), t = n/fs + chunk.start_time
         const double du = in.doppler_hz * p.inv_fs;
         const double u0 = in.doppler_hz * p.start_time[in.stream] + in.carrier_phase * 0.15915494309189533577;
-        cf c[16];
-        correlate_ms<K>(p.iq + (int64_t)in.stream * p.stream_stride, u0, du, carrier_steps<K>(du), sm, rep, c);
-        const EplResult r = epl_from_c0<K>(c, in.code_phase, sm.red,
-                                           p.profile_out ? p.profile_out + (int64_t)ch * N : nullptr);
+        const EplResult r = track_ms<K>(p.iq + (int64_t)in.stream * p.stream_stride, u0, du, carrier_steps<K>(du), in.code_phase,
+                                        sm, rep, p.profile_out ? p.profile_out + (int64_t)ch * N : nullptr);
         if (threadIdx.x == 0) {
             gyp_chan_out o;
             o.early_re = r.early.x; o.early_im = r.early.y;
@@ -543,7 +605,7 @@ __device__ __forceinline__ void workgroup_mem_fence_wave() {
 }
 
 template <int K, bool PROF>
-__global__ __launch_bounds__(64 * K, K >= 8 ? 4 : 3) void track_block_kernel(TrackBlockParams p) {
+__global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void track_block_kernel(TrackBlockParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int N = K * kChips;
     const Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
@@ -580,15 +642,15 @@ __global__ __launch_bounds__(64 * K, K >= 8 ? 4 : 3) void track_block_kernel(Tra
             continue;
         }
         long long t_a = prof ? (long long)__builtin_readcyclecounter() : 0;
-        cf c[16];
+        EplResult r;
         {
             const double t0 = p.start_time[ms];
             const double f = sm.red->dstate[0], phi = sm.red->dstate[1];
             const CarrierSteps cs = sm.red->steps;
-            correlate_ms<K>(stream + (int64_t)ms * N, f * t0 + phi * 0.15915494309189533577, f * p.inv_fs, cs, sm, rep, c);
+            r = track_ms<K>(stream + (int64_t)ms * N, f * t0 + phi * 0.15915494309189533577, f * p.inv_fs, cs,
+                            sm.red->istate[0], sm, rep, nullptr);
         }
-        long long t_b = prof ? (long long)__builtin_readcyclecounter() : 0;
-        const EplResult r = epl_from_c0<K>(c, sm.red->istate[0], sm.red, nullptr);
+        long long t_b = t_a;
         long long t_c = prof ? (long long)__builtin_readcyclecounter() : 0;
         if (wave == 0) {
             const double f = sm.red->dstate[0], phi = sm.red->dstate[1];

@@ -146,3 +146,63 @@ def test_track_block_closed_loop(engine_factory, tag):
         assert sym_agree == 1.0 and cp_agree == 1.0
         assert dopp_err < 1e-3
     bank.close()
+
+
+@pytest.mark.parametrize("fs,n_ms", [(16_368_000, 3), (49_104_000, 10), (4_092_000, 4), (1_023_000, 5)])
+def test_other_sample_rates_against_oracle(engine_factory, fs, n_ms):
+    """K = N/1023 of 16 and 48 run as rounds of 8 polyphase branches; config 5 (49.104 Msps, 10 ms coherent,
+    100-Hz Doppler grid) is one of the cases.  Coherent cells use the pre-folded single transform."""
+    from gypsum_amd import synth
+
+    n = fs // 1000
+    eng = engine_factory(fs, n)
+    scene = synth.random_scene(fs, n_ms, 3, 777 + n, max_doppler=9500.0, with_nav_bits=False)
+    iq = synth.render(scene)
+    chips = orc.generate_ca_codes()
+    sats = [s.sat_id for s in scene.sats] + [(scene.sats[0].sat_id % 32) + 1]
+    dopp = [100.0 * round(s.doppler_hz / 100.0) for s in scene.sats] + [-1200.0]
+    cells = np.zeros(len(sats), dtype=CELL_DESC)
+    cells["sat_id"] = sats
+    cells["doppler_hz"] = dopp
+    cells["tap_index"] = [s.code_phase for s in scene.sats] + [7]
+    for integ, kind in ((GYP_COHERENT, orc.COHERENT), (GYP_NON_COHERENT, orc.NON_COHERENT)):
+        out, prof = eng.correlate_cells(iq, 1, n_ms, cells, integ, want_profiles=True)
+        for i, (sv, d) in enumerate(zip(sats, dopp)):
+            ref = orc.integrate_correlation(kind, iq, fs, n, d, orc.prn_as_complex(chips[sv - 1], n))
+            scale = np.abs(ref).max()
+            assert np.abs(prof[i] - ref).max() <= 3e-5 * scale
+            assert out["argmax"][i] == int(np.argmax(np.abs(ref)))
+            assert out["peak"][i] == pytest.approx(scale, rel=RTOL_MAG)
+            np.testing.assert_allclose(eng.cell_strength(out[i:i + 1])[0], orc.peak_strength(np.abs(ref)), rtol=RTOL_MAG)
+            if integ == GYP_COHERENT:
+                tap = complex(out["tap_re"][i], out["tap_im"][i])
+                assert abs(tap - ref[cells["tap_index"][i]]) <= 3e-5 * scale
+        if i < len(scene.sats):
+            assert out["argmax"][0] == scene.sats[0].code_phase      # the planted satellite is where it was put
+    # one tracking millisecond through the same rounds, against the oracle tracker
+    s0 = scene.sats[0]
+    st = orc.TrackingState(dopp[0], 0.3, s0.code_phase)
+    trk = orc.Tracker(st, orc.prn_as_complex(chips[s0.sat_id - 1], n), fs, n)
+    t0, t1 = orc.chunk_times(n, n, fs)
+    rec = trk.process_samples(iq[n:2 * n], t0, t1)
+    ch = np.zeros(1, dtype=CHAN_IN)
+    ch[0] = (0, s0.sat_id, dopp[0], 0.3, s0.code_phase, 0)
+    o, _ = eng.track_step(iq[n:2 * n], 1, [t0], ch)
+    assert int(o["peak_offset"][0]) == rec.peak_offset
+    assert abs(complex(o["peak_re"][0], o["peak_im"][0]) - rec.peak) <= RTOL_MAG * abs(rec.peak)
+    assert abs(complex(o["early_re"][0], o["early_im"][0]) - rec.early) <= RTOL_MAG * abs(rec.peak)
+    assert abs(complex(o["late_re"][0], o["late_im"][0]) - rec.late) <= RTOL_MAG * abs(rec.peak)
+    pm = float(o["peak_mag"][0])
+    assert pm / ((o["sum"][0] - o["n_max"][0] * pm) / (n - o["n_max"][0])) == pytest.approx(rec.strength, rel=RTOL_MAG)
+
+
+def test_unsupported_rates_are_rejected(engine_factory):
+    from gypsum_amd._lib import GYP_E_BAD_RATE, GypsumHipError
+    from gypsum_amd.engine import GypsumEngine
+
+    eng = GypsumEngine(0)
+    for fs, n in ((2_048_000, 2048), (50_000_000, 50_000), (2_046_000, 2047), (3_069_000, 3069)):
+        with pytest.raises(GypsumHipError) as e:
+            eng.set_stream_format(fs, n)        # SURVEY F1: the reference itself cannot run 2.048 / 50 Msps
+        assert e.value.code == GYP_E_BAD_RATE
+    eng.close()
