@@ -17,6 +17,10 @@ Workload cfg3 (default; BASELINE.json configs[2], the configuration the >= 200x 
   N > 1: every rank owns B streams (weak scaling); the only exchange is one all-gather of the acquisition
   records per step (RCCL).
 Workload cfg2 (BASELINE.json configs[1]): 2.046 Msps, 32 satellites x range(-5000, 5000, 500) Hz x 1 ms flat grid.
+Workload cfg4 (configs[3]): the cfg2 grid on 64 concurrent streams in total, streams sharded over the ranks (strong
+  scaling), one all-gather of the per-(stream, satellite) best-bin records per step.
+Workload cfg5 (configs[4]): 49.104 Msps, 32 satellites x range(-10000, 10000, 100) Hz, 10 ms coherent; the 6400
+  (satellite x Doppler) cells are sharded over the ranks (strong scaling), one all-gather of the cell records.
 
 The JSON line also carries `roofline` (HBM, as north_star asks), `roofline_valu` (FP32 vector, the resource that
 actually binds this FFT/pointwise path) and `cpu_baseline` (the numpy oracle, i.e. the reference's
@@ -120,7 +124,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"])
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg4", "cfg5"])
     ap.add_argument("--streams", type=int, default=128, help="IQ streams per GPU")
     ap.add_argument("--track-ms", type=int, default=1000, help="ms of signal per stream per step (cfg3)")
     ap.add_argument("--grid-ms", type=int, default=64, help="ms of signal per stream per step (cfg2)")
@@ -260,10 +264,90 @@ def main() -> None:
         }
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_cfg3(fs, n)
+    elif args.workload == "cfg5":
+        from gypsum_amd.dist import shard_bounds
+        fs, n = 49_104_000, 49_104
+        eng.set_stream_format(fs, n)
+        n_ms, n_streams = 10, max(1, args.streams // 32)
+        scene = make_scene(np.random.default_rng(20260925), n_streams, 8, fs, 0.0008)
+        scene["doppler_hz"] *= 2.0                          # +-9 kHz
+        iq = eng.alloc(n_streams * n_ms * n * 8)
+        eng.synth_iq(iq, n_streams, n_ms * n, n_ms, scene, 0.005, 555)
+        bins = np.arange(-10000, 10000, 100, dtype=np.float64)
+        cells = np.zeros((n_streams, 32, len(bins)), dtype=CELL_DESC)
+        cells["stream"] = np.arange(n_streams)[:, None, None]
+        cells["sat_id"] = np.arange(1, 33)[None, :, None]
+        cells["doppler_hz"] = bins[None, None, :]
+        cells["tap_index"] = -1
+        flat = cells.reshape(-1)
+        lo, hi = shard_bounds(len(flat), rank, world)
+        mine = np.ascontiguousarray(flat[lo:hi])
+        cells_dev = eng.alloc(mine.nbytes).upload(mine)
+        counts = [b - a for a, b in (shard_bounds(len(flat), r, world) for r in range(world))]
+        pad = max(counts)
+        if dist is not None:
+            send = torch.zeros(pad * CELL.itemsize, dtype=torch.uint8, device="cuda")
+            recv = torch.empty(world * pad * CELL.itemsize, dtype=torch.uint8, device="cuda")
+            out_ptr = send.data_ptr()
+        else:
+            out_dev = eng.alloc(pad * CELL.itemsize)
+            out_ptr = out_dev.ptr.value
+        import ctypes as C
+
+        def step(i: int) -> None:
+            eng._check(eng.lib.gyp_correlate_cells_dev(eng.ctx, iq.ptr, n_ms * n, n_ms, cells_dev.ptr, len(mine), 0,
+                                                       C.c_void_p(out_ptr), None))
+            if dist is not None:
+                eng.sync()
+                dist.all_gather_into_tensor(recv, send)
+
+        for i in range(args.warmup):
+            step(i)
+        full_sync(); barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        full_sync(); barrier()
+        elapsed = time.perf_counter() - t0
+        eng.timer_start()
+        eng._check(eng.lib.gyp_correlate_cells_dev(eng.ctx, iq.ptr, n_ms * n, n_ms, cells_dev.ptr, len(mine), 0,
+                                                   C.c_void_p(out_ptr), None))
+        k_ms = eng.timer_stop()
+        if dist is not None:
+            got = np.frombuffer(send.cpu().numpy().tobytes(), dtype=CELL)[:len(mine)]
+        else:
+            got = out_dev.download(CELL, len(mine))
+        hits = None
+        if rank == 0:
+            table = {(int(c["stream"]), int(c["sat_id"]), float(c["doppler_hz"])): o for c, o in zip(mine, got)}
+            hits = 0
+            for c in range(8):
+                sat = scene[0, c]
+                d = 100.0 * round(float(sat["doppler_hz"]) / 100.0)
+                d = min(max(d, -10000.0), 9900.0)
+                o = table.get((0, int(sat["sat_id"]), d))
+                hits += int(o is not None and abs(int(o["argmax"]) - int(sat["code_phase"])) <= 1)
+        samples_per_step = n_streams * n_ms * n             # whole job: the cells are sharded, not the samples
+        flops = len(mine) * (n_ms * 6 * n + 2 * fft_flops(n) + 5 * n)
+        result = {
+            "workload_name": "cfg5", "scaling": "strong", "divide_by_world": True,
+            "config": {"workload": f"cfg5: synthetic IQ {fs / 1e6:.3f} Msps, {n_streams} stream(s), 32 sats x "
+                                   f"range(-10000,10000,100) Hz x 10 ms coherent = {len(flat)} cells",
+                       "sample_rate_hz": fs, "streams_total": n_streams, "cells_total": int(len(flat)),
+                       "parallelism": f"(satellite x Doppler) cells sharded over {world} GPU(s), all-gather of cell records"},
+            "samples_per_step": samples_per_step, "elapsed": elapsed, "fs": fs,
+            "dominant": {"kernel": "corr_cells_kernel<48,true>", "ms": k_ms, "flops": flops,
+                         "bytes": 8 * n * n_ms * n_streams + 32 * len(mine)},
+            "extra": {"planted_sats_found_stream0": None if hits is None else f"{hits}/8"},
+        }
     else:
+        from gypsum_amd.dist import shard_bounds
         fs, n = 2_046_000, 2046
         eng.set_stream_format(fs, n)
         B, T = args.streams, args.grid_ms
+        if args.workload == "cfg4":                         # 64 streams in total, sharded by stream
+            lo, hi = shard_bounds(64, rank, world)
+            B = hi - lo
         amp, sigma = 0.010, 0.05
         scene = make_scene(rng, B, 8, fs, amp)
         iq = eng.alloc(B * T * n * 8)
@@ -279,9 +363,17 @@ def main() -> None:
         cells_dev = eng.alloc(cells.nbytes).upload(cells.reshape(-1))
         out_dev = eng.alloc(cells.size * CELL.itemsize)
 
+        gather = None
+        if dist is not None and args.workload == "cfg4":     # per-(stream-ms, satellite) best-bin records, 16 B each
+            gather = (torch.zeros(22 * T * 32 * 16, dtype=torch.uint8, device="cuda"),
+                      torch.empty(world * 22 * T * 32 * 16, dtype=torch.uint8, device="cuda"))
+
         def step(i: int) -> None:
             eng._check(eng.lib.gyp_correlate_cells_dev(eng.ctx, iq.ptr, n, 1, cells_dev.ptr, cells.size, GYP_NON_COHERENT,
                                                        out_dev.ptr, None))
+            if gather is not None:
+                eng.sync()
+                dist.all_gather_into_tensor(gather[1], gather[0])
 
         for i in range(args.warmup):
             step(i)
@@ -305,8 +397,8 @@ def main() -> None:
         samples_per_step = B * T * n
         flops = n_units * (len(bins) * (6 * n + fft_flops(n)) + 32 * len(bins) * (6 * n + fft_flops(n) + 5 * n))
         result = {
-            "workload_name": "cfg2",
-            "config": {"workload": f"cfg2: synthetic IQ {fs / 1e6:.3f} Msps, 32 sats x range(-5000,5000,500) Hz x 1 ms "
+            "workload_name": args.workload, "scaling": "strong" if args.workload == "cfg4" else "weak",
+            "config": {"workload": f"{args.workload}: synthetic IQ {fs / 1e6:.3f} Msps, 32 sats x range(-5000,5000,500) Hz x 1 ms "
                                    f"non-coherent grid, {B} streams x {T} ms per step",
                        "sample_rate_hz": fs, "streams_per_gpu": B, "grid_ms_per_step": T,
                        "parallelism": f"stream-ms sharded over {world} GPU(s)"},
@@ -325,7 +417,9 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        total_samples = result["samples_per_step"] * args.steps * world
+        total_samples = result["samples_per_step"] * args.steps * (1 if result.get("divide_by_world") else world)
+        if result["workload_name"] == "cfg4":
+            total_samples = 64 * args.grid_ms * 2046 * args.steps
         value = total_samples / elapsed / 1e6
         dom = result["dominant"]
         traffic = None
@@ -338,11 +432,12 @@ def main() -> None:
         line = {
             "metric": "iq_msamples_per_s_32sat_acquire_plus_track" if result["workload_name"] == "cfg3" else "iq_msamples_per_s_32sat_acquisition_grid",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": result.get("scaling", "weak"),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (generated on device; no recording ships with the reference)",
             "config": result["config"],
             "x_realtime_aggregate": round(value * 1e6 / result["fs"], 2),
-            "x_realtime_per_stream": round(value * 1e6 / result["fs"] / (world * args.streams), 3),
+            "x_realtime_per_stream": round(value * 1e6 / result["fs"] / max(1, result.get("streams_total", world * args.streams)), 3),
             "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,

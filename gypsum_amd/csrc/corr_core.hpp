@@ -155,12 +155,11 @@ __device__ __forceinline__ void transpose32(cf (&x)[32], float* tile_half, int l
 #pragma unroll
     for (int g = 0; g < 32; ++g) tile_half[kXchRow * g + l] = x[perm(g)].x;
     wave_lds_fence();
-    float re[32];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < 16; ++j) {   // the old real parts are dead: the new ones land in the same registers
         const float2 v = row[j];
-        re[2 * j] = v.x;
-        re[2 * j + 1] = v.y;
+        x[2 * j].x = v.x;
+        x[2 * j + 1].x = v.y;
     }
     wave_lds_fence();
 #pragma unroll
@@ -169,8 +168,8 @@ __device__ __forceinline__ void transpose32(cf (&x)[32], float* tile_half, int l
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const float2 v = row[j];
-        x[2 * j] = make_float2(re[2 * j], v.x);
-        x[2 * j + 1] = make_float2(re[2 * j + 1], v.y);
+        x[2 * j].y = v.x;
+        x[2 * j + 1].y = v.y;
     }
     wave_lds_fence();
 }

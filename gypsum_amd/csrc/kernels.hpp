@@ -14,6 +14,10 @@
 #include "corr_core.hpp"
 #include "../../include/gypsum_hip.h"
 
+#ifndef GYP_CELLS8_WAVES
+#define GYP_CELLS8_WAVES 4
+#endif
+
 namespace gyp {
 
 // ---------------------------------------------------------------------------------------------------------
@@ -169,23 +173,32 @@ struct LaneStats {
 __device__ __forceinline__ LaneStats lane_stats_init() {
     return LaneStats{Best{-1.0f, 0x7fffffff}, make_float2(0.f, 0.f), 0.f, 0};
 }
-template <int K, typename KeyFn>
+// SQ: vals are SQUARED magnitudes (ordering and ties are then decided on re^2 + im^2, which resolves more
+// near-ties than the rounded square root would); the sum always accumulates magnitudes.  Branch-free.
+template <int K, bool SQ, typename KeyFn>
 __device__ __forceinline__ void lane_stats_update(LaneStats& ls, const float (&vals)[16], const cf* cvals, int rho, int tid,
                                                   KeyFn key_of) {
     const int base = lag_base<K>(tid, rho);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        if (slot_valid(j, tid)) {
-            const float v = vals[j];
-            const int key = key_of(base + 32 * K * j);
-            ls.sum += v;
-            if (v > ls.b.v) { ls.b = Best{v, key}; ls.cnt = 1; if (cvals) ls.val = cvals[j]; }
-            else if (v == ls.b.v) { ++ls.cnt; if (key < ls.b.key) { ls.b.key = key; if (cvals) ls.val = cvals[j]; } }
+        const bool valid = slot_valid(j, tid);
+        const float v = valid ? vals[j] : -1.0f;
+        const int key = key_of(base + 32 * K * j);
+        const float m = SQ ? __builtin_amdgcn_sqrtf(vals[j]) : vals[j];
+        ls.sum += valid ? m : 0.0f;
+        const bool gt = v > ls.b.v, eq = v == ls.b.v;
+        const bool take = gt || (eq && key < ls.b.key);
+        ls.cnt = gt ? 1 : ls.cnt + (eq ? 1 : 0);
+        ls.b.v = gt ? v : ls.b.v;
+        ls.b.key = take ? key : ls.b.key;
+        if (cvals) {
+            ls.val.x = take ? cvals[j].x : ls.val.x;
+            ls.val.y = take ? cvals[j].y : ls.val.y;
         }
     }
 }
 // Result valid in every thread of the workgroup.
-template <int K>
+template <int K, bool SQ = false>
 __device__ __forceinline__ ProfileStats lane_stats_finish(const LaneStats& ls, RedScratch* red, int tid) {
     constexpr int W = Geom<K>::W;
     const int wave = tid >> 6;
@@ -210,7 +223,7 @@ __device__ __forceinline__ ProfileStats lane_stats_finish(const LaneStats& ls, R
     st.n_max = 0;
 #pragma unroll
     for (int w = 0; w < W; ++w) st.n_max += (red->cand[w].v == g.v) ? red->cand[w].cnt : 0;
-    st.best = Best{g.v, g.key};
+    st.best = Best{SQ ? __builtin_amdgcn_sqrtf(g.v) : g.v, g.key};
     st.peak = make_float2(g.re, g.im);
     return st;
 }
@@ -232,7 +245,7 @@ struct CellsParams {
 };
 
 template <int K, bool COHERENT>
-__global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void corr_cells_kernel(CellsParams p) {
+__global__ __launch_bounds__(Geom<K>::kThreads, (K == 8 && !COHERENT) ? GYP_CELLS8_WAVES : Geom<K>::kMinWavesPerSimd) void corr_cells_kernel(CellsParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int N = K * kChips;
     constexpr int R = Geom<K>::R;
@@ -259,14 +272,14 @@ __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void 
                 float mag[16];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    mag[j] = sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
+                    mag[j] = __builtin_amdgcn_sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
                     if (slot_valid(j, tid)) {
                         const int idx = base + 32 * K * j;
                         if (idx == d.tap_index) { p.out[cell].tap_re = c[j].x; p.out[cell].tap_im = c[j].y; }
                         if (p.profile_out) reinterpret_cast<float2*>(p.profile_out)[(int64_t)cell * N + idx] = c[j];
                     }
                 }
-                lane_stats_update<K>(ls, mag, nullptr, rho, tid, [](int idx) { return idx; });
+                lane_stats_update<K, false>(ls, mag, nullptr, rho, tid, [](int idx) { return idx; });
                 __syncthreads();  // every wavefront is done with the tiles before the next round is staged
             }
         } else {
@@ -281,14 +294,14 @@ __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void 
                     cf c[16];
                     correlate_round<K>(stream + (int64_t)ms * N, rho, u0_step * (double)ms, du, cs, sm, rep, c);
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) mag[rho][j] += sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
+                    for (int j = 0; j < 16; ++j) mag[rho][j] += __builtin_amdgcn_sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
                     __syncthreads();
                 }
             }
             const int tid = launder(threadIdx.x);
 #pragma unroll
             for (int rho = 0; rho < R; ++rho) {
-                lane_stats_update<K>(ls, mag[rho], nullptr, rho, tid, [](int idx) { return idx; });
+                lane_stats_update<K, false>(ls, mag[rho], nullptr, rho, tid, [](int idx) { return idx; });
                 if (p.profile_out) {
                     const int base = lag_base<K>(tid, rho);
 #pragma unroll
@@ -348,9 +361,9 @@ __device__ __forceinline__ void epl_round(const cf (&c)[16], int rho, int s, Lan
     constexpr int N = K * kChips;
     constexpr int W = Geom<K>::W;
     const int ie = mod_n(s - 1, N), il = mod_n(s + 1, N);
-    float mag[16];
+    float pw[16];   // squared magnitudes
 #pragma unroll
-    for (int j = 0; j < 16; ++j) mag[j] = sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
+    for (int j = 0; j < 16; ++j) pw[j] = fmaf(c[j].x, c[j].x, c[j].y * c[j].y);
     // Lag index idx lives in round (idx % K) / W, wavefront (idx % K) % W, lane (q & 31) + 32*(q >> 9),
     // slot (q >> 5) & 15 with q = idx / K: all wave-uniform.
 #pragma unroll
@@ -367,14 +380,14 @@ __device__ __forceinline__ void epl_round(const cf (&c)[16], int rho, int s, Lan
         const int base = lag_base<K>(tid, rho);
 #pragma unroll
         for (int j = 0; j < 16; ++j)
-            if (slot_valid(j, tid)) { int k = base + 32 * K * j - s; profile_row[k < 0 ? k + N : k] = mag[j]; }
+            if (slot_valid(j, tid)) { int k = base + 32 * K * j - s; profile_row[k < 0 ? k + N : k] = __builtin_amdgcn_sqrtf(pw[j]); }
     }
-    lane_stats_update<K>(ls, mag, c, rho, tid, [s](int idx) { int k = idx - s; return k < 0 ? k + N : k; });
+    lane_stats_update<K, true>(ls, pw, c, rho, tid, [s](int idx) { int k = idx - s; return k < 0 ? k + N : k; });
 }
 
 template <int K>
 __device__ __forceinline__ EplResult epl_finish(const LaneStats& ls, RedScratch* red, int tid) {
-    const ProfileStats st = lane_stats_finish<K>(ls, red, tid);   // its barrier also publishes the taps
+    const ProfileStats st = lane_stats_finish<K, true>(ls, red, tid);   // its barrier also publishes the taps
     EplResult r;
     r.early = make_float2(red->taps[0], red->taps[1]);
     r.late = make_float2(red->taps[2], red->taps[3]);
