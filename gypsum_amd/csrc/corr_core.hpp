@@ -243,14 +243,8 @@ __device__ __forceinline__ void wave_fft_inv(cf (&x)[32], cf (&c)[16], float* ti
 }
 
 // The per-satellite frequency-domain replica table is [32 sats][32 physical regs][64 lanes] complex.
-__device__ __forceinline__ const cf* replica_column(const cf* __restrict__ table, int sat_index, int lane) {
-    return table + (size_t)sat_index * 32 * 64 + lane;
-}
-// Fetch this lane's 32 replica values (32 coalesced 512-byte rows, L1/L2 resident).  Issued before the forward
-// transform so the latency hides behind it.
-__device__ __forceinline__ void load_replica(cf (&p)[32], const cf* __restrict__ rep_column) {
-#pragma unroll
-    for (int i = 0; i < 32; ++i) p[i] = rep_column[64 * i];
+__device__ __forceinline__ const cf* replica_of(const cf* __restrict__ table, int sat_index) {
+    return table + (size_t)sat_index * 32 * 64;
 }
 // Multiply by the replica straight from L1/L2 in four batches of eight loads (bounded register footprint; the
 // other wavefronts of the SIMD cover the latency).  `rep_sat` is the wave-uniform base of this satellite's
@@ -267,23 +261,13 @@ __device__ __forceinline__ void spectrum_mul_from(cf (&x)[32], const cf* __restr
         __builtin_amdgcn_sched_barrier(0);
     }
 }
-__device__ __forceinline__ void spectrum_mul(cf (&x)[32], const cf (&p)[32]) {
-#pragma unroll
-    for (int i = 0; i < 32; ++i) x[i] = cmul(x[i], p[i]);
-}
 
 // ---------------------------------------------------------------------------------------------------------
-// carrier NCO: exp(-2*pi*i * u), u in cycles, float64 range reduction then float32 sincos
+// carrier NCO: exp(-2*pi*i * u), u in cycles.  float64 range reduction (a float32 2*pi*f*t fails the
+// 1e-4 bar at t ~ 40 s), then float32 sine/cosine: u is reduced to [-0.5, 0.5] revolutions, folded to the nearest
+// quarter turn, and odd/even Taylor polynomials of t = 2*pi*r, |t| <= pi/4, are evaluated (truncation < 2e-9, so
+// float32 rounding dominates: |error| < 1e-7, checked against numpy) -- ~25 instructions instead of a library call.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ cf carrier_from_cycles(double u) {
-    const double fr = u - rint(u);  // [-0.5, 0.5]: tiny per-sample increments keep their relative precision
-    float s, c;
-    sincospif(2.0f * (float)fr, &s, &c);
-    return make_float2(c, -s);
-}
-// Same for the per-chip anchors, without the library call's generality: the argument is already reduced to
-// [-0.5, 0.5] revolutions, so fold to the nearest quarter turn and evaluate odd/even Taylor polynomials of
-// t = 2*pi*r, |t| <= pi/4 (truncation < 2e-9, i.e. float32 rounding dominates) -- ~25 instructions.
 __device__ __forceinline__ cf carrier_from_cycles_fast(double u) {
     const float x = (float)(u - rint(u));
     const float q = rintf(4.0f * x);                     // -2 .. 2

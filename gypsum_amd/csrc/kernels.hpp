@@ -1,9 +1,10 @@
 // kernels.hpp -- the __global__ kernels of libgypsum_hip.so (gfx950 only).
 //
-//   corr_cells_kernel   one workgroup per (stream, satellite, Doppler) cell, K wavefronts (K = samples per chip):
-//                       for each ms block: carrier wipe-off + polyphase pre-sum (global -> LDS), then per
-//                       wavefront FFT2048 -> x conj(PRN spectrum) -> IFFT2048, |.| / complex accumulation in
-//                       registers; finally max / argmax / sum / count-of-max reductions.
+//   corr_cells_kernel   one workgroup per (stream, satellite, Doppler) cell, min(K, 8) wavefronts (K = samples per
+//                       chip; K > 8 in rounds of 8 polyphase branches): per ms block carrier wipe-off + polyphase
+//                       pre-sum (global -> LDS), then per wavefront FFT2048 -> x conj(PRN spectrum) -> IFFT2048 and
+//                       |.| accumulation in registers (non-coherent), or the blocks folded before ONE transform
+//                       (coherent); finally max / first-argmax / sum / count-of-max reductions.
 //                       == utils.py:77-108 + the reductions of acquisition.py:180-189.
 //   track_step_kernel   same core for one explicit millisecond of one tracking channel, plus the early/late taps
 //                       and the rolled-PRN argmax of tracker.py:284-313.
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, (K == 8 && !COHERENT) ? GYP_CELL
         const int cell = xcd_contiguous(v, p.n_cells);
         const gyp_cell_desc d = p.cells[cell];
         if (d.sat_id < 1 || d.sat_id > 32) continue;  // padding cell (uniform across the workgroup)
-        const cf* rep = replica_column(p.replica_table, d.sat_id - 1, 0);
+        const cf* rep = replica_of(p.replica_table, d.sat_id - 1);
         const double du = d.doppler_hz * p.inv_fs;
         const CarrierSteps cs = carrier_steps<K>(du);
         const cf* stream = p.iq + (int64_t)d.stream * p.stream_stride;
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void 
     for (int v = blockIdx.x; v < p.n_chan; v += gridDim.x) {
         const int ch = xcd_contiguous(v, p.n_chan);
         const gyp_chan_in in = p.chans[ch];
-        const cf* rep = replica_column(p.replica_table, in.sat_id - 1, 0);
+        const cf* rep = replica_of(p.replica_table, in.sat_id - 1);
         // tracker.py:271-281: carrier = exp(-1j*(2*pi*f*t + phi)), t = n/fs + chunk.start_time
         const double du = in.doppler_hz * p.inv_fs;
         const double u0 = in.doppler_hz * p.start_time[in.stream] + in.carrier_phase * 0.15915494309189533577;
@@ -627,7 +628,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void 
     if ((int)blockIdx.x >= p.n_chan) return;
     const int ch = xcd_contiguous(blockIdx.x, p.n_chan);
     ChanState* st = p.states + ch;
-    const cf* rep = replica_column(p.replica_table, st->sat_id - 1, 0);
+    const cf* rep = replica_of(p.replica_table, st->sat_id - 1);
     const cf* stream = p.iq + (int64_t)st->stream * p.stream_stride;
     // Loop state lives in LDS between milliseconds (RedScratch::dstate / istate / steps / loop) and is re-read where
     // it is needed, so that no wavefront carries it in registers across the transforms.
