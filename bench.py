@@ -274,17 +274,11 @@ def main() -> None:
         iq = eng.alloc(n_streams * n_ms * n * 8)
         eng.synth_iq(iq, n_streams, n_ms * n, n_ms, scene, 0.005, 555)
         bins = np.arange(-10000, 10000, 100, dtype=np.float64)
-        cells = np.zeros((n_streams, 32, len(bins)), dtype=CELL_DESC)
-        cells["stream"] = np.arange(n_streams)[:, None, None]
-        cells["sat_id"] = np.arange(1, 33)[None, :, None]
-        cells["doppler_hz"] = bins[None, None, :]
-        cells["tap_index"] = -1
-        flat = cells.reshape(-1)
-        lo, hi = shard_bounds(len(flat), rank, world)
-        mine = np.ascontiguousarray(flat[lo:hi])
-        cells_dev = eng.alloc(mine.nbytes).upload(mine)
-        counts = [b - a for a, b in (shard_bounds(len(flat), r, world) for r in range(world))]
-        pad = max(counts)
+        lo, hi = shard_bounds(len(bins), rank, world)        # shard the Doppler axis: a bin's wipe-off is shared by 32 sats
+        my_bins = bins[lo:hi]
+        all_ids = list(range(1, 33))
+        n_mine = n_streams * 32 * len(my_bins)
+        pad = n_streams * 32 * max(b - a for a, b in (shard_bounds(len(bins), r, world) for r in range(world)))
         if dist is not None:
             send = torch.zeros(pad * CELL.itemsize, dtype=torch.uint8, device="cuda")
             recv = torch.empty(world * pad * CELL.itemsize, dtype=torch.uint8, device="cuda")
@@ -292,11 +286,9 @@ def main() -> None:
         else:
             out_dev = eng.alloc(pad * CELL.itemsize)
             out_ptr = out_dev.ptr.value
-        import ctypes as C
 
         def step(i: int) -> None:
-            eng._check(eng.lib.gyp_correlate_cells_dev(eng.ctx, iq.ptr, n_ms * n, n_ms, cells_dev.ptr, len(mine), 0,
-                                                       C.c_void_p(out_ptr), None))
+            eng.correlate_grid_dev(iq.ptr.value, n_streams, n_ms * n, n_ms, all_ids, my_bins, 0, out_ptr)
             if dist is not None:
                 eng.sync()
                 dist.all_gather_into_tensor(recv, send)
@@ -310,23 +302,22 @@ def main() -> None:
         full_sync(); barrier()
         elapsed = time.perf_counter() - t0
         eng.timer_start()
-        eng._check(eng.lib.gyp_correlate_cells_dev(eng.ctx, iq.ptr, n_ms * n, n_ms, cells_dev.ptr, len(mine), 0,
-                                                   C.c_void_p(out_ptr), None))
+        eng.correlate_grid_dev(iq.ptr.value, n_streams, n_ms * n, n_ms, all_ids, my_bins, 0, out_ptr)
         k_ms = eng.timer_stop()
         if dist is not None:
-            got = np.frombuffer(send.cpu().numpy().tobytes(), dtype=CELL)[:len(mine)]
+            got = np.frombuffer(send.cpu().numpy().tobytes(), dtype=CELL)[:n_mine]
         else:
-            got = out_dev.download(CELL, len(mine))
-        hits = None
-        if rank == 0:
-            table = {(int(c["stream"]), int(c["sat_id"]), float(c["doppler_hz"])): o for c, o in zip(mine, got)}
-            hits = 0
-            for c in range(8):
-                sat = scene[0, c]
-                d = 100.0 * round(float(sat["doppler_hz"]) / 100.0)
-                d = min(max(d, -10000.0), 9900.0)
-                o = table.get((0, int(sat["sat_id"]), d))
-                hits += int(o is not None and abs(int(o["argmax"]) - int(sat["code_phase"])) <= 1)
+            got = out_dev.download(CELL, n_mine)
+        got = got.reshape(n_streams, 32, len(my_bins))
+        hits = 0
+        for c in range(8):
+            sat = scene[0, c]
+            d = min(max(100.0 * round(float(sat["doppler_hz"]) / 100.0), -10000.0), 9900.0)
+            b = int(round((d - my_bins[0]) / 100.0))
+            if 0 <= b < len(my_bins):
+                hits += int(abs(int(got[0, int(sat["sat_id"]) - 1, b]["argmax"]) - int(sat["code_phase"])) <= 1)
+        flat = np.zeros(n_streams * 32 * len(bins))
+        mine = np.zeros(n_mine)
         samples_per_step = n_streams * n_ms * n             # whole job: the cells are sharded, not the samples
         flops = len(mine) * (n_ms * 6 * n + 2 * fft_flops(n) + 5 * n)
         result = {
@@ -334,9 +325,9 @@ def main() -> None:
             "config": {"workload": f"cfg5: synthetic IQ {fs / 1e6:.3f} Msps, {n_streams} stream(s), 32 sats x "
                                    f"range(-10000,10000,100) Hz x 10 ms coherent = {len(flat)} cells",
                        "sample_rate_hz": fs, "streams_total": n_streams, "cells_total": int(len(flat)),
-                       "parallelism": f"(satellite x Doppler) cells sharded over {world} GPU(s), all-gather of cell records"},
+                       "parallelism": f"Doppler bins (x 32 satellites) sharded over {world} GPU(s), all-gather of cell records"},
             "samples_per_step": samples_per_step, "elapsed": elapsed, "fs": fs,
-            "dominant": {"kernel": "corr_cells_kernel<48,true>", "ms": k_ms, "flops": flops,
+            "dominant": {"kernel": "grid_fold_kernel<48,true> + grid_cells_kernel<48,true>", "ms": k_ms, "flops": flops,
                          "bytes": 8 * n * n_ms * n_streams + 32 * len(mine)},
             "extra": {"planted_sats_found_stream0": None if hits is None else f"{hits}/8"},
         }
@@ -355,22 +346,20 @@ def main() -> None:
         bins = np.arange(-5000, 5000, 500, dtype=np.float64)
         # every (stream, ms) is an independent 1-ms search: present each ms as its own "stream" of stride N
         n_units = B * T
-        cells = np.zeros((n_units, 32, len(bins)), dtype=CELL_DESC)
-        cells["stream"] = np.arange(n_units)[:, None, None]
-        cells["sat_id"] = np.arange(1, 33)[None, :, None]
-        cells["doppler_hz"] = bins[None, None, :]
-        cells["tap_index"] = -1
-        cells_dev = eng.alloc(cells.nbytes).upload(cells.reshape(-1))
-        out_dev = eng.alloc(cells.size * CELL.itemsize)
+        all_ids = list(range(1, 33))
+        n_cells = n_units * 32 * len(bins)
+        out_dev = eng.alloc(n_cells * CELL.itemsize)
 
+        class _Cells:                                      # only .size is used below
+            size = n_cells
+        cells = _Cells()
         gather = None
         if dist is not None and args.workload == "cfg4":     # per-(stream-ms, satellite) best-bin records, 16 B each
             gather = (torch.zeros(22 * T * 32 * 16, dtype=torch.uint8, device="cuda"),
                       torch.empty(world * 22 * T * 32 * 16, dtype=torch.uint8, device="cuda"))
 
         def step(i: int) -> None:
-            eng._check(eng.lib.gyp_correlate_cells_dev(eng.ctx, iq.ptr, n, 1, cells_dev.ptr, cells.size, GYP_NON_COHERENT,
-                                                       out_dev.ptr, None))
+            eng.correlate_grid_dev(iq.ptr.value, n_units, n, 1, all_ids, bins, GYP_NON_COHERENT, out_dev.ptr.value)
             if gather is not None:
                 eng.sync()
                 dist.all_gather_into_tensor(gather[1], gather[0])
@@ -403,7 +392,7 @@ def main() -> None:
                        "sample_rate_hz": fs, "streams_per_gpu": B, "grid_ms_per_step": T,
                        "parallelism": f"stream-ms sharded over {world} GPU(s)"},
             "samples_per_step": samples_per_step, "elapsed": elapsed, "fs": fs,
-            "dominant": {"kernel": "corr_cells_kernel<2,false>", "ms": k_ms, "flops": flops,
+            "dominant": {"kernel": "grid_fold_kernel<2,false> + grid_cells_kernel<2,false>", "ms": k_ms, "flops": flops,
                          "bytes": (8 * n + 32 * 32 * len(bins)) * n_units},
             "extra": {"visible_sats_found_stream0_ms0": f"{hits}/8"},
         }

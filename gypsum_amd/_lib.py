@@ -37,7 +37,8 @@ RECORD_SIZES = {"gyp_synth_sat": 32, "gyp_cell_desc": 24, "gyp_cell": 32, "gyp_a
 EXPORTS = (
     "gyp_version gyp_create gyp_destroy gyp_last_error gyp_device_name gyp_set_stream gyp_sync gyp_timer_start "
     "gyp_timer_stop gyp_set_stream_format gyp_prn_chips gyp_prn_spectrum_lane_layout gyp_malloc gyp_free "
-    "gyp_memcpy_h2d gyp_memcpy_d2h gyp_cell_strength gyp_correlate_cells_dev gyp_correlate_cells gyp_acquire_dev "
+    "gyp_memcpy_h2d gyp_memcpy_d2h gyp_cell_strength gyp_correlate_cells_dev gyp_correlate_cells gyp_correlate_grid_dev "
+    "gyp_correlate_grid gyp_acquire_dev "
     "gyp_acquire gyp_track_step_dev gyp_track_step gyp_bank_create gyp_bank_destroy gyp_bank_size "
     "gyp_track_block_dev gyp_track_block gyp_bank_get_state gyp_synth_iq_dev gyp_synth_nav_bit gyp_bank_reset_dev gyp_debug_track_profile gyp_debug_fft_bench"
 ).split()
@@ -83,6 +84,8 @@ def load() -> C.CDLL:
         "gyp_cell_strength": (dbl, [vp, i32]),
         "gyp_correlate_cells_dev": (C.c_int, [vp, vp, i64, i32, vp, i32, i32, vp, vp]),
         "gyp_correlate_cells": (C.c_int, [vp, vp, i32, i32, vp, i32, i32, vp, vp]),
+        "gyp_correlate_grid_dev": (C.c_int, [vp, vp, i32, i64, i32, vp, i32, vp, i32, i32, vp]),
+        "gyp_correlate_grid": (C.c_int, [vp, vp, i32, i32, vp, i32, vp, i32, i32, vp]),
         "gyp_acquire_dev": (C.c_int, [vp, vp, i32, i64, i32, vp, i32, vp]),
         "gyp_acquire": (C.c_int, [vp, vp, i32, i32, vp, i32, vp]),
         "gyp_track_step_dev": (C.c_int, [vp, vp, i64, vp, vp, i32, vp, vp]),

@@ -426,6 +426,78 @@ int gyp_correlate_cells(gyp_ctx* ctx, const float* iq_host, int32_t n_streams, i
     return GYP_OK;
 }
 
+// ---------------------------------------------------------------- flat search grid -----------------------
+int gyp_correlate_grid_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_t stream_stride_samples, int32_t n_ms,
+                           const int32_t* sat_ids_host, int32_t n_sats, const double* doppler_hz_host, int32_t n_bins,
+                           int32_t integration, gyp_cell* out_dev) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    if (!ctx->k) return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
+    if (!iq_dev || !sat_ids_host || !doppler_hz_host || !out_dev || n_streams <= 0 || n_ms <= 0 || n_sats <= 0 || n_bins <= 0 ||
+        (integration != GYP_COHERENT && integration != GYP_NON_COHERENT))
+        return fail(ctx, GYP_E_BAD_ARG, "gyp_correlate_grid_dev: bad argument");
+    for (int i = 0; i < n_sats; ++i)
+        if (sat_ids_host[i] < 1 || sat_ids_host[i] > 32) return fail(ctx, GYP_E_BAD_ARG, "satellite id out of range");
+    const bool coh = integration == GYP_COHERENT;
+    const int n_blk = coh ? 1 : n_ms;
+    const int64_t n_units = (int64_t)n_streams * n_bins;
+    if (n_units > 2147483647LL / 2 || n_blk > 65535) return fail(ctx, GYP_E_BAD_ARG, "gyp_correlate_grid_dev: grid too large");
+    int rc;
+    const size_t folded_bytes = (size_t)n_units * n_blk * ctx->k * 1024 * sizeof(cf);
+    if ((rc = ensure_scratch(ctx, 0, folded_bytes))) return rc;
+    if ((rc = ensure_scratch(ctx, 1, (size_t)n_sats * sizeof(int32_t) + 64))) return rc;
+    if ((rc = ensure_scratch(ctx, 4, (size_t)n_bins * sizeof(double) + 64))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[1], sat_ids_host, (size_t)n_sats * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[4], doppler_hz_host, (size_t)n_bins * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the host arrays may be temporaries
+    GridParams p;
+    p.iq = reinterpret_cast<const cf*>(iq_dev);
+    p.stream_stride = stream_stride_samples;
+    p.n_ms = n_ms; p.n_streams = n_streams; p.n_sats = n_sats; p.n_bins = n_bins;
+    p.sat_ids = (const int32_t*)ctx->scratch[1];
+    p.doppler = (const double*)ctx->scratch[4];
+    p.folded = (cf*)ctx->scratch[0];
+    p.out = out_dev;
+    p.replica_table = ctx->d_replicas;
+    p.tw_tables = ctx->d_tw;
+    p.inv_fs = 1.0 / (double)ctx->fs;
+    const int n_cells = n_streams * n_sats * n_bins;
+    const int grid = std::max(1, std::min(n_cells, ctx->n_cus * blocks_per_cu(ctx->k)) & ~7);
+    switch (ctx->k) {
+#define X(K)                                                                                                                  \
+    case K: {                                                                                                                 \
+        const dim3 fgrid((unsigned)n_units, (unsigned)n_blk, (unsigned)Geom<K>::R);                                            \
+        if (coh) hipLaunchKernelGGL((grid_fold_kernel<K, true>), fgrid, dim3(threads_for(K)), 0, ctx->stream, p);             \
+        else hipLaunchKernelGGL((grid_fold_kernel<K, false>), fgrid, dim3(threads_for(K)), 0, ctx->stream, p);                \
+        HIP_TRY(ctx, hipGetLastError());                                                                                      \
+        return coh ? launch_k(ctx, grid_cells_kernel<K, true>, K, grid, p, lds_bytes<K>())                                    \
+                   : launch_k(ctx, grid_cells_kernel<K, false>, K, grid, p, lds_bytes<K>());                                  \
+    }
+        GYP_FOR_EACH_RATE(X)
+#undef X
+    }
+    return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
+}
+
+int gyp_correlate_grid(gyp_ctx* ctx, const float* iq_host, int32_t n_streams, int32_t n_ms, const int32_t* sat_ids_host,
+                       int32_t n_sats, const double* doppler_hz_host, int32_t n_bins, int32_t integration, gyp_cell* out_host) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    if (!ctx->k) return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
+    if (!iq_host || !out_host || n_streams <= 0 || n_ms <= 0 || n_sats <= 0 || n_bins <= 0)
+        return fail(ctx, GYP_E_BAD_ARG, "gyp_correlate_grid: bad argument");
+    const size_t iq_bytes = (size_t)n_streams * n_ms * ctx->n * 8;
+    const size_t out_bytes = (size_t)n_streams * n_sats * n_bins * sizeof(gyp_cell);
+    int rc;
+    if ((rc = ensure_scratch(ctx, 5, iq_bytes))) return rc;
+    if ((rc = ensure_scratch(ctx, 2, out_bytes))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[5], iq_host, iq_bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = gyp_correlate_grid_dev(ctx, (const float*)ctx->scratch[5], n_streams, (int64_t)n_ms * ctx->n, n_ms, sat_ids_host, n_sats,
+                                doppler_hz_host, n_bins, integration, (gyp_cell*)ctx->scratch[2]);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out_host, ctx->scratch[2], out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GYP_OK;
+}
+
 // ---------------------------------------------------------------- acquisition ----------------------------
 int gyp_acquire_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_t stream_stride_samples,
                     int32_t n_ms, const int32_t* sat_ids_host, int32_t n_sats, gyp_acq_result* out_dev) {

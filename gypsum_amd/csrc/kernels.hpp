@@ -325,6 +325,104 @@ __global__ __launch_bounds__(Geom<K>::kThreads, (K == 8 && !COHERENT) ? GYP_CELL
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// flat search grid (every satellite shares the same Doppler bins, e.g. BASELINE configs 2/4/5 and the first level
+// of the acquisition search): the wipe-off + polyphase pre-sum depends on (stream, Doppler, ms) only, so it is
+// done ONCE per bin by grid_fold_kernel into a [unit][block][branch][1024] staging array in HBM/L2, and the 32
+// satellites' workgroups read it back (coalesced, straight into transform registers: no LDS staging, no barrier
+// in front of the transforms).
+// ---------------------------------------------------------------------------------------------------------
+struct GridParams {
+    const cf* iq;
+    int64_t stream_stride;
+    int32_t n_ms, n_streams, n_sats, n_bins;
+    const int32_t* sat_ids;     // [n_sats]
+    const double* doppler;      // [n_bins]
+    cf* folded;                 // [n_streams*n_bins][n_blk][K][1024]; n_blk = 1 (coherent) or n_ms
+    gyp_cell* out;              // [n_streams][n_sats][n_bins]
+    const cf* replica_table;
+    const cf* tw_tables;
+    double inv_fs;
+};
+
+// grid: (n_streams*n_bins, n_blk, R); block: 64*W threads
+template <int K, bool COHERENT>
+__global__ __launch_bounds__(Geom<K>::kThreads) void grid_fold_kernel(GridParams p) {
+    constexpr int W = Geom<K>::W;
+    constexpr int N = K * kChips;
+    const int unit = blockIdx.x, blk = blockIdx.y, rho = blockIdx.z;
+    const int stream = unit / p.n_bins, bin = unit % p.n_bins;
+    const int n_blk = COHERENT ? 1 : p.n_ms;
+    const double f = p.doppler[bin];
+    const double du = f * p.inv_fs;
+    const CarrierSteps cs = carrier_steps<K>(du);
+    const double u0_step = f * ((double)N * p.inv_fs);
+    cf* base = p.folded + (((int64_t)unit * n_blk + blk) * K + rho * W) * 1024;
+    cf* y_rows[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) y_rows[w] = base + w * 1024;
+    const cf* src = p.iq + (int64_t)stream * p.stream_stride + (COHERENT ? 0 : (int64_t)blk * N);
+    stage_general<K, W>(src, COHERENT ? p.n_ms : 1, rho, COHERENT ? 0.0 : u0_step * (double)blk, u0_step, du, cs, y_rows,
+                        (int)threadIdx.x);
+    if ((int)threadIdx.x < W) y_rows[threadIdx.x][kChips] = make_float2(0.f, 0.f);
+}
+
+// grid-stride over cells (stream, sat, bin); block: 64*W threads
+template <int K, bool COHERENT>
+__global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void grid_cells_kernel(GridParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int W = Geom<K>::W;
+    constexpr int R = Geom<K>::R;
+    const Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
+    __syncthreads();
+    const int n_cells = p.n_streams * p.n_sats * p.n_bins;
+    const int n_blk = COHERENT ? 1 : p.n_ms;
+    for (int v = blockIdx.x; v < n_cells; v += gridDim.x) {
+        // bins vary fastest inside an XCD's contiguous slice, satellites next: the folded inputs of a bin and the
+        // replica of a satellite are both re-read from the same L2
+        const int cell = xcd_contiguous(v, n_cells);
+        const int bin = cell % p.n_bins, sat = (cell / p.n_bins) % p.n_sats, stream = cell / (p.n_bins * p.n_sats);
+        const cf* rep = replica_of(p.replica_table, p.sat_ids[sat] - 1);
+        const cf* unit = p.folded + (int64_t)(stream * p.n_bins + bin) * n_blk * K * 1024;
+        const int tid = launder(threadIdx.x);
+        const int wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
+        float* tile_half = reinterpret_cast<float*>(sm.xch + wave * kXchWave) + h * kXchTile;
+        const LdsTables t{sm.tw1024, sm.tw2048};
+        LaneStats ls = lane_stats_init();
+        float mag[R][16];
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) mag[rho][j] = 0.f;
+        for (int blk = 0; blk < n_blk; ++blk) {
+#pragma unroll
+            for (int rho = 0; rho < R; ++rho) {
+                const cf* yw = unit + ((int64_t)blk * K + rho * W + wave) * 1024 + launder(l);
+                cf x[32];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) x[j] = yw[32 * j];
+                cf c[16];
+                wave_fft_fwd(x, tile_half, t, l, h);
+                spectrum_mul_from(x, rep, lane);
+                wave_fft_inv(x, c, tile_half, t, l, h);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) mag[rho][j] += __builtin_amdgcn_sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
+            }
+        }
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho)
+            lane_stats_update<K, false>(ls, mag[rho], nullptr, rho, tid, [](int idx) { return idx; });
+        const ProfileStats st = lane_stats_finish<K>(ls, sm.red, tid);
+        if (threadIdx.x == 0) {
+            gyp_cell o;
+            o.peak = st.best.v; o.argmax = st.best.key; o.sum = st.sum; o.n_max = st.n_max; o.reserved = 0;
+            o.tap_re = 0.f; o.tap_im = 0.f;
+            p.out[cell] = o;
+        }
+        __syncthreads();   // the reduction scratch is reused by the next cell
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // tracking, one explicit millisecond
 // ---------------------------------------------------------------------------------------------------------
 struct TrackStepParams {

@@ -126,6 +126,26 @@ class GypsumEngine:
                                                   integration, ptr(out), ptr(prof)))
         return out, prof
 
+    def correlate_grid(self, iq: np.ndarray, n_streams: int, n_ms: int, sat_ids: Sequence[int], doppler_hz: Sequence[float],
+                       integration: int) -> np.ndarray:
+        """Flat grid with shared Doppler bins: CELL records [n_streams, n_sats, n_bins]."""
+        iq = _as_iq(iq).reshape(-1)
+        if iq.size != n_streams * n_ms * self.n:
+            raise ValueError(f"expected {n_streams}*{n_ms}*{self.n} samples, got {iq.size}")
+        ids = np.ascontiguousarray(sat_ids, dtype=np.int32)
+        bins = np.ascontiguousarray(doppler_hz, dtype=np.float64)
+        out = np.zeros((n_streams, len(ids), len(bins)), dtype=CELL)
+        self._check(self.lib.gyp_correlate_grid(self.ctx, ptr(iq), n_streams, n_ms, ptr(ids), len(ids), ptr(bins), len(bins),
+                                                 integration, ptr(out)))
+        return out
+
+    def correlate_grid_dev(self, iq_ptr: int, n_streams: int, stream_stride: int, n_ms: int, sat_ids: Sequence[int],
+                           doppler_hz: Sequence[float], integration: int, out_ptr: int) -> None:
+        ids = np.ascontiguousarray(sat_ids, dtype=np.int32)
+        bins = np.ascontiguousarray(doppler_hz, dtype=np.float64)
+        self._check(self.lib.gyp_correlate_grid_dev(self.ctx, C.c_void_p(iq_ptr), n_streams, stream_stride, n_ms, ptr(ids),
+                                                     len(ids), ptr(bins), len(bins), integration, C.c_void_p(out_ptr)))
+
     def cell_strength(self, cells: np.ndarray) -> np.ndarray:
         """utils.py:111-116 on the reduced record, float64."""
         pk = cells["peak"].astype(np.float64)

@@ -117,6 +117,19 @@ int gyp_correlate_cells(gyp_ctx* ctx, const float* iq_host, int32_t n_streams, i
                         const gyp_cell_desc* cells_host, int32_t n_cells, int32_t integration,
                         gyp_cell* out_host, float* profile_out_host);
 
+/* A flat (satellite x Doppler) search grid in which every satellite uses the SAME Doppler bins -- one level of
+ * acquisition.py:154-190 get_best_doppler_shift_estimation for many satellites at once, e.g. BASELINE configs 2/4
+ * (range(-5000, 5000, 500), 1 ms) and 5 (range(-10000, 10000, 100), 10 ms coherent).  Same results as
+ * gyp_correlate_cells on the corresponding cells, but the carrier wipe-off is done once per (stream, bin) instead
+ * of once per (stream, satellite, bin).  out: n_streams x n_sats x n_bins records, bins fastest.
+ * Coherent: abs(sum_i c_i) reduced (no tap); non-coherent: sum_i abs(c_i). */
+int gyp_correlate_grid_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_t stream_stride_samples,
+                           int32_t n_ms, const int32_t* sat_ids_host, int32_t n_sats, const double* doppler_hz_host,
+                           int32_t n_bins, int32_t integration, gyp_cell* out_dev);
+int gyp_correlate_grid(gyp_ctx* ctx, const float* iq_host, int32_t n_streams, int32_t n_ms,
+                       const int32_t* sat_ids_host, int32_t n_sats, const double* doppler_hz_host, int32_t n_bins,
+                       int32_t integration, gyp_cell* out_host);
+
 /* ---------------------------------------------------------------- acquisition ------------------------- */
 /* acquisition.py:35-41 SatelliteAcquisitionAttemptResult */
 typedef struct gyp_acq_result {

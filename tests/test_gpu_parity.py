@@ -206,3 +206,59 @@ def test_unsupported_rates_are_rejected(engine_factory):
             eng.set_stream_format(fs, n)        # the reference itself cannot run 2.048 / 50 Msps
         assert e.value.code == GYP_E_BAD_RATE
     eng.close()
+
+
+def test_flat_grid_entry_point_matches_reference_and_cells(engine_factory):
+    """gyp_correlate_grid (wipe-off shared by the satellites of a bin) == the golden cfg2 grid == gyp_correlate_cells."""
+    z = gu.load("grid_kat_2046.npz")
+    fs, n = int(z["fs"]), int(z["n"])
+    eng = engine_factory(fs, n)
+    bins = z["bins"].astype(np.float64)
+    out = eng.correlate_grid(z["iq"], 1, 1, list(range(1, 33)), bins, GYP_NON_COHERENT)[0]
+    assert np.array_equal(out["argmax"], z["cell_argmax"])
+    np.testing.assert_allclose(out["peak"], z["cell_max"], rtol=RTOL_MAG)
+    np.testing.assert_allclose(eng.cell_strength(out), z["cell_strength"], rtol=RTOL_MAG)
+    # multi-ms, both integration kinds, two streams, against the per-cell entry point and the oracle
+    a = gu.load("acq_2046.npz")
+    iq2 = np.concatenate([a["iq"], a["iq"][::-1].copy()])
+    sats, dopp = [3, 19, 22, 7], [3696.0, -1143.0, 250.0]
+    chips = orc.generate_ca_codes()
+    for integ, kind in ((GYP_NON_COHERENT, orc.NON_COHERENT), (GYP_COHERENT, orc.COHERENT)):
+        g = eng.correlate_grid(iq2, 2, 10, sats, dopp, integ)
+        cells = np.zeros((2, len(sats), len(dopp)), dtype=CELL_DESC)
+        cells["stream"] = np.arange(2)[:, None, None]
+        cells["sat_id"] = np.array(sats)[None, :, None]
+        cells["doppler_hz"] = np.array(dopp)[None, None, :]
+        cells["tap_index"] = -1
+        c, _ = eng.correlate_cells(iq2, 2, 10, cells.reshape(-1), integ)
+        c = c.reshape(g.shape)
+        assert np.array_equal(g["argmax"], c["argmax"])
+        np.testing.assert_allclose(g["peak"], c["peak"], rtol=2e-6)
+        np.testing.assert_allclose(g["sum"], c["sum"], rtol=2e-6)
+        for si, sv in enumerate(sats[:2]):
+            ref = np.abs(orc.integrate_correlation(kind, iq2[:10 * n], fs, n, dopp[1], orc.prn_as_complex(chips[sv - 1], n)))
+            assert g["argmax"][0, si, 1] == int(np.argmax(ref))
+            assert g["peak"][0, si, 1] == pytest.approx(ref.max(), rel=RTOL_MAG)
+
+
+def test_config5_grid_slice_against_oracle(engine_factory):
+    """49.104 Msps, 10 ms coherent, 100-Hz bins (a slice of BASELINE config 5) through the grid entry point."""
+    from gypsum_amd import synth
+
+    fs, n = 49_104_000, 49_104
+    eng = engine_factory(fs, n)
+    scene = synth.random_scene(fs, 10, 2, 4242, max_doppler=9500.0, with_nav_bits=False)
+    iq = synth.render(scene)
+    chips = orc.generate_ca_codes()
+    s0 = scene.sats[0]
+    centre = 100.0 * round(s0.doppler_hz / 100.0)
+    bins = [centre - 100.0, centre, centre + 100.0]
+    sats = [s0.sat_id, scene.sats[1].sat_id, (s0.sat_id % 32) + 1]
+    g = eng.correlate_grid(iq, 1, 10, sats, bins, GYP_COHERENT)[0]
+    for si, sv in enumerate(sats):
+        for bi, d in enumerate(bins):
+            ref = np.abs(orc.integrate_correlation(orc.COHERENT, iq, fs, n, d, orc.prn_as_complex(chips[sv - 1], n)))
+            assert g["argmax"][si, bi] == int(np.argmax(ref)), (sv, d)
+            assert g["peak"][si, bi] == pytest.approx(ref.max(), rel=RTOL_MAG)
+            assert eng.cell_strength(g[si, bi:bi + 1])[0] == pytest.approx(orc.peak_strength(ref), rel=RTOL_MAG)
+    assert g["argmax"][0, 1] == s0.code_phase and g["peak"][0, 1] == g["peak"][0].max()
