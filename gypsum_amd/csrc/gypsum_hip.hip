@@ -469,6 +469,15 @@ int gyp_correlate_grid_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams,
         if (coh) hipLaunchKernelGGL((grid_fold_kernel<K, true>), fgrid, dim3(threads_for(K)), 0, ctx->stream, p);             \
         else hipLaunchKernelGGL((grid_fold_kernel<K, false>), fgrid, dim3(threads_for(K)), 0, ctx->stream, p);                \
         HIP_TRY(ctx, hipGetLastError());                                                                                      \
+        if (n_blk == 1 && K <= 8) { /* one wavefront per cell, no barriers */                                                \
+            const size_t lds = kTablesBytes + 8 * kXchWaveBytes;                                                               \
+            const int wgrid = std::max(1, std::min((n_cells + 7) / 8, ctx->n_cus * 2));                                        \
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(grid_cells_wave_kernel<K>),                         \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
+            hipLaunchKernelGGL(grid_cells_wave_kernel<K>, dim3(wgrid), dim3(512), lds, ctx->stream, p);                        \
+            HIP_TRY(ctx, hipGetLastError());                                                                                  \
+            return GYP_OK;                                                                                                    \
+        }                                                                                                                     \
         return coh ? launch_k(ctx, grid_cells_kernel<K, true>, K, grid, p, lds_bytes<K>())                                    \
                    : launch_k(ctx, grid_cells_kernel<K, false>, K, grid, p, lds_bytes<K>());                                  \
     }

@@ -422,6 +422,63 @@ __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void 
     }
 }
 
+// Single-block flat grid (n_ms == 1, or coherent): ONE wavefront per cell runs the K polyphase branches one after
+// the other, so cells never synchronise -- no workgroup barrier, no LDS reduction scratch; eight independent
+// wavefronts per workgroup only share the twiddle table.
+template <int K>
+__global__ __launch_bounds__(512, 4) void grid_cells_wave_kernel(GridParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cf* tw1024 = reinterpret_cast<cf*>(smem_raw);
+    cf* tiles = tw1024 + 1024;
+    for (int i = threadIdx.x; i < 1024; i += 512) tw1024[i] = p.tw_tables[i];
+    __syncthreads();
+    const int n_cells = p.n_streams * p.n_sats * p.n_bins;
+    const int tid = launder(threadIdx.x);
+    const int wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
+    float* tile_half = reinterpret_cast<float*>(tiles + wave * kXchWave) + h * kXchTile;
+    const LdsTables t{tw1024, p.tw_tables + 1024};
+    for (int v = blockIdx.x * 8 + wave; v < n_cells; v += gridDim.x * 8) {
+        // consecutive wavefronts of a workgroup take consecutive bins of one satellite: one replica, neighbouring inputs
+        const int cell = (n_cells & 7) ? v : xcd_contiguous(v >> 3, n_cells >> 3) * 8 + (v & 7);
+        const int bin = cell % p.n_bins, sat = (cell / p.n_bins) % p.n_sats, stream = cell / (p.n_bins * p.n_sats);
+        const cf* rep = replica_of(p.replica_table, p.sat_ids[sat] - 1);
+        const cf* unit = p.folded + (int64_t)(stream * p.n_bins + bin) * K * 1024;
+        LaneStats ls = lane_stats_init();
+#pragma unroll 1
+        for (int r = 0; r < K; ++r) {
+            const cf* yw = unit + (int64_t)r * 1024 + launder(l);
+            cf x[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) x[j] = yw[32 * j];
+            cf c[16];
+            wave_fft_fwd(x, tile_half, t, l, h);
+            spectrum_mul_from(x, rep, lane);
+            wave_fft_inv(x, c, tile_half, t, l, h);
+            const int base = K * (l + 512 * h) + r;          // lag index of slot j: base + 32*K*j
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const bool valid = slot_valid(j, tid);
+                const float m = __builtin_amdgcn_sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
+                const float vv = valid ? m : -1.0f;
+                const int key = base + 32 * K * j;
+                ls.sum += valid ? m : 0.0f;
+                const bool gt = vv > ls.b.v, eq = vv == ls.b.v;
+                ls.cnt = gt ? 1 : ls.cnt + (eq ? 1 : 0);
+                ls.b.key = (gt || (eq && key < ls.b.key)) ? key : ls.b.key;
+                ls.b.v = gt ? vv : ls.b.v;
+            }
+        }
+        const Best wb = wave_best(ls.b);
+        const int cnt = wave_sum(ls.b.v == wb.v ? ls.cnt : 0);
+        const double sum = wave_sum((double)ls.sum);
+        if (lane == 0) {
+            gyp_cell o;
+            o.peak = wb.v; o.argmax = wb.key; o.sum = sum; o.n_max = cnt; o.reserved = 0; o.tap_re = 0.f; o.tap_im = 0.f;
+            p.out[cell] = o;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // tracking, one explicit millisecond
 // ---------------------------------------------------------------------------------------------------------
