@@ -443,7 +443,11 @@ __global__ __launch_bounds__(512, 4) void grid_cells_wave_kernel(GridParams p) {
         const int bin = cell % p.n_bins, sat = (cell / p.n_bins) % p.n_sats, stream = cell / (p.n_bins * p.n_sats);
         const cf* rep = replica_of(p.replica_table, p.sat_ids[sat] - 1);
         const cf* unit = p.folded + (int64_t)(stream * p.n_bins + bin) * K * 1024;
-        LaneStats ls = lane_stats_init();
+        // running statistics are reduced over the wavefront after every branch and kept wave-uniform (scalar
+        // registers), so nothing but the transform lives in vector registers across a transform pair
+        Best wb{-1.0f, 0x7fffffff};
+        int cnt = 0;
+        double sum = 0.0;
 #pragma unroll 1
         for (int r = 0; r < K; ++r) {
             const cf* yw = unit + (int64_t)r * 1024 + launder(l);
@@ -455,6 +459,7 @@ __global__ __launch_bounds__(512, 4) void grid_cells_wave_kernel(GridParams p) {
             spectrum_mul_from(x, rep, lane);
             wave_fft_inv(x, c, tile_half, t, l, h);
             const int base = K * (l + 512 * h) + r;          // lag index of slot j: base + 32*K*j
+            LaneStats ls = lane_stats_init();
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const bool valid = slot_valid(j, tid);
@@ -467,10 +472,12 @@ __global__ __launch_bounds__(512, 4) void grid_cells_wave_kernel(GridParams p) {
                 ls.b.key = (gt || (eq && key < ls.b.key)) ? key : ls.b.key;
                 ls.b.v = gt ? vv : ls.b.v;
             }
+            const Best rb = wave_best(ls.b);
+            const int rc = wave_sum(ls.b.v == rb.v ? ls.cnt : 0);
+            sum += wave_sum((double)ls.sum);
+            if (rb.v > wb.v) { wb = rb; cnt = rc; }
+            else if (rb.v == wb.v) { cnt += rc; wb.key = rb.key < wb.key ? rb.key : wb.key; }
         }
-        const Best wb = wave_best(ls.b);
-        const int cnt = wave_sum(ls.b.v == wb.v ? ls.cnt : 0);
-        const double sum = wave_sum((double)ls.sum);
         if (lane == 0) {
             gyp_cell o;
             o.peak = wb.v; o.argmax = wb.key; o.sum = sum; o.n_max = cnt; o.reserved = 0; o.tap_re = 0.f; o.tap_im = 0.f;
