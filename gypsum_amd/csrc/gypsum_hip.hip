@@ -803,13 +803,13 @@ int gyp_debug_fft_bench(gyp_ctx* ctx, int waves_per_wg, int wgs, int iters, floa
     for (int rep = 0; rep < 2; ++rep) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         switch (waves_per_wg) {
-            case 1: hipFuncSetAttribute(reinterpret_cast<const void*>(fft_bench_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<1>());
+            case 1: HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fft_bench_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<1>()));
                     hipLaunchKernelGGL(fft_bench_kernel<1>, dim3(wgs), dim3(64), lds_bytes<1>(), ctx->stream, ctx->d_tw, ctx->d_replicas, iters, sink); break;
-            case 2: hipFuncSetAttribute(reinterpret_cast<const void*>(fft_bench_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<2>());
+            case 2: HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fft_bench_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<2>()));
                     hipLaunchKernelGGL(fft_bench_kernel<2>, dim3(wgs), dim3(128), lds_bytes<2>(), ctx->stream, ctx->d_tw, ctx->d_replicas, iters, sink); break;
-            case 4: hipFuncSetAttribute(reinterpret_cast<const void*>(fft_bench_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<4>());
+            case 4: HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fft_bench_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<4>()));
                     hipLaunchKernelGGL(fft_bench_kernel<4>, dim3(wgs), dim3(256), lds_bytes<4>(), ctx->stream, ctx->d_tw, ctx->d_replicas, iters, sink); break;
-            case 8: hipFuncSetAttribute(reinterpret_cast<const void*>(fft_bench_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<8>());
+            case 8: HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fft_bench_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<8>()));
                     hipLaunchKernelGGL(fft_bench_kernel<8>, dim3(wgs), dim3(512), lds_bytes<8>(), ctx->stream, ctx->d_tw, ctx->d_replicas, iters, sink); break;
             default: return fail(ctx, GYP_E_BAD_ARG, "waves_per_wg must be 1, 2, 4 or 8");
         }
