@@ -31,7 +31,15 @@ TRACK_REC = np.dtype([("peak_re", "<f4"), ("peak_im", "<f4"), ("strength", "<f4"
                       ("nudged", "i1"), ("reserved", "<i4")], align=True)
 SYNTH_SAT = np.dtype([("sat_id", "<i4"), ("code_phase", "<i4"), ("doppler_hz", "<f8"), ("carrier_phase", "<f8"),
                       ("amplitude", "<f4"), ("nav_bit_offset_ms", "<i4")], align=True)
-RECORD_SIZES = {"gyp_synth_sat": 32, "gyp_cell_desc": 24, "gyp_cell": 32, "gyp_acq_result": 32, "gyp_chan_in": 32, "gyp_chan_out": 48,
+BIT_EVENT = np.dtype([("receiver_timestamp", "<f8"), ("trailing_edge_receiver_timestamp", "<f8"), ("channel", "<i4"),
+                      ("bit_value", "<i4")], align=True)
+BITS_STATE = np.dtype([("determined_bit_phase", "<i4"), ("previous_bit_phase_decision", "<i4"),
+                       ("sequential_unknown_bit_value_counter", "<i4"), ("queued_pseudosymbols", "<i4"),
+                       ("pseudosymbol_cursor_within_queue", "<i8"), ("slide", "<i8"), ("failed_bit_count", "<i8"),
+                       ("emitted_bit_count", "<i8"), ("processed_pseudosymbol_count", "<i8"),
+                       ("last_emitted_bits_len", "<i4"), ("last_emitted_bits", "i1", (52,))], align=True)
+GYP_BIT_ZERO, GYP_BIT_ONE, GYP_BIT_UNKNOWN = 0, 1, 2
+RECORD_SIZES = {"gyp_bit_event": 24, "gyp_bits_state": 112, "gyp_synth_sat": 32, "gyp_cell_desc": 24, "gyp_cell": 32, "gyp_acq_result": 32, "gyp_chan_in": 32, "gyp_chan_out": 48,
                 "gyp_track_rec": 56}
 
 EXPORTS = (
@@ -40,7 +48,8 @@ EXPORTS = (
     "gyp_memcpy_h2d gyp_memcpy_d2h gyp_cell_strength gyp_correlate_cells_dev gyp_correlate_cells gyp_correlate_grid_dev "
     "gyp_correlate_grid gyp_acquire_dev "
     "gyp_acquire gyp_track_step_dev gyp_track_step gyp_bank_create gyp_bank_destroy gyp_bank_size "
-    "gyp_track_block_dev gyp_track_block gyp_bank_get_state gyp_synth_iq_dev gyp_synth_nav_bit gyp_bank_reset_dev gyp_debug_track_profile gyp_debug_fft_bench"
+    "gyp_track_block_dev gyp_track_block gyp_bank_get_state gyp_synth_iq_dev gyp_synth_nav_bit gyp_bank_reset_dev gyp_debug_track_profile gyp_debug_fft_bench "
+    "gyp_bits_create gyp_bits_destroy gyp_bits_reset gyp_bits_push gyp_bits_push_block gyp_bits_drain gyp_bits_get_state"
 ).split()
 
 
@@ -101,6 +110,13 @@ def load() -> C.CDLL:
         "gyp_debug_fft_bench": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
         "gyp_synth_iq_dev": (C.c_int, [vp, vp, i32, i64, i32, vp, i32, C.c_float, u64]),
         "gyp_synth_nav_bit": (C.c_int, [u64, i32, i32, i32, i64]),
+        "gyp_bits_create": (C.c_int, [i32, C.POINTER(vp)]),
+        "gyp_bits_destroy": (None, [vp]),
+        "gyp_bits_reset": (C.c_int, [vp, i32]),
+        "gyp_bits_push": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, C.POINTER(i32)]),
+        "gyp_bits_push_block": (C.c_int, [vp, vp, i32, i32, vp, vp, vp, i32, C.POINTER(i32)]),
+        "gyp_bits_drain": (C.c_int, [vp, vp, i32, C.POINTER(i32)]),
+        "gyp_bits_get_state": (C.c_int, [vp, i32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # AttributeError here == the library does not export what the header declares

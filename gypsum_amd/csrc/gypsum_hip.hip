@@ -8,11 +8,13 @@
 #include <complex>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
 #include "../../include/gypsum_hip.h"
 #include "kernels.hpp"
+#include "bit_integrator.hpp"
 
 using namespace gyp;
 
@@ -823,6 +825,135 @@ int gyp_debug_fft_bench(gyp_ctx* ctx, int waves_per_wg, int wgs, int iters, floa
 
 int gyp_synth_nav_bit(uint64_t seed, int32_t stream, int32_t sat_id, int32_t nav_bit_offset_ms, int64_t ms) {
     return synth_nav_bit(seed, stream, sat_id, nav_bit_offset_ms, ms);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// navigation bits (host only)
+// ---------------------------------------------------------------------------------------------------------
+struct gyp_bits {
+    std::vector<gyp_bits_impl::Channel> chans;
+    std::deque<gyp_bit_event> fifo;
+};
+
+static int bits_take(gyp_bits* b, gyp_bit_event* out, int32_t cap, int32_t* n_out) {
+    int32_t n = 0;
+    if (out)
+        while (n < cap && !b->fifo.empty()) {
+            out[n++] = b->fifo.front();
+            b->fifo.pop_front();
+        }
+    if (n_out) *n_out = n;
+    return GYP_OK;
+}
+
+extern "C" {
+
+int gyp_bits_create(int32_t n_channels, gyp_bits** out) {
+    if (!out) return fail(nullptr, GYP_E_BAD_ARG, "gyp_bits_create: out is NULL");
+    *out = nullptr;
+    if (n_channels <= 0) return fail(nullptr, GYP_E_BAD_ARG, "gyp_bits_create: n_channels must be positive");
+    gyp_bits* b = new (std::nothrow) gyp_bits();
+    if (!b) return fail(nullptr, GYP_E_NOMEM, "gyp_bits_create: out of memory");
+    b->chans.resize(n_channels);
+    *out = b;
+    return GYP_OK;
+}
+
+void gyp_bits_destroy(gyp_bits* bits) { delete bits; }
+
+int gyp_bits_reset(gyp_bits* bits, int32_t channel) {
+    if (!bits) return fail(nullptr, GYP_E_BAD_ARG, "gyp_bits_reset: bits is NULL");
+    if (channel < -1 || channel >= (int32_t)bits->chans.size())
+        return fail(nullptr, GYP_E_BAD_ARG, "gyp_bits_reset: channel out of range");
+    for (int32_t c = 0; c < (int32_t)bits->chans.size(); ++c)
+        if (channel < 0 || c == channel) bits->chans[c].reset();
+    return GYP_OK;
+}
+
+int gyp_bits_push(gyp_bits* bits, int32_t channel, int32_t n, const double* receiver_timestamp,
+                  const double* start_of_pseudosymbol, const double* end_of_pseudosymbol,
+                  const int8_t* pseudosymbol, int32_t* cursor_at_emit_out, gyp_bit_event* events_out,
+                  int32_t capacity, int32_t* n_events_out) {
+    if (n_events_out) *n_events_out = 0;
+    if (!bits) return fail(nullptr, GYP_E_BAD_ARG, "gyp_bits_push: bits is NULL");
+    if (channel < 0 || channel >= (int32_t)bits->chans.size())
+        return fail(nullptr, GYP_E_BAD_ARG, "gyp_bits_push: channel out of range");
+    if (n < 0 || capacity < 0 || (n > 0 && (!receiver_timestamp || !start_of_pseudosymbol || !end_of_pseudosymbol || !pseudosymbol)))
+        return fail(nullptr, GYP_E_BAD_ARG, "gyp_bits_push: bad arguments");
+    for (int32_t i = 0; i < n; ++i)   // NavigationBitPseudosymbol.from_val raises KeyError on anything else
+        if (pseudosymbol[i] != 1 && pseudosymbol[i] != -1)
+            return fail(nullptr, GYP_E_BAD_ARG, "gyp_bits_push: pseudosymbol " + std::to_string(i) + " is not -1/+1");
+    gyp_bits_impl::Channel& ch = bits->chans[channel];
+    auto sink = [&](const gyp_bits_impl::BitOut& o) {
+        bits->fifo.push_back(gyp_bit_event{o.start, o.end, channel, o.bit});
+    };
+    for (int32_t i = 0; i < n; ++i) {
+        const int64_t at = ch.process(receiver_timestamp[i],
+                                      gyp_bits_impl::Symbol{start_of_pseudosymbol[i], end_of_pseudosymbol[i], pseudosymbol[i]}, sink);
+        if (cursor_at_emit_out) cursor_at_emit_out[i] = (int32_t)at;
+    }
+    return bits_take(bits, events_out, capacity, n_events_out);
+}
+
+int gyp_bits_push_block(gyp_bits* bits, const gyp_track_rec* recs_host, int32_t n_chan, int32_t n_ms,
+                        const double* start_time, const double* end_time, gyp_bit_event* events_out,
+                        int32_t capacity, int32_t* n_events_out) {
+    if (n_events_out) *n_events_out = 0;
+    if (!bits) return fail(nullptr, GYP_E_BAD_ARG, "gyp_bits_push_block: bits is NULL");
+    if (n_chan < 0 || n_chan > (int32_t)bits->chans.size() || n_ms < 0 || capacity < 0)
+        return fail(nullptr, GYP_E_BAD_ARG, "gyp_bits_push_block: bad sizes");
+    if (n_chan * (int64_t)n_ms > 0 && (!recs_host || !start_time || !end_time))
+        return fail(nullptr, GYP_E_BAD_ARG, "gyp_bits_push_block: NULL input");
+    std::vector<int32_t> live_ms(n_chan, n_ms);   // first ms with status != 0, per channel
+    for (int32_t c = 0; c < n_chan; ++c)
+        for (int32_t t = 0; t < n_ms; ++t) {
+            const gyp_track_rec& r = recs_host[(size_t)c * n_ms + t];
+            if (r.status != 0) { live_ms[c] = t; break; }
+            if (r.pseudosymbol != 1 && r.pseudosymbol != -1)
+                return fail(nullptr, GYP_E_BAD_ARG, "gyp_bits_push_block: channel " + std::to_string(c) + " ms " +
+                                                        std::to_string(t) + ": pseudosymbol is not -1/+1");
+        }
+    for (int32_t t = 0; t < n_ms; ++t)
+        for (int32_t c = 0; c < n_chan; ++c) {
+            if (t >= live_ms[c]) continue;
+            const gyp_track_rec& r = recs_host[(size_t)c * n_ms + t];
+            // tracker.py:319-326: the pseudosymbol's edges are the chunk's plus the code-phase delay
+            const double delay = (static_cast<double>(r.code_phase) / 2046.0) * 0.001;
+            bits->chans[c].process(start_time[t], gyp_bits_impl::Symbol{start_time[t] + delay, end_time[t] + delay, r.pseudosymbol},
+                                   [&](const gyp_bits_impl::BitOut& o) {
+                                       bits->fifo.push_back(gyp_bit_event{o.start, o.end, c, o.bit});
+                                   });
+        }
+    return bits_take(bits, events_out, capacity, n_events_out);
+}
+
+int gyp_bits_drain(gyp_bits* bits, gyp_bit_event* events_out, int32_t capacity, int32_t* n_events_out) {
+    if (n_events_out) *n_events_out = 0;
+    if (!bits || capacity < 0) return fail(nullptr, GYP_E_BAD_ARG, "gyp_bits_drain: bad arguments");
+    return bits_take(bits, events_out, capacity, n_events_out);
+}
+
+int gyp_bits_get_state(const gyp_bits* bits, int32_t channel, gyp_bits_state* out) {
+    if (!bits || !out) return fail(nullptr, GYP_E_BAD_ARG, "gyp_bits_get_state: NULL argument");
+    if (channel < 0 || channel >= (int32_t)bits->chans.size())
+        return fail(nullptr, GYP_E_BAD_ARG, "gyp_bits_get_state: channel out of range");
+    const gyp_bits_impl::Channel& ch = bits->chans[channel];
+    std::memset(out, 0, sizeof(*out));
+    out->determined_bit_phase = ch.determined_bit_phase;
+    out->previous_bit_phase_decision = ch.previous_bit_phase_decision;
+    out->sequential_unknown_bit_value_counter = ch.sequential_unknown;
+    out->queued_pseudosymbols = (int32_t)ch.queue.size();
+    out->pseudosymbol_cursor_within_queue = ch.cursor;
+    out->slide = ch.slide;
+    out->failed_bit_count = ch.failed_bit_count;
+    out->emitted_bit_count = ch.emitted_bit_count;
+    out->processed_pseudosymbol_count = ch.processed;
+    out->last_emitted_bits_len = ch.bits_len;
+    for (int i = 0; i < ch.bits_len; ++i)
+        out->last_emitted_bits[i] = ch.bits[(ch.bits_head + i) % gyp_bits_impl::kBitHistory];
+    return GYP_OK;
 }
 
 }  // extern "C"

@@ -2,9 +2,11 @@
 
 The reference's module needs Python 3.11 and pulls in the navigation-message decoder and the matplotlib
 visualizer, which are outside this engine's scope.  This shim keeps the constructor and
-`process_samples(chunk) -> list[Event]` contract around the GPU tracker; the bit integrator / message decoder are
-plug-ins: anything with the reference's `process_pseudosymbol(receiver_timestamp, pseudosymbol) -> list[Event]`
-(e.g. the reference's own NavigationBitIntegrator) can be passed in, and its events are returned unchanged.
+`process_samples(chunk) -> list[Event]` contract around the GPU tracker and feeds the pseudosymbols to the native
+bit integrator (`gypsum_amd.navigation_bit_intergrator`, pipeline.py:70,79), returning its EmitNavigationBitEvents.
+The integrator is replaceable: anything with the reference's `process_pseudosymbol(receiver_timestamp,
+pseudosymbol) -> list[Event]` (e.g. the reference's own NavigationBitIntegrator) can be passed in; `None` disables it.
+The message decoder stays a consumer of the returned events.
 """
 from __future__ import annotations
 
@@ -13,6 +15,7 @@ from typing import Any, Callable, List, Optional
 
 from .acquisition import SatelliteAcquisitionAttemptResult
 from .antenna_sample_provider import AntennaSampleChunk, SampleProviderAttributes
+from .navigation_bit_intergrator import NavigationBitIntegrator
 from .tracker import EmittedPseudosymbol, GpsSatelliteTracker, GpsSatelliteTrackingParameters, LostSatelliteLockError  # noqa: F401
 
 
@@ -24,7 +27,7 @@ class TrackingState(Enum):
 class GpsSatelliteSignalProcessingPipeline:
     def __init__(self, satellite: Any, acquisition_result: SatelliteAcquisitionAttemptResult,
                  stream_attributes: SampleProviderAttributes, should_present_matplotlib_satellite_tracker: bool = False,
-                 should_present_web_ui: bool = False, pseudosymbol_integrator: Any = None,
+                 should_present_web_ui: bool = False, pseudosymbol_integrator: Any = "native",
                  tracker_factory: Optional[Callable[..., Any]] = None) -> None:
         self.satellite = satellite
         self.state = TrackingState.PROVISIONAL_PROBE
@@ -36,6 +39,8 @@ class GpsSatelliteSignalProcessingPipeline:
             doppler_shifts=[],
         )
         self.tracker = (tracker_factory or GpsSatelliteTracker)(tracking_params, stream_attributes)
+        if isinstance(pseudosymbol_integrator, str) and pseudosymbol_integrator == "native":
+            pseudosymbol_integrator = NavigationBitIntegrator(getattr(satellite, "satellite_id", satellite))   # pipeline.py:70
         self.pseudosymbol_integrator = pseudosymbol_integrator
         self.emitted_pseudosymbols: List[EmittedPseudosymbol] = []
 

@@ -254,6 +254,64 @@ int gyp_synth_iq_dev(gyp_ctx* ctx, float* out_dev, int32_t n_streams, int64_t st
 /* +-1 data bit satellite `sat_id` of stream `stream` carries during millisecond `ms` (host mirror of the kernel). */
 int gyp_synth_nav_bit(uint64_t seed, int32_t stream, int32_t sat_id, int32_t nav_bit_offset_ms, int64_t ms);
 
+/* ---------------------------------------------------------------- navigation bits (host) -------------- */
+/* SURVEY.md 8 f4.  Host-side replacement for gypsum/navigation_bit_intergrator.py:100-288
+ * NavigationBitIntegrator: one integrator per tracking channel, fed the 1 kHz pseudosymbols, emitting the
+ * 50 bit/s EmitNavigationBitEvent stream with the reference's bit-phase selection / resynchronisation rules.
+ * No GPU involved; errors are reported through gyp_last_error(NULL). */
+typedef struct gyp_bits gyp_bits;
+
+#define GYP_BIT_ZERO 0      /* tracker.py:48-51 BitValue.ZERO */
+#define GYP_BIT_ONE 1       /* BitValue.ONE */
+#define GYP_BIT_UNKNOWN 2   /* BitValue.UNKNOWN */
+
+/* navigation_bit_intergrator.py:29-39 EmitNavigationBitEvent */
+typedef struct gyp_bit_event {
+    double receiver_timestamp;                 /* start_of_pseudosymbol of the bit's first pseudosymbol */
+    double trailing_edge_receiver_timestamp;   /* end_of_pseudosymbol of its last pseudosymbol */
+    int32_t channel;
+    int32_t bit_value;                         /* GYP_BIT_* */
+} gyp_bit_event;
+
+/* navigation_bit_intergrator.py:55-74 NavigationBitIntegratorHistory scalars (+ NavigationBitIntegrator.slide) */
+typedef struct gyp_bits_state {
+    int32_t determined_bit_phase;          /* -1 = None */
+    int32_t previous_bit_phase_decision;   /* -1 = None */
+    int32_t sequential_unknown_bit_value_counter;
+    int32_t queued_pseudosymbols;          /* len(queued_pseudosymbols) */
+    int64_t pseudosymbol_cursor_within_queue;
+    int64_t slide;
+    int64_t failed_bit_count;
+    int64_t emitted_bit_count;
+    int64_t processed_pseudosymbol_count;
+    int32_t last_emitted_bits_len;         /* <= 50 */
+    int8_t last_emitted_bits[52];          /* oldest first, GYP_BIT_* */
+} gyp_bits_state;
+
+int gyp_bits_create(int32_t n_channels, gyp_bits** out);
+void gyp_bits_destroy(gyp_bits* bits);
+int gyp_bits_reset(gyp_bits* bits, int32_t channel /* -1 = every channel */);
+/* process_pseudosymbol (:267-288) for `n` consecutive pseudosymbols of one channel.  receiver_timestamp[i] is the
+ * chunk.start_time the pipeline passes (pipeline.py:79); start/end are EmittedPseudosymbol.start_of_pseudosymbol /
+ * end_of_pseudosymbol; pseudosymbol[i] is -1 or +1.  cursor_at_emit_out (may be NULL) receives the value the
+ * reference stores into EmittedPseudosymbol.cursor_at_emit_time.  Emitted bits are appended to an internal FIFO;
+ * up to `capacity` of them are moved to events_out (n_events_out = how many), the rest wait for gyp_bits_drain. */
+int gyp_bits_push(gyp_bits* bits, int32_t channel, int32_t n, const double* receiver_timestamp,
+                  const double* start_of_pseudosymbol, const double* end_of_pseudosymbol,
+                  const int8_t* pseudosymbol, int32_t* cursor_at_emit_out, gyp_bit_event* events_out,
+                  int32_t capacity, int32_t* n_events_out);
+/* The same for a whole gyp_track_block output: recs_host is n_chan x n_ms (channel-major), channel c feeds
+ * integrator c, visited millisecond by millisecond in channel order like receiver.py:244-247 visits its pipelines.
+ * A channel stops being fed at its first record with status != 0 (the tracker raised LostSatelliteLockError before
+ * the integrator saw that pseudosymbol).  start_time/end_time: n_ms chunk timestamps shared by all channels; each
+ * pseudosymbol's edges are those plus (code_phase / 2046) ms as in tracker.py:319-326, and the chunk start is the
+ * receiver timestamp (pipeline.py:79). */
+int gyp_bits_push_block(gyp_bits* bits, const gyp_track_rec* recs_host, int32_t n_chan, int32_t n_ms,
+                        const double* start_time, const double* end_time, gyp_bit_event* events_out,
+                        int32_t capacity, int32_t* n_events_out);
+int gyp_bits_drain(gyp_bits* bits, gyp_bit_event* events_out, int32_t capacity, int32_t* n_events_out);
+int gyp_bits_get_state(const gyp_bits* bits, int32_t channel, gyp_bits_state* out);
+
 /* Debug: per-phase shader-cycle counters of workgroup 0 of gyp_track_block_dev (correlate, reduce, loop update,
  * barrier, ms count).  enable != 0 arms it; out8 (may be NULL) receives the counters of the last launch. */
 int gyp_debug_track_profile(gyp_ctx* ctx, int enable, long long* out8);

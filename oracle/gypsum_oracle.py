@@ -441,3 +441,122 @@ class Tracker:
 def chunk_times(cursor_samples: int, n: int, fs: int) -> Tuple[float, float]:
     """start/end receiver timestamps of the 1-ms chunk at `cursor_samples`: round(cursor/fs, 6)."""
     return round(cursor_samples / fs, 6), round((cursor_samples + n) / fs, 6)
+
+
+# --------------------------------------------------------------------------
+# f4 -- navigation bit integrator (navigation_bit_intergrator.py:100-288)
+# --------------------------------------------------------------------------
+SYMBOLS_PER_BIT = 20                       # constants.py:25
+BIT_UNKNOWN, BIT_ZERO, BIT_ONE = 2, 0, 1   # tracker.py:48-51 BitValue, coded like include/gypsum_hip.h GYP_BIT_*
+BIT_RESYNC_PERIOD = 1000 * 1               # navigation_bit_intergrator.py:106 with config.py:40
+BIT_HEALTH_MEMORY = 10                     # config.py:43
+BIT_HEALTH_THRESHOLD_PERCENT = 50          # config.py:45
+BIT_RESYNC_DEADLINE_S = 40                 # navigation_bit_intergrator.py:276
+
+
+class BitIntegrator:
+    """Pseudosymbols (+-1 per ms) -> navigation bits, decision for decision as the reference's
+    NavigationBitIntegrator.  Events are (first symbol start, last symbol end, bit code) tuples."""
+
+    def __init__(self) -> None:
+        self.last_seen: Deque[int] = collections.deque(maxlen=1000)          # :85
+        self.last_bits: Deque[int] = collections.deque(maxlen=50)            # :87
+        self.previous_bit_phase_decision: Optional[int] = None
+        self.determined_bit_phase: Optional[int] = None
+        self.failed_bit_count = 0
+        self.emitted_bit_count = 0
+        self.processed = 0
+        self.sequential_unknown = 0
+        self.queued: List[Tuple[float, float, int]] = []
+        self.cursor = 0
+        self.slide = 0
+
+    @staticmethod
+    def confidence(symbols: Sequence[int]) -> float:
+        """_compute_bit_confidence_score, :111-127 (full 20-symbol groups only, utils.py:28-38)."""
+        sums = [sum(symbols[i:i + SYMBOLS_PER_BIT]) for i in range(0, len(symbols), SYMBOLS_PER_BIT)
+                if len(symbols) - i >= SYMBOLS_PER_BIT]
+        strength = sum(abs(x) for x in sums) / (len(symbols) / SYMBOLS_PER_BIT)
+        return strength / SYMBOLS_PER_BIT
+
+    def redetermine_bit_phase(self) -> Optional[int]:
+        """:129-147 -- best of the 20 alignments over the last (up to) 320 pseudosymbols; first maximum wins."""
+        if len(self.last_seen) < SYMBOLS_PER_BIT * 4:
+            return None
+        window = np.array(list(self.last_seen)[-SYMBOLS_PER_BIT * 16:])
+        scores = [self.confidence([int(v) for v in np.roll(window, -p)]) for p in range(SYMBOLS_PER_BIT)]
+        return max(range(SYMBOLS_PER_BIT), key=lambda p: scores[p])
+
+    def should_resynchronize(self) -> bool:
+        """:213-243"""
+        if self.processed % BIT_RESYNC_PERIOD == 0:
+            return True
+        if self.processed % SYMBOLS_PER_BIT != 0:
+            return False
+        if self.previous_bit_phase_decision is None:
+            return True
+        recent = list(self.last_bits)[-BIT_HEALTH_MEMORY:]
+        if len(recent) == BIT_HEALTH_MEMORY:
+            if recent.count(BIT_UNKNOWN) / len(recent) * 100 >= BIT_HEALTH_THRESHOLD_PERCENT:
+                return True
+        return False
+
+    def resynchronize_if_necessary(self) -> None:
+        """:245-277"""
+        if not self.should_resynchronize():
+            return
+        previous, new = self.previous_bit_phase_decision, self.redetermine_bit_phase()
+        self.previous_bit_phase_decision = new
+        self.determined_bit_phase = new
+        if previous is None and new is not None:
+            if new > 0:
+                self.cursor = new
+                self.slide = new
+        elif previous is not None and new is not None and previous != new:
+            self.slide += new - previous
+            self.cursor += new - previous
+
+    def emit_bit(self, group: Sequence[Tuple[float, float, int]]) -> Tuple[float, float, int]:
+        """:149-193"""
+        total = sum(v for _, _, v in group)
+        bit = BIT_ONE if total > 0 else BIT_ZERO
+        if abs(int((total / len(group)) * 100)) <= 50:
+            bit = BIT_UNKNOWN
+        self.last_bits.append(bit)
+        if bit == BIT_UNKNOWN:
+            self.sequential_unknown += 1
+            self.failed_bit_count += 1
+            if self.sequential_unknown >= 30:
+                self.determined_bit_phase = None
+        else:
+            self.sequential_unknown = 0
+        return group[0][0], group[-1][1], bit
+
+    def emit_from_queue(self) -> List[Tuple[float, float, int]]:
+        """:195-211 (Python slice semantics of a negative cursor included)."""
+        if self.determined_bit_phase is None:
+            return []
+        events = []
+        pending = self.queued[self.cursor:]
+        for i in range(0, len(pending), SYMBOLS_PER_BIT):
+            if len(pending) - i < SYMBOLS_PER_BIT:
+                break
+            events.append(self.emit_bit(pending[i:i + SYMBOLS_PER_BIT]))
+            self.cursor += SYMBOLS_PER_BIT
+            self.emitted_bit_count += 1
+        if len(self.queued) >= SYMBOLS_PER_BIT:
+            offset_from_end = len(self.queued) - self.cursor
+            self.queued = self.queued[-SYMBOLS_PER_BIT:]
+            self.cursor = SYMBOLS_PER_BIT - offset_from_end
+        return events
+
+    def process(self, receiver_timestamp: float, start: float, end: float, value: int) -> Tuple[int, List[Tuple[float, float, int]]]:
+        """process_pseudosymbol, :267-288.  Returns (cursor_at_emit_time, events)."""
+        cursor_at_emit = self.slide
+        self.queued.append((start, end, value))
+        self.last_seen.append(value)
+        if receiver_timestamp < BIT_RESYNC_DEADLINE_S:
+            self.resynchronize_if_necessary()
+        events = self.emit_from_queue()
+        self.processed += 1
+        return cursor_at_emit, events

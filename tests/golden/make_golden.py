@@ -182,8 +182,43 @@ def make_tracking(tag: str, fs: int, seed: int, n_ms: int, n_track: int, n_sats:
     np.savez_compressed(HERE / f"track_{tag}.npz", **out)
 
 
+def make_bits() -> None:
+    """Reference NavigationBitIntegrator (navigation_bit_intergrator.py:100-288) on the streams of
+    tests/bits_scenarios.py: emitted bits, every pseudosymbol's cursor_at_emit_time, the final history scalars."""
+    sys.path.insert(0, str(REPO / "tests"))
+    import bits_scenarios
+    from gypsum.navigation_bit_intergrator import NavigationBitIntegrator
+    from gypsum.tracker import BitValue, EmittedPseudosymbol, NavigationBitPseudosymbol
+    code = {BitValue.ZERO: 0, BitValue.ONE: 1, BitValue.UNKNOWN: 2}
+    out = {}
+    for name, sc in bits_scenarios.scenarios().items():
+        integ = NavigationBitIntegrator(GpsSatelliteId(1))
+        events, cursors = [], []
+        for v, st, en in zip(sc["symbols"], sc["start"], sc["end"]):
+            ps = EmittedPseudosymbol(start_of_pseudosymbol=float(st), end_of_pseudosymbol=float(en),
+                                     pseudosymbol=NavigationBitPseudosymbol.from_val(int(v)), cursor_at_emit_time=0)
+            for e in integ.process_pseudosymbol(float(st), ps):
+                events.append((e.receiver_timestamp, e.trailing_edge_receiver_timestamp, code[e.bit_value], len(cursors)))
+            cursors.append(ps.cursor_at_emit_time)
+        h = integ.history
+        none = lambda v: -1 if v is None else v
+        state = [none(h.determined_bit_phase), none(h.previous_bit_phase_decision), h.failed_bit_count,
+                 h.emitted_bit_count, h.processed_pseudosymbol_count, h.sequential_unknown_bit_value_counter,
+                 h.pseudosymbol_cursor_within_queue, integ.slide, len(h.queued_pseudosymbols)]
+        out[f"{name}__symbols"] = sc["symbols"]
+        out[f"{name}__start"] = sc["start"]
+        out[f"{name}__end"] = sc["end"]
+        out[f"{name}__events"] = np.array(events, dtype=np.float64).reshape(-1, 4)
+        out[f"{name}__cursors"] = np.array(cursors, dtype=np.int64)
+        out[f"{name}__state"] = np.array(state, dtype=np.int64)
+        out[f"{name}__last_bits"] = np.array([code[b] for b in h.last_emitted_bits], dtype=np.int8)
+        ev = out[f"{name}__events"]
+        print("bits", name, "events", len(ev), "unknown", int((ev[:, 2] == 2).sum()) if len(ev) else 0, "state", state)
+    np.savez_compressed(HERE / "bits.npz", **out)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["prn", "grid", "acq", "track", "lock", "long"]
+    what = sys.argv[1:] or ["prn", "grid", "acq", "track", "lock", "long", "bits"]
     if "prn" in what:
         make_prn()
     if "grid" in what:
@@ -199,3 +234,5 @@ if __name__ == "__main__":
     if "long" in what:
         make_tracking("2046_long", 2_046_000, 20260930, 6600, 4, n_sats=4, noise_sigma=0.02,
                       doppler_offsets=(0, 0, 250, 40))
+    if "bits" in what:
+        make_bits()

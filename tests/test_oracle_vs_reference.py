@@ -88,3 +88,42 @@ def test_acquisition_and_tracking_closed_loop(ref):
         assert rec.pseudosymbol == ps.pseudosymbol.as_val()
         assert rec.start_of_pseudosymbol == ps.start_of_pseudosymbol
         assert ot.s.is_locked() == params.is_locked()
+
+
+def test_bit_integrator_fuzz(ref):
+    """Random bit streams with flips, slips and junk: reference, oracle and the native integrator agree event for event."""
+    from gypsum.navigation_bit_intergrator import NavigationBitIntegrator
+    from gypsum_amd import _lib
+    from gypsum_amd.navigation_bit_intergrator import NavigationBitIntegratorBank
+    from oracle import gypsum_oracle as orc
+
+    rng = np.random.default_rng(77)
+    trk = ref["trk"]
+    code = {trk.BitValue.ZERO: 0, trk.BitValue.ONE: 1, trk.BitValue.UNKNOWN: 2}
+    for case in range(12):
+        n_ms = int(rng.integers(200, 4000))
+        bits = rng.integers(0, 2, n_ms // 20 + 3) * 2 - 1
+        sym = np.repeat(bits, 20)[int(rng.integers(0, 20)):][:n_ms].astype(np.int8)
+        sym = np.where(rng.random(n_ms) < rng.choice([0.0, 0.05, 0.2, 0.4]), -sym, sym)
+        for _ in range(int(rng.integers(0, 4))):                     # slips: drop or repeat a few symbols
+            at, k = int(rng.integers(100, n_ms - 30)), int(rng.integers(1, 19))
+            sym = np.concatenate([sym[:at], sym[at + k:]]) if rng.random() < 0.5 else np.concatenate([sym[:at], sym[at - k:]])
+        t0 = float(rng.choice([0.0, 37.5, 39.9]))
+        start = np.round(t0 + np.arange(len(sym)) / 1000, 6)
+        end = np.round(t0 + (np.arange(len(sym)) + 1) / 1000, 6)
+        r = NavigationBitIntegrator(ref["codes"].GpsSatelliteId(1))
+        o = orc.BitIntegrator()
+        want, got_o = [], []
+        for v, st, en in zip(sym, start, end):
+            ps = trk.EmittedPseudosymbol(float(st), float(en), trk.NavigationBitPseudosymbol.from_val(int(v)), 0)
+            want += [(e.receiver_timestamp, e.trailing_edge_receiver_timestamp, code[e.bit_value])
+                     for e in r.process_pseudosymbol(float(st), ps)]
+            at, ev = o.process(float(st), float(st), float(en), int(v))
+            assert at == ps.cursor_at_emit_time
+            got_o += ev
+        assert got_o == want, case
+        recs = np.zeros((1, len(sym)), dtype=_lib.TRACK_REC)
+        recs["pseudosymbol"] = sym
+        ev = NavigationBitIntegratorBank(1).push_block(recs, start, end)
+        got_n = list(zip(ev["receiver_timestamp"].tolist(), ev["trailing_edge_receiver_timestamp"].tolist(), ev["bit_value"].tolist()))
+        assert got_n == want, case
