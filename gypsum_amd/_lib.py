@@ -9,7 +9,8 @@ import numpy as np
 LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libgypsum_hip.so"
 
 GYP_OK = 0
-GYP_E_BAD_ARG, GYP_E_BAD_RATE, GYP_E_NO_DEVICE, GYP_E_HIP, GYP_E_NO_FORMAT, GYP_E_NOMEM = -1, -2, -3, -4, -5, -6
+GYP_E_BAD_ARG, GYP_E_BAD_RATE, GYP_E_NO_DEVICE, GYP_E_HIP, GYP_E_NO_FORMAT, GYP_E_NOMEM, GYP_E_IO = -1, -2, -3, -4, -5, -6, -7
+GYP_FMT_F32, GYP_FMT_I8, GYP_FMT_I16, GYP_FMT_U8 = 0, 1, 2, 3
 GYP_COHERENT, GYP_NON_COHERENT = 0, 1
 
 # numpy mirrors of the C records (layouts asserted against the header in tests/test_abi.py)
@@ -49,7 +50,8 @@ EXPORTS = (
     "gyp_correlate_grid gyp_acquire_dev "
     "gyp_acquire gyp_track_step_dev gyp_track_step gyp_bank_create gyp_bank_destroy gyp_bank_size "
     "gyp_track_block_dev gyp_track_block gyp_bank_get_state gyp_synth_iq_dev gyp_synth_nav_bit gyp_bank_reset_dev gyp_debug_track_profile gyp_debug_fft_bench "
-    "gyp_bits_create gyp_bits_destroy gyp_bits_reset gyp_bits_push gyp_bits_push_block gyp_bits_drain gyp_bits_get_state"
+    "gyp_bits_create gyp_bits_destroy gyp_bits_reset gyp_bits_push gyp_bits_push_block gyp_bits_drain gyp_bits_get_state "
+    "gyp_ingest_open gyp_ingest_close gyp_ingest_total_ms gyp_ingest_seek gyp_ingest_next_host gyp_ingest_next_dev gyp_ingest_times"
 ).split()
 
 
@@ -117,6 +119,13 @@ def load() -> C.CDLL:
         "gyp_bits_push_block": (C.c_int, [vp, vp, i32, i32, vp, vp, vp, i32, C.POINTER(i32)]),
         "gyp_bits_drain": (C.c_int, [vp, vp, i32, C.POINTER(i32)]),
         "gyp_bits_get_state": (C.c_int, [vp, i32, vp]),
+        "gyp_ingest_open": (C.c_int, [vp, C.c_char_p, i32, i64, i32, i32, i32, C.POINTER(vp)]),
+        "gyp_ingest_close": (None, [vp]),
+        "gyp_ingest_total_ms": (i64, [vp]),
+        "gyp_ingest_seek": (C.c_int, [vp, i64]),
+        "gyp_ingest_next_host": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(i32)]),
+        "gyp_ingest_next_dev": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(i32)]),
+        "gyp_ingest_times": (C.c_int, [vp, i64, i32, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # AttributeError here == the library does not export what the header declares

@@ -73,16 +73,42 @@ class _CursorProvider(AntennaSampleProvider):
 
 
 class AntennaSampleProviderBackedByFile(_CursorProvider):
-    """GNU Radio recording: interleaved float32 I/Q (antenna_sample_provider.py:79-136)."""
+    """GNU Radio recording: interleaved float32 I/Q (antenna_sample_provider.py:79-136).
+
+    `block_ms > 0` serves the usual one-millisecond chunks out of blocks read by the native reader thread
+    (`gypsum_amd.ingest.IqFileIngest`, host-only mode) instead of opening the file and `np.fromfile`-ing it for
+    every millisecond (:112-117); chunks, timestamps and the end-of-data condition are unchanged."""
 
     def __init__(self, path: Path | str, sample_rate: float, utc_start_time: float = 0.0,
-                 sample_component_data_type=np.float32) -> None:
+                 sample_component_data_type=np.float32, block_ms: int = 0) -> None:
         self.path = Path(path)
         self.cursor = 0
         self.sample_rate = sample_rate
         self.utc_start_time = utc_start_time
         self.sample_component_data_type = sample_component_data_type
         self.file_size_in_bytes = self.path.stat().st_size
+        self._reader = None
+        self._block_first_ms = 0
+        self._block: np.ndarray | None = None
+        if block_ms > 0:
+            from .ingest import IqFileIngest
+            self._reader = IqFileIngest(self.path, int(sample_rate), sample_component_data_type, block_ms=block_ms)
+
+    def _words_from_reader(self, sample_count: int) -> np.ndarray | None:
+        n = self._reader.n
+        if sample_count != n or self.cursor % n:
+            return None                              # not a whole aligned millisecond: use the plain path
+        ms = self.cursor // n
+        if ms >= self._reader.total_ms:
+            return None                              # the plain path raises NoMoreSamplesError
+        if self._block is None or not (self._block_first_ms <= ms < self._block_first_ms + len(self._block)):
+            if self._block is None or ms != self._block_first_ms + len(self._block):
+                self._reader.seek(ms)
+            got = self._reader.next_host_block()
+            if got is None:
+                return None
+            self._block_first_ms, self._block = got[0], got[1].copy()
+        return self._block[ms - self._block_first_ms]
 
     def peek_samples(self, sample_count: int) -> AntennaSampleChunk:
         word_bytes = np.dtype(self.sample_component_data_type).itemsize
@@ -90,8 +116,10 @@ class AntennaSampleProviderBackedByFile(_CursorProvider):
         end = start + sample_count * 2 * word_bytes
         if end >= self.file_size_in_bytes:   # same (off-by-one-conservative) bound as the reference, :106
             raise NoMoreSamplesError(f"Ran out of samples at {self.seconds_since_start():.2f}s")
-        words = np.fromfile(self.path.as_posix(), dtype=self.sample_component_data_type,
-                            count=sample_count * 2, offset=start)
+        words = self._words_from_reader(sample_count) if self._reader is not None else None
+        if words is None:
+            words = np.fromfile(self.path.as_posix(), dtype=self.sample_component_data_type,
+                                count=sample_count * 2, offset=start)
         return AntennaSampleChunk(
             start_time=self.seconds_since_start(),
             end_time=self._elapsed(self.cursor + sample_count),

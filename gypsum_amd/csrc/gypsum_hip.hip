@@ -957,3 +957,227 @@ int gyp_bits_get_state(const gyp_bits* bits, int32_t channel, gyp_bits_state* ou
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// IQ ingest
+// ---------------------------------------------------------------------------------------------------------
+#include "ingest.hpp"
+
+static void ingest_free(gyp_ingest* g) {
+    ingest_stop_reader(g);
+    if (g->ctx) {
+        (void)hipSetDevice(g->ctx->device);
+        if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
+        for (auto p : g->dev_raw) if (p) (void)hipFree(p);
+        for (auto p : g->dev_iq) if (p) (void)hipFree(p);
+        for (auto e : g->uploaded) if (e) (void)hipEventDestroy(e);
+        for (auto e : g->ready) if (e) (void)hipEventDestroy(e);
+        if (g->consumer_mark) (void)hipEventDestroy(g->consumer_mark);
+        if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
+        for (auto p : g->host) if (p) (void)hipHostFree(p);
+    } else {
+        for (auto p : g->host) std::free(p);
+    }
+    if (g->fd >= 0) close(g->fd);
+    delete g;
+}
+
+// Enqueue the upload (+ widening) of the reader's next block on the copy stream.  Returns 1 if a block was
+// enqueued, 0 if none is available (end of data, or not yet read and !wait), negative on error.
+static int ingest_enqueue_upload(gyp_ingest* g, gyp_ingest::Upload* u, bool wait) {
+    gyp_ctx* ctx = g->ctx;
+    // keep fewer than `depth` host slots tied up in uploads: retire the oldest first
+    while ((int)g->in_flight.size() >= g->depth - 1) {
+        const gyp_ingest::Upload& f = g->in_flight.front();
+        HIP_TRY(ctx, hipEventSynchronize(g->uploaded[f.block % g->depth]));
+        ingest_release(g, f.block + 1);
+        g->in_flight.pop_front();
+    }
+    int slot;
+    if (!ingest_take(g, &slot, &u->first_ms, &u->n_ms, wait)) {
+        if (g->io_errno) return fail(ctx, GYP_E_IO, std::string("gyp_ingest: read failed: ") + std::strerror(g->io_errno));
+        return 0;
+    }
+    u->host_slot = slot;
+    u->block = g->taken - 1;
+    const int d = (int)(u->block % g->depth);
+    // the device slot may hold an older block: everything the consumer has enqueued so far drains first (that is
+    // the kernels of block k-1 when block k+1 is uploaded ahead, so the upload still overlaps block k's kernels)
+    HIP_TRY(ctx, hipEventRecord(g->consumer_mark, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(g->copy_stream, g->consumer_mark, 0));
+    const size_t bytes = (size_t)u->n_ms * g->ms_bytes;
+    const size_t words = (size_t)u->n_ms * g->n * 2;
+    void* dst = g->fmt == kFmtF32 ? (void*)g->dev_iq[d] : (void*)g->dev_raw[d];
+    HIP_TRY(ctx, hipMemcpyAsync(dst, g->host[slot], bytes, hipMemcpyHostToDevice, g->copy_stream));
+    HIP_TRY(ctx, hipEventRecord(g->uploaded[d], g->copy_stream));
+    if (g->fmt != kFmtF32) {
+        const int grid = (int)std::min<size_t>((words / 16 + 255) / 256 + 1, (size_t)ctx->n_cus * 8);
+        switch (g->fmt) {
+            case kFmtI8: hipLaunchKernelGGL(ingest_widen_kernel<int8_t>, dim3(grid), dim3(256), 0, g->copy_stream, (const int8_t*)dst, g->dev_iq[d], words); break;
+            case kFmtU8: hipLaunchKernelGGL(ingest_widen_kernel<uint8_t>, dim3(grid), dim3(256), 0, g->copy_stream, (const uint8_t*)dst, g->dev_iq[d], words); break;
+            default: hipLaunchKernelGGL(ingest_widen_kernel<int16_t>, dim3(grid), dim3(256), 0, g->copy_stream, (const int16_t*)dst, g->dev_iq[d], words); break;
+        }
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipEventRecord(g->ready[d], g->copy_stream));
+    g->in_flight.push_back(*u);
+    ++g->dev_blocks;
+    return 1;
+}
+
+// Python's round(x, 6) for the magnitudes a cursor/fs takes: correctly rounded decimal -> nearest double.
+static double round6(double x) {
+    char buf[64];
+    std::snprintf(buf, sizeof buf, "%.6f", x);
+    return std::strtod(buf, nullptr);
+}
+
+extern "C" {
+
+int gyp_ingest_open(gyp_ctx* ctx, const char* path, int32_t fmt, int64_t fs_hz, int32_t n, int32_t block_ms,
+                    int32_t depth, gyp_ingest** out) {
+    if (!out) return fail(ctx, GYP_E_BAD_ARG, "gyp_ingest_open: out is NULL");
+    *out = nullptr;
+    const int wb = ingest_word_bytes(fmt);
+    if (!path || !wb || fs_hz <= 0 || n <= 0 || block_ms < 1 || depth < 3 || depth > 64)
+        return fail(ctx, GYP_E_BAD_ARG, "gyp_ingest_open: bad arguments (format, fs, n, block_ms >= 1, 3 <= depth <= 64)");
+    if ((int64_t)n != fs_hz / 1000)   // antenna_sample_provider.py:135
+        return fail(ctx, GYP_E_BAD_RATE, "gyp_ingest_open: n must be fs // 1000");
+    gyp_ingest* g = new (std::nothrow) gyp_ingest();
+    if (!g) return fail(ctx, GYP_E_NOMEM, "gyp_ingest_open: out of memory");
+    g->ctx = ctx;
+    g->fmt = fmt;
+    g->fs = fs_hz;
+    g->n = n;
+    g->block_ms = block_ms;
+    g->depth = depth;
+    g->ms_bytes = (size_t)n * 2 * wb;
+    g->fd = open(path, O_RDONLY | O_CLOEXEC);
+    struct stat st;
+    if (g->fd < 0 || fstat(g->fd, &st) != 0) {
+        const std::string why = std::strerror(errno);
+        ingest_free(g);
+        return fail(ctx, GYP_E_IO, std::string("gyp_ingest_open: ") + path + ": " + why);
+    }
+    g->total_ms = st.st_size > 0 ? (int64_t)((st.st_size - 1) / (off_t)g->ms_bytes) : 0;
+    (void)posix_fadvise(g->fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+    const size_t block_bytes = (size_t)block_ms * g->ms_bytes;
+    g->host.assign(depth, nullptr);
+    g->host_first.assign(depth, 0);
+    g->host_ms.assign(depth, 0);
+    int rc = GYP_OK;
+    auto setup = [&]() -> int {
+        if (!ctx) {
+            for (auto& p : g->host) {
+                void* m = nullptr;
+                if (posix_memalign(&m, 4096, block_bytes)) return fail(ctx, GYP_E_NOMEM, "gyp_ingest_open: out of memory");
+                p = (uint8_t*)m;
+            }
+            return GYP_OK;
+        }
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        for (auto& p : g->host) HIP_TRY(ctx, hipHostMalloc((void**)&p, block_bytes, hipHostMallocDefault));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
+        g->dev_raw.assign(depth, nullptr);
+        g->dev_iq.assign(depth, nullptr);
+        g->uploaded.assign(depth, nullptr);
+        g->ready.assign(depth, nullptr);
+        for (int i = 0; i < depth; ++i) {
+            if (fmt != kFmtF32) HIP_TRY(ctx, hipMalloc((void**)&g->dev_raw[i], block_bytes));
+            HIP_TRY(ctx, hipMalloc((void**)&g->dev_iq[i], (size_t)block_ms * n * 2 * sizeof(float)));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&g->uploaded[i], hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&g->ready[i], hipEventDisableTiming));
+        }
+        HIP_TRY(ctx, hipEventCreateWithFlags(&g->consumer_mark, hipEventDisableTiming));
+        return GYP_OK;
+    };
+    if ((rc = setup())) {
+        ingest_free(g);
+        return rc;
+    }
+    ingest_start_reader(g, 0);
+    *out = g;
+    return GYP_OK;
+}
+
+void gyp_ingest_close(gyp_ingest* ing) {
+    if (ing) ingest_free(ing);
+}
+
+int64_t gyp_ingest_total_ms(const gyp_ingest* ing) { return ing ? ing->total_ms : 0; }
+
+int gyp_ingest_seek(gyp_ingest* g, int64_t ms) {
+    if (!g) return fail(nullptr, GYP_E_BAD_ARG, "gyp_ingest_seek: handle is NULL");
+    if (ms < 0 || ms > g->total_ms) return fail(g->ctx, GYP_E_BAD_ARG, "gyp_ingest_seek: millisecond out of range");
+    ingest_stop_reader(g);
+    if (g->ctx) {
+        HIP_TRY(g->ctx, hipStreamSynchronize(g->copy_stream));
+        g->in_flight.clear();
+        g->have_ahead = false;
+    }
+    ingest_start_reader(g, ms);
+    return GYP_OK;
+}
+
+int gyp_ingest_next_host(gyp_ingest* g, const void** raw_out, int64_t* first_ms_out, int32_t* n_ms_out) {
+    if (!g || !raw_out || !first_ms_out || !n_ms_out) return fail(g ? g->ctx : nullptr, GYP_E_BAD_ARG, "gyp_ingest_next_host: NULL argument");
+    *raw_out = nullptr;
+    *n_ms_out = 0;
+    if (g->ctx && (!g->in_flight.empty() || g->have_ahead))
+        return fail(g->ctx, GYP_E_BAD_ARG, "gyp_ingest_next_host: device blocks are in flight on this handle; seek first");
+    ingest_release(g, g->taken);   // the block handed out by the previous call may be overwritten now
+    int slot;
+    if (!ingest_take(g, &slot, first_ms_out, n_ms_out, true)) {
+        *n_ms_out = 0;
+        if (g->io_errno) return fail(g->ctx, GYP_E_IO, std::string("gyp_ingest: read failed: ") + std::strerror(g->io_errno));
+        return GYP_OK;
+    }
+    *raw_out = g->host[slot];
+    return GYP_OK;
+}
+
+int gyp_ingest_next_dev(gyp_ingest* g, const float** iq_dev_out, int64_t* first_ms_out, int32_t* n_ms_out) {
+    if (!g || !iq_dev_out || !first_ms_out || !n_ms_out) return fail(g ? g->ctx : nullptr, GYP_E_BAD_ARG, "gyp_ingest_next_dev: NULL argument");
+    *iq_dev_out = nullptr;
+    *n_ms_out = 0;
+    gyp_ctx* ctx = g->ctx;
+    if (!ctx) return fail(nullptr, GYP_E_NO_DEVICE, "gyp_ingest_next_dev: the handle was opened without a context");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    gyp_ingest::Upload cur{};
+    if (g->have_ahead) {
+        cur = g->ahead;
+        g->have_ahead = false;
+    } else {
+        const int rc = ingest_enqueue_upload(g, &cur, true);
+        if (rc < 0) return rc;
+        if (rc == 0) return GYP_OK;   // end of data
+    }
+    // start the next block's upload now if the reader already has it: it then overlaps this block's kernels
+    const int rc = ingest_enqueue_upload(g, &g->ahead, false);
+    if (rc < 0) return rc;
+    g->have_ahead = rc == 1;
+    const int d = (int)(cur.block % g->depth);
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, g->ready[d], 0));
+    // hand back host slots whose upload has finished
+    while (!g->in_flight.empty() && hipEventQuery(g->uploaded[g->in_flight.front().block % g->depth]) == hipSuccess) {
+        ingest_release(g, g->in_flight.front().block + 1);
+        g->in_flight.pop_front();
+    }
+    *iq_dev_out = g->dev_iq[d];
+    *first_ms_out = cur.first_ms;
+    *n_ms_out = cur.n_ms;
+    return GYP_OK;
+}
+
+int gyp_ingest_times(const gyp_ingest* g, int64_t first_ms, int32_t n_ms, double* start_out, double* end_out) {
+    if (!g || n_ms < 0 || first_ms < 0 || (n_ms > 0 && (!start_out || !end_out)))
+        return fail(g ? g->ctx : nullptr, GYP_E_BAD_ARG, "gyp_ingest_times: bad arguments");
+    for (int32_t i = 0; i < n_ms; ++i) {
+        const int64_t cursor = (first_ms + i) * g->n;
+        start_out[i] = round6((double)cursor / (double)g->fs);
+        end_out[i] = round6((double)(cursor + g->n) / (double)g->fs);
+    }
+    return GYP_OK;
+}
+
+}  // extern "C"

@@ -37,7 +37,8 @@ enum {
     GYP_E_NO_DEVICE = -3,
     GYP_E_HIP = -4,
     GYP_E_NO_FORMAT = -5,   /* gyp_set_stream_format has not been called */
-    GYP_E_NOMEM = -6
+    GYP_E_NOMEM = -6,
+    GYP_E_IO = -7           /* file could not be opened / read */
 };
 
 /* utils.py:23-25 IntegrationType */
@@ -311,6 +312,41 @@ int gyp_bits_push_block(gyp_bits* bits, const gyp_track_rec* recs_host, int32_t 
                         int32_t capacity, int32_t* n_events_out);
 int gyp_bits_drain(gyp_bits* bits, gyp_bit_event* events_out, int32_t capacity, int32_t* n_events_out);
 int gyp_bits_get_state(const gyp_bits* bits, int32_t channel, gyp_bits_state* out);
+
+/* ---------------------------------------------------------------- IQ ingest ---------------------------- */
+/* SURVEY.md 8 f2.  Replaces the per-millisecond file open + np.fromfile of
+ * antenna_sample_provider.py:79-136 AntennaSampleProviderBackedByFile (format of radio_input.py:22-44: interleaved
+ * I,Q words, GNU Radio float32 by default): a reader thread preads blocks of `block_ms` milliseconds into a ring of
+ * `depth` (pinned) host buffers; gyp_ingest_next_dev uploads them on a copy stream one block ahead of the consumer
+ * and, for integer recordings, widens the words to float32 pairs on the device.  Sample values are exactly
+ * `words[0::2] + 1j*words[1::2]` of the same dtype. */
+typedef struct gyp_ingest gyp_ingest;
+
+#define GYP_FMT_F32 0   /* numpy float32, GNU Radio recordings (radio_input.py:41) */
+#define GYP_FMT_I8 1    /* numpy int8   (HackRF raw) */
+#define GYP_FMT_I16 2   /* numpy int16 */
+#define GYP_FMT_U8 3    /* numpy uint8  (RTL-SDR raw; no offset is removed, as np.fromfile would not) */
+
+/* ctx may be NULL: host-only reader (plain host buffers, gyp_ingest_next_host only).  n = samples per millisecond
+ * (SampleProviderAttributes.samples_per_prn_transmission); block_ms >= 1; 3 <= depth <= 64. */
+int gyp_ingest_open(gyp_ctx* ctx, const char* path, int32_t fmt, int64_t fs_hz, int32_t n, int32_t block_ms,
+                    int32_t depth, gyp_ingest** out);
+void gyp_ingest_close(gyp_ingest* ing);
+/* Milliseconds the reference provider hands out before raising NoMoreSamplesError: it refuses a chunk whose end
+ * offset is >= the file size (antenna_sample_provider.py:106), so a chunk ending exactly at EOF is not delivered. */
+int64_t gyp_ingest_total_ms(const gyp_ingest* ing);
+/* Restart reading at millisecond `ms` (the provider's cursor / N). */
+int gyp_ingest_seek(gyp_ingest* ing, int64_t ms);
+/* Next block as raw file words on the host (n_ms x 2N words); valid until the next call on this handle.
+ * *n_ms_out == 0 means end of data. */
+int gyp_ingest_next_host(gyp_ingest* ing, const void** raw_out, int64_t* first_ms_out, int32_t* n_ms_out);
+/* Next block as complex64 (interleaved float32 I,Q) in HBM, n_ms x N samples.  The context's stream is made to wait
+ * for the upload, so kernels enqueued on it afterwards see the data; nothing blocks the host except waiting for the
+ * reader thread.  The block stays valid while the next depth-2 calls are made.  *n_ms_out == 0: end of data. */
+int gyp_ingest_next_dev(gyp_ingest* ing, const float** iq_dev_out, int64_t* first_ms_out, int32_t* n_ms_out);
+/* AntennaSampleChunk.start_time / end_time of milliseconds first_ms .. first_ms+n_ms-1: round(cursor / fs, 6)
+ * (antenna_sample_provider.py:88-89), bit-identical to Python's round(). */
+int gyp_ingest_times(const gyp_ingest* ing, int64_t first_ms, int32_t n_ms, double* start_out, double* end_out);
 
 /* Debug: per-phase shader-cycle counters of workgroup 0 of gyp_track_block_dev (correlate, reduce, loop update,
  * barrier, ms count).  enable != 0 arms it; out8 (may be NULL) receives the counters of the last launch. */

@@ -29,7 +29,7 @@ def lib():
 
 def test_library_exports_every_declared_symbol(lib):
     text = HEADER.read_text()
-    declared = set(re.findall(r"^\s*(?:int|void|double|const char\*)\s+(gyp_\w+)\s*\(", text, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int64_t|void|double|const char\*)\s+(gyp_\w+)\s*\(", text, flags=re.M))
     assert declared, "no declarations parsed from the header"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
@@ -40,7 +40,8 @@ def test_library_exports_every_declared_symbol(lib):
 def test_record_layouts_match_the_header(tmp_path):
     structs = {"gyp_cell_desc": _lib.CELL_DESC, "gyp_cell": _lib.CELL, "gyp_acq_result": _lib.ACQ_RESULT,
                "gyp_chan_in": _lib.CHAN_IN, "gyp_chan_out": _lib.CHAN_OUT, "gyp_chan_init": _lib.CHAN_INIT,
-               "gyp_track_rec": _lib.TRACK_REC, "gyp_synth_sat": _lib.SYNTH_SAT}
+               "gyp_track_rec": _lib.TRACK_REC, "gyp_synth_sat": _lib.SYNTH_SAT, "gyp_bit_event": _lib.BIT_EVENT,
+               "gyp_bits_state": _lib.BITS_STATE}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for name, dt in structs.items():
         lines.append(f'printf("{name} size %zu\\n", sizeof({name}));')
