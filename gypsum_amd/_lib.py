@@ -51,7 +51,7 @@ EXPORTS = (
     "gyp_acquire gyp_track_step_dev gyp_track_step gyp_bank_create gyp_bank_destroy gyp_bank_size "
     "gyp_track_block_dev gyp_track_block gyp_bank_get_state gyp_synth_iq_dev gyp_synth_nav_bit gyp_bank_reset_dev gyp_debug_track_profile gyp_debug_fft_bench "
     "gyp_bits_create gyp_bits_destroy gyp_bits_reset gyp_bits_push gyp_bits_push_block gyp_bits_drain gyp_bits_get_state "
-    "gyp_ingest_open gyp_ingest_close gyp_ingest_total_ms gyp_ingest_seek gyp_ingest_next_host gyp_ingest_next_dev gyp_ingest_times"
+    "gyp_ingest_open gyp_ingest_close gyp_ingest_total_ms gyp_ingest_set_scale gyp_ingest_seek gyp_ingest_next_host gyp_ingest_next_dev gyp_ingest_times"
 ).split()
 
 
@@ -122,6 +122,7 @@ def load() -> C.CDLL:
         "gyp_ingest_open": (C.c_int, [vp, C.c_char_p, i32, i64, i32, i32, i32, C.POINTER(vp)]),
         "gyp_ingest_close": (None, [vp]),
         "gyp_ingest_total_ms": (i64, [vp]),
+        "gyp_ingest_set_scale": (C.c_int, [vp, C.c_float]),
         "gyp_ingest_seek": (C.c_int, [vp, i64]),
         "gyp_ingest_next_host": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(i32)]),
         "gyp_ingest_next_dev": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(i32)]),

@@ -1013,9 +1013,9 @@ static int ingest_enqueue_upload(gyp_ingest* g, gyp_ingest::Upload* u, bool wait
     if (g->fmt != kFmtF32) {
         const int grid = (int)std::min<size_t>((words / 16 + 255) / 256 + 1, (size_t)ctx->n_cus * 8);
         switch (g->fmt) {
-            case kFmtI8: hipLaunchKernelGGL(ingest_widen_kernel<int8_t>, dim3(grid), dim3(256), 0, g->copy_stream, (const int8_t*)dst, g->dev_iq[d], words); break;
-            case kFmtU8: hipLaunchKernelGGL(ingest_widen_kernel<uint8_t>, dim3(grid), dim3(256), 0, g->copy_stream, (const uint8_t*)dst, g->dev_iq[d], words); break;
-            default: hipLaunchKernelGGL(ingest_widen_kernel<int16_t>, dim3(grid), dim3(256), 0, g->copy_stream, (const int16_t*)dst, g->dev_iq[d], words); break;
+            case kFmtI8: hipLaunchKernelGGL(ingest_widen_kernel<int8_t>, dim3(grid), dim3(256), 0, g->copy_stream, (const int8_t*)dst, g->dev_iq[d], words, g->scale); break;
+            case kFmtU8: hipLaunchKernelGGL(ingest_widen_kernel<uint8_t>, dim3(grid), dim3(256), 0, g->copy_stream, (const uint8_t*)dst, g->dev_iq[d], words, g->scale); break;
+            default: hipLaunchKernelGGL(ingest_widen_kernel<int16_t>, dim3(grid), dim3(256), 0, g->copy_stream, (const int16_t*)dst, g->dev_iq[d], words, g->scale); break;
         }
         HIP_TRY(ctx, hipGetLastError());
     }
@@ -1105,6 +1105,14 @@ void gyp_ingest_close(gyp_ingest* ing) {
 }
 
 int64_t gyp_ingest_total_ms(const gyp_ingest* ing) { return ing ? ing->total_ms : 0; }
+
+int gyp_ingest_set_scale(gyp_ingest* g, float scale) {
+    if (!g) return fail(nullptr, GYP_E_BAD_ARG, "gyp_ingest_set_scale: handle is NULL");
+    if (!(scale > 0.0f) || !std::isfinite(scale)) return fail(g->ctx, GYP_E_BAD_ARG, "gyp_ingest_set_scale: scale must be positive and finite");
+    if (g->fmt == kFmtF32) return fail(g->ctx, GYP_E_BAD_ARG, "gyp_ingest_set_scale: float32 recordings are uploaded as they are");
+    g->scale = scale;
+    return GYP_OK;
+}
 
 int gyp_ingest_seek(gyp_ingest* g, int64_t ms) {
     if (!g) return fail(nullptr, GYP_E_BAD_ARG, "gyp_ingest_seek: handle is NULL");

@@ -5,7 +5,7 @@
 // pinned buffers, the consumer's call enqueues the upload of the *next* block on a copy stream while the kernels of
 // the current block run, and integer sample formats (RTL-SDR / HackRF raw int8, int16) cross PCIe in their file
 // width and are widened to float32 pairs by a kernel on the device.  Values are exactly what
-// `words[0::2] + 1j*words[1::2]` holds for the same dtype (no scaling, no offset).
+// `words[0::2] + 1j*words[1::2]` holds for the same dtype (no offset; no scaling unless gyp_ingest_set_scale asks).
 #pragma once
 
 #include <fcntl.h>
@@ -31,7 +31,7 @@ static inline int ingest_word_bytes(int32_t fmt) {
 
 // 16 input bytes per lane per iteration: coalesced dwordx4 loads, 64-256 B of contiguous float stores per lane.
 template <class T>
-__global__ __launch_bounds__(256) void ingest_widen_kernel(const T* __restrict__ raw, float* __restrict__ out, size_t n_words) {
+__global__ __launch_bounds__(256) void ingest_widen_kernel(const T* __restrict__ raw, float* __restrict__ out, size_t n_words, float scale) {
     constexpr int kPer = 16 / sizeof(T);
     const size_t n_vec = n_words / kPer;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -42,16 +42,17 @@ __global__ __launch_bounds__(256) void ingest_widen_kernel(const T* __restrict__
         float4* o = reinterpret_cast<float4*>(out + v * kPer);
 #pragma unroll
         for (int i = 0; i < kPer / 4; ++i)
-            o[i] = make_float4((float)e[4 * i], (float)e[4 * i + 1], (float)e[4 * i + 2], (float)e[4 * i + 3]);
+            o[i] = make_float4((float)e[4 * i] * scale, (float)e[4 * i + 1] * scale, (float)e[4 * i + 2] * scale, (float)e[4 * i + 3] * scale);
     }
     if (blockIdx.x == 0)   // tail (block sizes are multiples of 2N words, so this is at most 15 words)
-        for (size_t i = n_vec * kPer + threadIdx.x; i < n_words; i += blockDim.x) out[i] = (float)raw[i];
+        for (size_t i = n_vec * kPer + threadIdx.x; i < n_words; i += blockDim.x) out[i] = (float)raw[i] * scale;
 }
 
 struct gyp_ingest {
     gyp_ctx* ctx = nullptr;   // null: host-only (no pinned memory, no device ring)
     int fd = -1;
     int32_t fmt = kFmtF32;
+    float scale = 1.0f;       // integer formats only: sample = word * scale (1 = the reference's raw values)
     int64_t fs = 0;
     int32_t n = 0, block_ms = 0, depth = 0;
     size_t ms_bytes = 0;

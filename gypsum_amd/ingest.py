@@ -59,6 +59,10 @@ class IqFileIngest:
         """Milliseconds the reference's provider delivers before NoMoreSamplesError."""
         return int(self._lib.gyp_ingest_total_ms(self._h))
 
+    def set_scale(self, scale: float) -> None:
+        """Integer recordings: device samples = word * scale (default 1 = the reference's raw values)."""
+        self._check(self._lib.gyp_ingest_set_scale(self._h, float(scale)))
+
     def seek(self, ms: int) -> None:
         self._check(self._lib.gyp_ingest_seek(self._h, int(ms)))
 

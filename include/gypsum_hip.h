@@ -335,6 +335,10 @@ void gyp_ingest_close(gyp_ingest* ing);
 /* Milliseconds the reference provider hands out before raising NoMoreSamplesError: it refuses a chunk whose end
  * offset is >= the file size (antenna_sample_provider.py:106), so a chunk ending exactly at EOF is not delivered. */
 int64_t gyp_ingest_total_ms(const gyp_ingest* ing);
+/* Integer recordings only: device samples become word * scale (one float32 multiply) for blocks uploaded from now
+ * on.  The default 1 keeps the reference's raw integer values; the tracking loops' fixed thresholds and gains
+ * (tracker.py:157-203,246-262) assume GNU-Radio-like amplitudes, so an 8-bit front end wants about 1/100. */
+int gyp_ingest_set_scale(gyp_ingest* ing, float scale);
 /* Restart reading at millisecond `ms` (the provider's cursor / N). */
 int gyp_ingest_seek(gyp_ingest* ing, int64_t ms);
 /* Next block as raw file words on the host (n_ms x 2N words); valid until the next call on this handle.

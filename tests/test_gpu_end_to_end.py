@@ -27,10 +27,13 @@ def test_file_to_navigation_bits(tmp_path, dtype):
     iq = synth.render(scene)
     words = np.empty(2 * len(iq), dtype=np.float32)
     words[0::2], words[1::2] = iq.real, iq.imag
-    if dtype is np.int8:                                   # an 8-bit front end: scale, round, saturate
-        words = np.clip(np.rint(words * (120 / np.abs(words).max())), -127, 127).astype(np.int8)
+    scale = np.float32(1.0)
+    if dtype is np.int8:                                   # an 8-bit front end: noise sigma = 2 LSB, saturating
+        words = np.clip(np.rint(words * 100), -127, 127).astype(np.int8)
+        scale = np.float32(0.01)                            # bring the amplitudes back where the loop constants expect them
     words.tofile(tmp_path / "rec")
-    iq_file = ((words[0::2]) + (1j * words[1::2])).astype(np.complex64)     # what the reference's provider yields
+    # what the reference's provider yields (antenna_sample_provider.py:119), times the ingest scale
+    iq_file = ((words[0::2] * scale) + (1j * (words[1::2] * scale))).astype(np.complex64)
 
     eng = default_engine(fs, n)
     sat_ids = [s.sat_id for s in scene.sats]
@@ -42,6 +45,8 @@ def test_file_to_navigation_bits(tmp_path, dtype):
 
     # host-buffer path: the block the C ABI copies itself
     ing = IqFileIngest(tmp_path / "rec", fs, dtype, block_ms=250, depth=3, engine=eng)
+    if dtype is np.int8:
+        ing.set_scale(scale)
     total = ing.total_ms
     assert total == n_ms - 1                                # the chunk ending exactly at EOF is refused upstream
     start_all, end_all = ing.times(0, total)
