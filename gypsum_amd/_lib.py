@@ -6,7 +6,10 @@ from pathlib import Path
 
 import numpy as np
 
-LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libgypsum_hip.so"
+import os
+
+# GYPSUM_HIP_LIB points at an alternative build of the same library (A/B experiments); default: the in-tree one
+LIB_PATH = Path(os.environ.get("GYPSUM_HIP_LIB") or Path(__file__).resolve().parent / "csrc" / "libgypsum_hip.so")
 
 GYP_OK = 0
 GYP_E_BAD_ARG, GYP_E_BAD_RATE, GYP_E_NO_DEVICE, GYP_E_HIP, GYP_E_NO_FORMAT, GYP_E_NOMEM, GYP_E_IO = -1, -2, -3, -4, -5, -6, -7

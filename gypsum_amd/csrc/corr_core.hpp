@@ -26,7 +26,10 @@ constexpr int kXchWave = kXchWaveFloats / 2; // in complex elements: 1088 >= the
 constexpr int kXchWaveBytes = kXchWaveFloats * 4;  // 8704 B per wavefront: 16 wavefronts (4 per SIMD) fit a CU's LDS
 
 typedef float2 cf;
-constexpr int kTwBatch = 8;   // twiddle / replica values fetched per scheduling group (bounds their register footprint)
+#ifndef GYP_TW_BATCH
+#define GYP_TW_BATCH 8
+#endif
+constexpr int kTwBatch = GYP_TW_BATCH;   // twiddle / replica values fetched per scheduling group (bounds their register footprint)
 
 // Hide a thread-id-derived value from the optimiser so that everything computed from it is re-derived where it
 // is used (a handful of integer instructions) instead of being hoisted out of the per-millisecond loop as a
@@ -368,6 +371,66 @@ __device__ __forceinline__ void stage_ms(const cf* __restrict__ block, double u0
                     y_rows[r][m] = acc;
                 }
             }
+        }
+    }
+}
+
+// The two halves of stage_ms as separate steps, for kernels that fetch the next block's samples while the transforms
+// of the current one run (software pipelining; needs the 256-VGPR budget): stage_fetch issues every global load of
+// the block into registers, stage_emit wipes them, pre-sums and writes the K rows (+ the zero of the padding slot).
+template <int K>
+struct StagedSamples {
+    static constexpr int T = 64 * K;
+    static constexpr int CH = (kChips + T - 1) / T;
+    cf w[CH][2 * K - 1];
+};
+template <int K>
+__device__ __forceinline__ void stage_fetch(const cf* __restrict__ block, StagedSamples<K>& s, int tid) {
+#pragma unroll
+    for (int c = 0; c < StagedSamples<K>::CH; ++c) {
+        const int m = tid + c * StagedSamples<K>::T;
+        if (m < kChips) {
+            load_samples<K>(block + K * m, s.w[c]);
+            const int mn = (m + 1 == kChips) ? 0 : m + 1;
+            if (K > 1) load_samples<K - 1>(block + K * mn, s.w[c] + K);
+        }
+    }
+}
+template <int K>
+__device__ __forceinline__ void stage_emit(StagedSamples<K>& s, double u0, double du, const CarrierSteps& cs,
+                                           cf* (&y_rows)[K], int tid) {
+    const cf rot1 = cs.rot1, rot_wrap = cs.rot_wrap;
+#pragma unroll
+    for (int c = 0; c < StagedSamples<K>::CH; ++c) {
+        const int m = tid + c * StagedSamples<K>::T;
+        if (m < kChips) {
+            cf (&w)[2 * K - 1] = s.w[c];
+            cf car = carrier_from_cycles_fast(u0 + du * (double)(K * m));
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                w[i] = cmul(w[i], car);
+                car = cmul(car, rot1);
+            }
+            if (K > 1) {
+                if (m + 1 == kChips) car = cmul(car, rot_wrap);
+#pragma unroll
+                for (int i = 0; i < K - 1; ++i) {
+                    w[K + i] = cmul(w[K + i], car);
+                    car = cmul(car, rot1);
+                }
+            }
+            cf acc = w[0];
+#pragma unroll
+            for (int i = 1; i < K; ++i) acc = cadd(acc, w[i]);
+            y_rows[0][m] = acc;
+#pragma unroll
+            for (int r = 1; r < K; ++r) {
+                acc = cadd(csub(acc, w[r - 1]), w[r + K - 1]);
+                y_rows[r][m] = acc;
+            }
+        } else if (m == kChips) {
+#pragma unroll
+            for (int r = 0; r < K; ++r) y_rows[r][m] = make_float2(0.f, 0.f);
         }
     }
 }

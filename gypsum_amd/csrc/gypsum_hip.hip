@@ -7,6 +7,7 @@
 #include <cmath>
 #include <complex>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -101,6 +102,7 @@ struct gyp_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cus = 256;
+    bool no_pipe = false;      // GYP_NO_PIPE=1: A/B switch back to the two-workgroups-per-CU cells kernel
     std::string err;
     // stream format
     int64_t fs = 0;
@@ -170,6 +172,7 @@ int gyp_create(int device_ordinal, gyp_ctx** out) {
     gyp_ctx* ctx = new gyp_ctx();
     ctx->device = device_ordinal;
     ctx->n_cus = prop.multiProcessorCount;
+    ctx->no_pipe = std::getenv("GYP_NO_PIPE") != nullptr;
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         delete ctx;
@@ -338,6 +341,10 @@ static int launch_k(gyp_ctx* ctx, KernelT kernel, int k, int grid, const ParamsT
 static int launch_cells(gyp_ctx* ctx, const CellsParams& p, int integration) {
     const int grid = std::max(1, std::min(p.n_cells, ctx->n_cus * blocks_per_cu(ctx->k)) & ~7);
     const bool coh = integration == GYP_COHERENT;
+    if (!coh && ctx->k == 8 && !ctx->no_pipe) {   // one pipelined workgroup per CU (256 VGPRs, double-buffered LDS)
+        const int grid1 = std::max(1, std::min(p.n_cells, ctx->n_cus) & ~7);
+        return launch_k(ctx, corr_cells_pipe_kernel<8>, 8, grid1, p, lds_bytes_pipe<8>());
+    }
     switch (ctx->k) {
 #define X(K) case K: return coh ? launch_k(ctx, corr_cells_kernel<K, true>, K, grid, p, lds_bytes<K>()) \
                                 : launch_k(ctx, corr_cells_kernel<K, false>, K, grid, p, lds_bytes<K>());

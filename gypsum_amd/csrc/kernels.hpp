@@ -324,6 +324,114 @@ __global__ __launch_bounds__(Geom<K>::kThreads, (K == 8 && !COHERENT) ? GYP_CELL
     }
 }
 
+// Software-pipelined non-coherent cells for K <= 8 (used for K == 8, the acquisition search at 8.184 Msps): ONE
+// workgroup per CU with the 256-VGPR budget -- no accumulator spills (at 128 VGPRs the 16 running magnitudes per lane
+// went through scratch, whose footprint across 16 waves x 256 CUs overflowed L2 and turned into HBM round trips) --
+// and two row/tile buffers in LDS: while the wavefronts transform block ms out of one buffer, the samples of block
+// ms+1 (fetched during the previous iteration) are wiped and staged into the other, and the loads of block ms+2 are
+// in flight.  One workgroup barrier per millisecond instead of two, no exposed global-load latency.
+template <int K>
+constexpr int lds_bytes_pipe() { return 2 * kTablesBytes + 2 * Geom<K>::W * kXchWaveBytes + kRedBytes; }
+
+template <int K>
+__global__ __launch_bounds__(Geom<K>::kThreads, 2) void corr_cells_pipe_kernel(CellsParams p) {
+    static_assert(Geom<K>::R == 1, "pipelined cells need all K branches resident");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int N = K * kChips;
+    constexpr int W = Geom<K>::W;
+    Smem sm;
+    sm.tw1024 = reinterpret_cast<cf*>(smem_raw);
+    cf* tw2048 = sm.tw1024 + 1024;          // both twiddle tables live in LDS here: no global load inside a transform
+    sm.tw2048 = tw2048;
+    sm.xch = tw2048 + 1024;
+    sm.red = reinterpret_cast<RedScratch*>(smem_raw + 2 * kTablesBytes + 2 * W * kXchWaveBytes);
+    for (int i = threadIdx.x; i < 2048; i += Geom<K>::kThreads) sm.tw1024[i] = p.tw_tables[i];
+    __syncthreads();
+    const LdsTables tables{sm.tw1024, sm.tw2048};
+    for (int v = blockIdx.x; v < p.n_cells; v += gridDim.x) {
+        const int cell = xcd_contiguous(v, p.n_cells);
+        const gyp_cell_desc d = p.cells[cell];
+        if (d.sat_id < 1 || d.sat_id > 32) continue;  // padding cell (uniform across the workgroup)
+        const cf* rep = replica_of(p.replica_table, d.sat_id - 1);
+        const double du = d.doppler_hz * p.inv_fs;
+        const CarrierSteps cs = carrier_steps<K>(du);
+        const cf* stream = p.iq + (int64_t)d.stream * p.stream_stride;
+        const double u0_step = d.doppler_hz * ((double)N * p.inv_fs);   // utils.py:92-96
+        const int tid = launder(threadIdx.x);
+        const int wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
+        float mag[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) mag[j] = 0.f;
+        StagedSamples<K> smp;
+        {   // prologue: block 0 staged into buffer 0, block 1 in flight
+            cf* y_rows[W];
+#pragma unroll
+            for (int r = 0; r < W; ++r) y_rows[r] = sm.xch + r * kXchWave;
+            stage_fetch<K>(stream, smp, tid);
+            stage_emit<K>(smp, 0.0, du, cs, y_rows, tid);
+            if (p.n_ms > 1) stage_fetch<K>(stream + N, smp, tid);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int ms = 0; ms < p.n_ms; ++ms) {
+            cf* cur = sm.xch + (ms & 1) * (W * kXchWave);
+            cf* nxt = sm.xch + ((ms + 1) & 1) * (W * kXchWave);
+            cf prn[32];   // this satellite's replica spectrum, requested now and used after the forward transform
+            {
+                const cf* row = rep + launder(lane);
+#pragma unroll
+                for (int i = 0; i < 32; ++i) prn[i] = row[64 * i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ms + 1 < p.n_ms) {   // uniform
+                cf* y_rows[W];
+#pragma unroll
+                for (int r = 0; r < W; ++r) y_rows[r] = nxt + r * kXchWave;
+                stage_emit<K>(smp, u0_step * (double)(ms + 1), du, cs, y_rows, tid);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            cf x[32];
+            const cf* yw = cur + wave * kXchWave;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) x[j] = yw[32 * j + l];
+            wave_lds_fence();
+            float* tile_half = reinterpret_cast<float*>(cur + wave * kXchWave) + h * kXchTile;
+            cf c[16];
+            wave_fft_fwd(x, tile_half, tables, l, h);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) x[i] = cmul(x[i], prn[i]);
+            __builtin_amdgcn_sched_barrier(0);
+            // the replica registers are dead: fetch the block after next into them while the inverse transform runs
+            if (ms + 2 < p.n_ms) stage_fetch<K>(stream + (int64_t)(ms + 2) * N, smp, tid);
+            __builtin_amdgcn_sched_barrier(0);
+            wave_fft_inv(x, c, tile_half, tables, l, h);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) mag[j] += __builtin_amdgcn_sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
+            __syncthreads();   // next buffer fully staged; this buffer's tiles free for the block after next
+        }
+        LaneStats ls = lane_stats_init();
+        lane_stats_update<K, false>(ls, mag, nullptr, 0, tid, [](int idx) { return idx; });
+        if (p.profile_out) {
+            const int base = lag_base<K>(tid, 0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (slot_valid(j, tid)) p.profile_out[(int64_t)cell * N + base + 32 * K * j] = mag[j];
+        }
+        const ProfileStats st = lane_stats_finish<K>(ls, sm.red, tid);
+        if (threadIdx.x == 0) {
+            gyp_cell* o = p.out + cell;
+            o->peak = st.best.v;
+            o->argmax = st.best.key;
+            o->sum = st.sum;
+            o->n_max = st.n_max;
+            o->reserved = 0;
+            o->tap_re = 0.f;
+            o->tap_im = 0.f;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // flat search grid (every satellite shares the same Doppler bins, e.g. BASELINE configs 2/4/5 and the first level
 // of the acquisition search): the wipe-off + polyphase pre-sum depends on (stream, Doppler, ms) only, so it is
