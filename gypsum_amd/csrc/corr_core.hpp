@@ -177,27 +177,39 @@ __device__ __forceinline__ void transpose32(cf (&x)[32], float* tile_half, int l
     wave_lds_fence();
 }
 
+// x[reg_of(g)] *= table[32*g + l] (or its conjugate) for the kTwBatch rows g = b .. b+kTwBatch-1: every load of the
+// batch is issued before the first multiply (one exposed latency per batch instead of one per element -- left to
+// itself the scheduler serialises load, wait, multiply under the 128-VGPR budget).  Row 0 of a table is 1.
+template <bool CONJ, bool SKIP_ROW0, typename RegOf>
+__device__ __forceinline__ void twiddle_batch(cf (&x)[32], const cf* __restrict__ table_lane, int b, RegOf reg_of) {
+    cf tw[kTwBatch];
+#pragma unroll
+    for (int j = 0; j < kTwBatch; ++j) tw[j] = table_lane[32 * (b + j)];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < kTwBatch; ++j) {
+        if (SKIP_ROW0 && b + j == 0) continue;
+        cf& v = x[reg_of(b + j)];
+        v = CONJ ? cmulc(v, tw[j]) : cmul(v, tw[j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // Forward transform.  In: x[j] = y[32*j + l] (identical in both half-waves; y[1023] must be 0).
 // Out: physical register i holds bin f = 2*(l + 32*bitrev5(i)) + h.
 __device__ __forceinline__ void wave_fft_fwd(cf (&x)[32], float* tile_half, const LdsTables& t, int l, int h) {
     if (h) {
+        const cf* tab = t.tw2048 + launder(l);
 #pragma unroll
-        for (int b = 0; b < 32; b += kTwBatch) {
-            const cf* row = t.tw2048 + 32 * b + launder(l);
-#pragma unroll
-            for (int j = 0; j < kTwBatch; ++j) x[b + j] = cmul(x[b + j], row[32 * j]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int b = 0; b < 32; b += kTwBatch) twiddle_batch<false, false>(x, tab, b, [](int g) { return g; });
     }
     __builtin_amdgcn_sched_barrier(0);
     fft32_dif<-1>(x);
     __builtin_amdgcn_sched_barrier(0);
+    {
+        const cf* tab = t.tw1024 + l;
 #pragma unroll
-    for (int b = 0; b < 32; b += kTwBatch) {
-#pragma unroll
-        for (int g = b; g < b + kTwBatch; ++g)
-            if (g) x[bitrev5(g)] = cmul(x[bitrev5(g)], t.tw1024[32 * g + l]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int b = 0; b < 32; b += kTwBatch) twiddle_batch<false, true>(x, tab, b, [](int g) { return bitrev5(g); });
     }
     transpose32(x, tile_half, l, [](int g) { return bitrev5(g); });
     __builtin_amdgcn_sched_barrier(0);
@@ -212,12 +224,10 @@ __device__ __forceinline__ void wave_fft_inv(cf (&x)[32], cf (&c)[16], float* ti
     __builtin_amdgcn_sched_barrier(0);
     fft32_dit<+1>(x);
     __builtin_amdgcn_sched_barrier(0);
+    {
+        const cf* tab = t.tw1024 + l;
 #pragma unroll
-    for (int b = 0; b < 32; b += kTwBatch) {
-#pragma unroll
-        for (int q = b; q < b + kTwBatch; ++q)
-            if (q) x[q] = cmulc(x[q], t.tw1024[32 * q + l]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int b = 0; b < 32; b += kTwBatch) twiddle_batch<true, true>(x, tab, b, [](int q) { return q; });
     }
     transpose32(x, tile_half, l, [](int q) { return q; });
     __builtin_amdgcn_sched_barrier(0);
@@ -225,13 +235,9 @@ __device__ __forceinline__ void wave_fft_inv(cf (&x)[32], cf (&c)[16], float* ti
     __builtin_amdgcn_sched_barrier(0);
     // lag q = l + 32*qb sits in x[bitrev5(qb)]; the odd half carries exp(+2*pi*i*q/2048)
     if (h) {
+        const cf* tab = t.tw2048 + launder(l);
 #pragma unroll
-        for (int b = 0; b < 32; b += kTwBatch) {
-            const cf* row = t.tw2048 + 32 * b + launder(l);
-#pragma unroll
-            for (int j = 0; j < kTwBatch; ++j) x[bitrev5(b + j)] = cmulc(x[bitrev5(b + j)], row[32 * j]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int b = 0; b < 32; b += kTwBatch) twiddle_batch<true, false>(x, tab, b, [](int qb) { return bitrev5(qb); });
     }
     // c[q] = even[q] + odd[q].  Registers bitrev5(qb) and bitrev5(qb+16) = bitrev5(qb)+1 are swapped across the
     // half-waves so the low half finishes qb = 0..15 and the high half qb = 16..31.

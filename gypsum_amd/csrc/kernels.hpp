@@ -362,6 +362,12 @@ __global__ __launch_bounds__(Geom<K>::kThreads, 2) void corr_cells_pipe_kernel(C
         float mag[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) mag[j] = 0.f;
+        cf prn[32];   // this satellite's replica spectrum stays in registers for all the cell's blocks
+        {
+            const cf* row = rep + launder(lane);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) prn[i] = row[64 * i];
+        }
         StagedSamples<K> smp;
         {   // prologue: block 0 staged into buffer 0, block 1 in flight
             cf* y_rows[W];
@@ -377,13 +383,6 @@ __global__ __launch_bounds__(Geom<K>::kThreads, 2) void corr_cells_pipe_kernel(C
         for (int ms = 0; ms < p.n_ms; ++ms) {
             cf* cur = sm.xch + (ms & 1) * (W * kXchWave);
             cf* nxt = sm.xch + ((ms + 1) & 1) * (W * kXchWave);
-            cf prn[32];   // this satellite's replica spectrum, requested now and used after the forward transform
-            {
-                const cf* row = rep + launder(lane);
-#pragma unroll
-                for (int i = 0; i < 32; ++i) prn[i] = row[64 * i];
-            }
-            __builtin_amdgcn_sched_barrier(0);
             if (ms + 1 < p.n_ms) {   // uniform
                 cf* y_rows[W];
 #pragma unroll
@@ -402,7 +401,6 @@ __global__ __launch_bounds__(Geom<K>::kThreads, 2) void corr_cells_pipe_kernel(C
 #pragma unroll
             for (int i = 0; i < 32; ++i) x[i] = cmul(x[i], prn[i]);
             __builtin_amdgcn_sched_barrier(0);
-            // the replica registers are dead: fetch the block after next into them while the inverse transform runs
             if (ms + 2 < p.n_ms) stage_fetch<K>(stream + (int64_t)(ms + 2) * N, smp, tid);
             __builtin_amdgcn_sched_barrier(0);
             wave_fft_inv(x, c, tile_half, tables, l, h);
