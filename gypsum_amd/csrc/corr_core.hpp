@@ -34,6 +34,24 @@ constexpr int kTwBatch = GYP_TW_BATCH;   // twiddle / replica values fetched per
 // Hide a thread-id-derived value from the optimiser so that everything computed from it is re-derived where it
 // is used (a handful of integer instructions) instead of being hoisted out of the per-millisecond loop as a
 // loop invariant and then spilled: every scratch reload is a ~250-cycle stall in these latency-bound kernels.
+// Compiler-level fence: no load or store is moved across it by any pass (sched_barrier only binds the machine
+// scheduler; IR passes still hoist loads over it).
+__device__ __forceinline__ void pin_memory_order() { asm volatile("" ::: "memory"); }
+
+// launder() whose result additionally "depends" on `after`: whatever is addressed through it cannot be issued
+// before `after` has been computed (keeps prefetches where they were written instead of wherever the scheduler
+// hoists them to, which both inflates register pressure and drags their latency under an early s_waitcnt).
+__device__ __forceinline__ int launder_after(int v, float after) {
+    asm volatile("" : "+v"(v) : "v"(after));
+    return v;
+}
+// Forces the 32 values to be materialised at this point of the program: without it LLVM sinks pure VALU work (a
+// whole FFT32 + the spectrum multiply) below a later conditional block, which puts that block's loads -- and the
+// s_waitcnt the register allocator's copies need -- in front of the arithmetic they were meant to overlap.
+__device__ __forceinline__ void pin_values(cf (&x)[32]) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(x[i].x), "+v"(x[i].y));
+}
 __device__ __forceinline__ int launder(int v) {
     asm volatile("" : "+v"(v));
     return v;
@@ -98,6 +116,14 @@ __device__ __forceinline__ cf twiddle32(cf v, int t) {
                    : make_float2(fmaf(v.x, c, -v.y * s), fmaf(v.y, c, v.x * s));
 }
 
+// Between the radix-2 stages of a register FFT: with GYP_FFT_STAGE_FENCES the machine scheduler may not interleave
+// butterflies of different stages (shorter live ranges of temporaries at the price of less freedom).
+#ifdef GYP_FFT_STAGE_FENCES
+#define GYP_FFT_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define GYP_FFT_STAGE_FENCE() ((void)0)
+#endif
+
 // 32-point DFT, decimation in frequency: natural-order input, X[k] lands in x[bitrev5(k)].
 template <int DIR>
 __device__ __forceinline__ void fft32_dif(cf (&x)[32]) {
@@ -113,6 +139,7 @@ __device__ __forceinline__ void fft32_dif(cf (&x)[32]) {
                 x[g + j + half] = twiddle32<DIR>(csub(a, b), j << s);
             }
         }
+        GYP_FFT_STAGE_FENCE();
     }
 }
 
@@ -132,6 +159,7 @@ __device__ __forceinline__ void fft32_dit(cf (&x)[32]) {
                 x[g + j + half] = csub(a, b);
             }
         }
+        GYP_FFT_STAGE_FENCE();
     }
 }
 
@@ -439,6 +467,86 @@ __device__ __forceinline__ void stage_emit(StagedSamples<K>& s, double u0, doubl
             for (int r = 0; r < K; ++r) y_rows[r][m] = make_float2(0.f, 0.f);
         }
     }
+}
+
+// Halo-free variant of the split staging (K >= 2, workgroup of K wavefronts): a thread fetches and wipes ONLY its
+// chips' own K samples (half the loads, half the wipes, 2K instead of 4K-2 registers per chip) and forms
+//   y_r[m] = S_r(m) + P_r(m+1),   S_r = sum_{i>=r} w[i]  (suffix sums),  P_r = sum_{i<r} w[i]  (prefix sums),
+// where the neighbour chip's prefix sums arrive from the next lane through the DPP network (wave_shl:1).  Lane 63
+// has no next lane: it receives 0, and the prefix sums of every wavefront's lane-0 chips are published in a small
+// LDS table `halo[c][wave][r]` from which the row loader (halo_fixup) completes those sixteen chips.
+template <int K>
+struct OwnSamples {
+    static constexpr int T = 64 * K;
+    static constexpr int CH = (kChips + T - 1) / T;
+    cf w[CH][K];
+};
+template <int K>
+__device__ __forceinline__ void stage_fetch_own(const cf* __restrict__ block, OwnSamples<K>& s, int tid) {
+#pragma unroll
+    for (int c = 0; c < OwnSamples<K>::CH; ++c) {
+        const int m = tid + c * OwnSamples<K>::T;
+        if (m < kChips) {
+            load_samples<K>(block + K * m, s.w[c]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < K; ++i) s.w[c][i] = make_float2(0.f, 0.f);   // the padding chip: S = P = 0
+        }
+    }
+}
+__device__ __forceinline__ cf next_lane(cf v) {   // lane i <- lane i+1, lane 63 <- 0
+    return make_float2(__uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v.x), 0x130, 0xF, 0xF, false)),
+                       __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v.y), 0x130, 0xF, 0xF, false)));
+}
+template <int K>
+__device__ __forceinline__ void stage_emit_own(OwnSamples<K>& s, double u0, double du, const CarrierSteps& cs,
+                                               cf* (&y_rows)[K], cf* __restrict__ halo, int tid) {
+    const cf rot1 = cs.rot1;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int c = 0; c < OwnSamples<K>::CH; ++c) {
+        const int m = tid + c * OwnSamples<K>::T;   // m == kChips (padding chip) carries zeros: writes y_r[1023] = 0
+        cf (&w)[K] = s.w[c];
+        cf car = carrier_from_cycles_fast(u0 + du * (double)(K * m));
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            w[i] = cmul(w[i], car);
+            car = cmul(car, rot1);
+        }
+        cf pre[K];   // pre[r] = P_r, pre[0] = 0
+        pre[0] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int r = 1; r < K; ++r) pre[r] = cadd(pre[r - 1], w[r - 1]);
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < K; ++r) halo[(c * K + wave) * K + r] = pre[r];
+        }
+        cf suf = make_float2(0.f, 0.f);   // running S_r from r = K-1 down
+#pragma unroll
+        for (int r = K - 1; r >= 1; --r) {
+            suf = cadd(suf, w[r]);
+            y_rows[r][m] = cadd(suf, next_lane(pre[r]));
+        }
+        y_rows[0][m] = cadd(suf, w[0]);
+    }
+}
+// Row loader side: x[j] holds y[32*j + l] of branch `r`; chips 63 + 64*k (k = 0..14) take P_r of chip 64*(k+1),
+// chip 1022 takes P_r of chip 0 (the block is circular; the wipe-off of a wrapped sample is the one of its index).
+template <int K>
+__device__ __forceinline__ void halo_fixup(cf (&x)[32], const cf* __restrict__ halo, int r, int l) {
+    static_assert(K == 8, "halo table layout below is for 8 wavefronts x 2 chips");
+    cf hv[16];   // all sixteen table reads are in flight before the first one is consumed
+#pragma unroll
+    for (int k = 0; k < 16; ++k) hv[k] = halo[k * K + r];   // table index (c*K + wave) == k; uniform address: broadcast
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+        x[2 * k + 1].x += (l == 31) ? hv[k + 1].x : 0.f;
+        x[2 * k + 1].y += (l == 31) ? hv[k + 1].y : 0.f;
+    }
+    x[31].x += (l == 30) ? hv[0].x : 0.f;
+    x[31].y += (l == 30) ? hv[0].y : 0.f;
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // General staging: the W branches r = rho*W .. rho*W + W-1 of a K-samples-per-chip stream (K a multiple of W),

@@ -343,7 +343,8 @@ static int launch_cells(gyp_ctx* ctx, const CellsParams& p, int integration) {
     const bool coh = integration == GYP_COHERENT;
     if (!coh && ctx->k == 8 && !ctx->no_pipe) {   // one pipelined workgroup per CU (256 VGPRs, double-buffered LDS)
         const int grid1 = std::max(1, std::min(p.n_cells, ctx->n_cus) & ~7);
-        return launch_k(ctx, corr_cells_pipe_kernel<8>, 8, grid1, p, lds_bytes_pipe<8>());
+        return p.prof ? launch_k(ctx, corr_cells_pipe_kernel<8, true>, 8, grid1, p, lds_bytes_pipe<8>())
+                      : launch_k(ctx, corr_cells_pipe_kernel<8, false>, 8, grid1, p, lds_bytes_pipe<8>());
     }
     switch (ctx->k) {
 #define X(K) case K: return coh ? launch_k(ctx, corr_cells_kernel<K, true>, K, grid, p, lds_bytes<K>()) \
@@ -400,6 +401,7 @@ int gyp_correlate_cells_dev(gyp_ctx* ctx, const float* iq_dev, int64_t stream_st
     p.replica_table = ctx->d_replicas;
     p.tw_tables = ctx->d_tw;
     p.inv_fs = 1.0 / (double)ctx->fs;
+    p.prof = ctx->d_prof;
     return launch_cells(ctx, p, integration);
 }
 

@@ -243,6 +243,7 @@ struct CellsParams {
     const cf* replica_table;
     const cf* tw_tables;
     double inv_fs;
+    long long* prof;   // optional: per-phase cycle counters of workgroup 0 of the pipelined kernel (debug)
 };
 
 template <int K, bool COHERENT>
@@ -330,10 +331,11 @@ __global__ __launch_bounds__(Geom<K>::kThreads, (K == 8 && !COHERENT) ? GYP_CELL
 // and two row/tile buffers in LDS: while the wavefronts transform block ms out of one buffer, the samples of block
 // ms+1 (fetched during the previous iteration) are wiped and staged into the other, and the loads of block ms+2 are
 // in flight.  One workgroup barrier per millisecond instead of two, no exposed global-load latency.
+constexpr int kHaloBytes = 2 * 8 * 8 * 8;   // [chip-of-thread][wave][branch] complex, per row buffer
 template <int K>
-constexpr int lds_bytes_pipe() { return 2 * kTablesBytes + 2 * Geom<K>::W * kXchWaveBytes + kRedBytes; }
+constexpr int lds_bytes_pipe() { return 2 * kTablesBytes + 2 * Geom<K>::W * kXchWaveBytes + kRedBytes + 2 * kHaloBytes; }
 
-template <int K>
+template <int K, bool PROF>
 __global__ __launch_bounds__(Geom<K>::kThreads, 2) void corr_cells_pipe_kernel(CellsParams p) {
     static_assert(Geom<K>::R == 1, "pipelined cells need all K branches resident");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -345,9 +347,13 @@ __global__ __launch_bounds__(Geom<K>::kThreads, 2) void corr_cells_pipe_kernel(C
     sm.tw2048 = tw2048;
     sm.xch = tw2048 + 1024;
     sm.red = reinterpret_cast<RedScratch*>(smem_raw + 2 * kTablesBytes + 2 * W * kXchWaveBytes);
+    cf* halo_base = reinterpret_cast<cf*>(smem_raw + 2 * kTablesBytes + 2 * W * kXchWaveBytes + kRedBytes);
     for (int i = threadIdx.x; i < 2048; i += Geom<K>::kThreads) sm.tw1024[i] = p.tw_tables[i];
     __syncthreads();
     const LdsTables tables{sm.tw1024, sm.tw2048};
+    const bool prof = PROF && p.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+    long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define GYP_TICK(var) const long long var = PROF ? (long long)__builtin_readcyclecounter() : 0
     for (int v = blockIdx.x; v < p.n_cells; v += gridDim.x) {
         const int cell = xcd_contiguous(v, p.n_cells);
         const gyp_cell_desc d = p.cells[cell];
@@ -362,20 +368,22 @@ __global__ __launch_bounds__(Geom<K>::kThreads, 2) void corr_cells_pipe_kernel(C
         float mag[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) mag[j] = 0.f;
-        cf prn[32];   // this satellite's replica spectrum stays in registers for all the cell's blocks
+        // This satellite's replica spectrum stays in registers for all the cell's blocks: re-reading it every
+        // millisecond cost 4 exposed L2 latencies (the sample stream flushes it out of L1), 26 % of the iteration.
+        cf prn[32];
         {
             const cf* row = rep + launder(lane);
 #pragma unroll
             for (int i = 0; i < 32; ++i) prn[i] = row[64 * i];
         }
-        StagedSamples<K> smp;
+        OwnSamples<K> smp;
         {   // prologue: block 0 staged into buffer 0, block 1 in flight
             cf* y_rows[W];
 #pragma unroll
             for (int r = 0; r < W; ++r) y_rows[r] = sm.xch + r * kXchWave;
-            stage_fetch<K>(stream, smp, tid);
-            stage_emit<K>(smp, 0.0, du, cs, y_rows, tid);
-            if (p.n_ms > 1) stage_fetch<K>(stream + N, smp, tid);
+            stage_fetch_own<K>(stream, smp, tid);
+            stage_emit_own<K>(smp, 0.0, du, cs, y_rows, halo_base, tid);
+            if (p.n_ms > 1) stage_fetch_own<K>(stream + N, smp, tid);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
@@ -383,30 +391,44 @@ __global__ __launch_bounds__(Geom<K>::kThreads, 2) void corr_cells_pipe_kernel(C
         for (int ms = 0; ms < p.n_ms; ++ms) {
             cf* cur = sm.xch + (ms & 1) * (W * kXchWave);
             cf* nxt = sm.xch + ((ms + 1) & 1) * (W * kXchWave);
+            GYP_TICK(t_a);
             if (ms + 1 < p.n_ms) {   // uniform
                 cf* y_rows[W];
 #pragma unroll
                 for (int r = 0; r < W; ++r) y_rows[r] = nxt + r * kXchWave;
-                stage_emit<K>(smp, u0_step * (double)(ms + 1), du, cs, y_rows, tid);
+                stage_emit_own<K>(smp, u0_step * (double)(ms + 1), du, cs, y_rows, halo_base + ((ms + 1) & 1) * (kHaloBytes / 8), tid);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            GYP_TICK(t_b);
             cf x[32];
             const cf* yw = cur + wave * kXchWave;
 #pragma unroll
             for (int j = 0; j < 32; ++j) x[j] = yw[32 * j + l];
+            halo_fixup<K>(x, halo_base + (ms & 1) * (kHaloBytes / 8), wave, l);
             wave_lds_fence();
             float* tile_half = reinterpret_cast<float*>(cur + wave * kXchWave) + h * kXchTile;
             cf c[16];
             wave_fft_fwd(x, tile_half, tables, l, h);
+            GYP_TICK(t_c);
 #pragma unroll
             for (int i = 0; i < 32; ++i) x[i] = cmul(x[i], prn[i]);
+            pin_values(x);
             __builtin_amdgcn_sched_barrier(0);
-            if (ms + 2 < p.n_ms) stage_fetch<K>(stream + (int64_t)(ms + 2) * N, smp, tid);
+            // requested now, consumed at the top of the next iteration: a whole inverse transform to arrive.  The
+            // thread index is laundered here so that the addresses are re-derived (a few VALU ops) instead of being
+            // hoisted out of the loop, spilled, and reloaded behind an s_waitcnt vmcnt(0) that serialises the fetch
+            if (ms + 2 < p.n_ms) stage_fetch_own<K>(stream + (int64_t)(ms + 2) * N, smp, launder(tid));
             __builtin_amdgcn_sched_barrier(0);
+            GYP_TICK(t_d);
             wave_fft_inv(x, c, tile_half, tables, l, h);
 #pragma unroll
             for (int j = 0; j < 16; ++j) mag[j] += __builtin_amdgcn_sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
+            GYP_TICK(t_e);
             __syncthreads();   // next buffer fully staged; this buffer's tiles free for the block after next
+            if (PROF) {
+                const long long t_f = (long long)__builtin_readcyclecounter();
+                tp[0] += t_b - t_a; tp[1] += t_c - t_b; tp[2] += t_d - t_c; tp[3] += t_e - t_d; tp[4] += t_f - t_e; tp[5] += 1;
+            }
         }
         LaneStats ls = lane_stats_init();
         lane_stats_update<K, false>(ls, mag, nullptr, 0, tid, [](int idx) { return idx; });
@@ -428,6 +450,8 @@ __global__ __launch_bounds__(Geom<K>::kThreads, 2) void corr_cells_pipe_kernel(C
             o->tap_im = 0.f;
         }
     }
+#undef GYP_TICK
+    if (prof) for (int i = 0; i < 8; ++i) p.prof[i] = tp[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------
