@@ -474,7 +474,7 @@ __device__ __forceinline__ void stage_emit(StagedSamples<K>& s, double u0, doubl
 //   y_r[m] = S_r(m) + P_r(m+1),   S_r = sum_{i>=r} w[i]  (suffix sums),  P_r = sum_{i<r} w[i]  (prefix sums),
 // where the neighbour chip's prefix sums arrive from the next lane through the DPP network (wave_shl:1).  Lane 63
 // has no next lane: it receives 0, and the prefix sums of every wavefront's lane-0 chips are published in a small
-// LDS table `halo[c][wave][r]` from which the row loader (halo_fixup) completes those sixteen chips.
+// LDS table `halo[m / 64][r]` (16 x K entries) from which the row loader (halo_fixup) completes those sixteen chips.
 template <int K>
 struct OwnSamples {
     static constexpr int T = 64 * K;
@@ -502,7 +502,7 @@ template <int K>
 __device__ __forceinline__ void stage_emit_own(OwnSamples<K>& s, double u0, double du, const CarrierSteps& cs,
                                                cf* (&y_rows)[K], cf* __restrict__ halo, int tid) {
     const cf rot1 = cs.rot1;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
 #pragma unroll
     for (int c = 0; c < OwnSamples<K>::CH; ++c) {
         const int m = tid + c * OwnSamples<K>::T;   // m == kChips (padding chip) carries zeros: writes y_r[1023] = 0
@@ -519,7 +519,7 @@ __device__ __forceinline__ void stage_emit_own(OwnSamples<K>& s, double u0, doub
         for (int r = 1; r < K; ++r) pre[r] = cadd(pre[r - 1], w[r - 1]);
         if (lane == 0) {
 #pragma unroll
-            for (int r = 0; r < K; ++r) halo[(c * K + wave) * K + r] = pre[r];
+            for (int r = 0; r < K; ++r) halo[(m >> 6) * K + r] = pre[r];   // m = 64*g for a lane-0 chip
         }
         cf suf = make_float2(0.f, 0.f);   // running S_r from r = K-1 down
 #pragma unroll
@@ -534,10 +534,9 @@ __device__ __forceinline__ void stage_emit_own(OwnSamples<K>& s, double u0, doub
 // chip 1022 takes P_r of chip 0 (the block is circular; the wipe-off of a wrapped sample is the one of its index).
 template <int K>
 __device__ __forceinline__ void halo_fixup(cf (&x)[32], const cf* __restrict__ halo, int r, int l) {
-    static_assert(K == 8, "halo table layout below is for 8 wavefronts x 2 chips");
     cf hv[16];   // all sixteen table reads are in flight before the first one is consumed
 #pragma unroll
-    for (int k = 0; k < 16; ++k) hv[k] = halo[k * K + r];   // table index (c*K + wave) == k; uniform address: broadcast
+    for (int k = 0; k < 16; ++k) hv[k] = halo[k * K + r];   // uniform address: one broadcast read each
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < 15; ++k) {

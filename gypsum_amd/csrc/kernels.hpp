@@ -41,7 +41,7 @@ struct Geom {
     static constexpr int kMinWavesPerSimd = K > 8 ? 2 : (K == 8 ? 4 : 3);
 };
 template <int K>
-constexpr int lds_bytes() { return kTablesBytes + Geom<K>::W * kXchWaveBytes + kRedBytes; }
+constexpr int lds_bytes() { return kTablesBytes + Geom<K>::W * kXchWaveBytes + kRedBytes + (K == 8 ? 1024 : 0); }
 
 struct WaveCand {   // one wavefront's candidate for the profile maximum
     float v;
@@ -85,7 +85,13 @@ struct Smem {
     const cf* tw2048;   // global
     cf* xch;
     RedScratch* red;
+    cf* halo;           // [16][K] prefix sums of the lane-0 chips (halo-free staging, K == 8 only)
 };
+constexpr int kHaloBytes = 16 * 8 * 8;
+// Halo-free staging (stage_fetch_own / stage_emit_own / halo_fixup) is used where all K branches are resident and
+// the workgroup has 8 wavefronts.
+template <int K>
+constexpr bool kOwnStaging = (K == 8);
 
 template <int K>
 __device__ __forceinline__ Smem carve_smem(char* base, const cf* __restrict__ tw_global) {
@@ -94,13 +100,14 @@ __device__ __forceinline__ Smem carve_smem(char* base, const cf* __restrict__ tw
     s.tw2048 = tw_global + 1024;
     s.xch = s.tw1024 + 1024;
     s.red = reinterpret_cast<RedScratch*>(base + kTablesBytes + Geom<K>::W * kXchWaveBytes);
+    s.halo = reinterpret_cast<cf*>(base + kTablesBytes + Geom<K>::W * kXchWaveBytes + kRedBytes);
     for (int i = threadIdx.x; i < 1024; i += Geom<K>::kThreads) s.tw1024[i] = tw_global[i];
     return s;
 }
 
 // The transform pair of one branch per wavefront on inputs already staged in LDS.
 // c[j]: complex correlation at lag index K*(l + 32*(j + 16*h)) + rho*W + wavefront.
-template <int K>
+template <int K, bool HALO = false>
 __device__ __forceinline__ void transform_staged(const Smem& sm, const cf* __restrict__ rep_table_sat, cf (&c)[16], int tid) {
     const int wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
     if (tid < Geom<K>::W) sm.xch[tid * kXchWave + kChips] = make_float2(0.f, 0.f);
@@ -109,6 +116,7 @@ __device__ __forceinline__ void transform_staged(const Smem& sm, const cf* __res
     const cf* yw = sm.xch + wave * kXchWave;
 #pragma unroll
     for (int j = 0; j < 32; ++j) x[j] = yw[32 * j + l];
+    if (HALO) halo_fixup<K>(x, sm.halo, wave, l);
     wave_lds_fence();
     float* tile_half = reinterpret_cast<float*>(sm.xch + wave * kXchWave) + h * kXchTile;
     const LdsTables t{sm.tw1024, sm.tw2048};
@@ -127,9 +135,16 @@ __device__ __forceinline__ void correlate_round(const cf* __restrict__ block, in
     cf* y_rows[W];
 #pragma unroll
     for (int r = 0; r < W; ++r) y_rows[r] = sm.xch + r * kXchWave;
-    if (Geom<K>::R == 1) stage_ms<W>(block, u0, du, cs, y_rows, tid);
-    else stage_general<K, W>(block, 1, rho, u0, 0.0, du, cs, y_rows, tid);
-    transform_staged<K>(sm, rep_table_sat, c, tid);
+    if constexpr (kOwnStaging<K>) {
+        OwnSamples<K> smp;
+        stage_fetch_own<K>(block, smp, tid);
+        stage_emit_own<K>(smp, u0, du, cs, y_rows, sm.halo, tid);
+        transform_staged<K, true>(sm, rep_table_sat, c, tid);
+    } else {
+        if (Geom<K>::R == 1) stage_ms<W>(block, u0, du, cs, y_rows, tid);
+        else stage_general<K, W>(block, 1, rho, u0, 0.0, du, cs, y_rows, tid);
+        transform_staged<K>(sm, rep_table_sat, c, tid);
+    }
 }
 
 // Coherent integration of n_blocks millisecond blocks, round rho, with ONE transform (pre-folded inputs).
@@ -331,7 +346,6 @@ __global__ __launch_bounds__(Geom<K>::kThreads, (K == 8 && !COHERENT) ? GYP_CELL
 // and two row/tile buffers in LDS: while the wavefronts transform block ms out of one buffer, the samples of block
 // ms+1 (fetched during the previous iteration) are wiped and staged into the other, and the loads of block ms+2 are
 // in flight.  One workgroup barrier per millisecond instead of two, no exposed global-load latency.
-constexpr int kHaloBytes = 2 * 8 * 8 * 8;   // [chip-of-thread][wave][branch] complex, per row buffer
 template <int K>
 constexpr int lds_bytes_pipe() { return 2 * kTablesBytes + 2 * Geom<K>::W * kXchWaveBytes + kRedBytes + 2 * kHaloBytes; }
 
