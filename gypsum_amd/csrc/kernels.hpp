@@ -6,6 +6,11 @@
 //                       |.| accumulation in registers (non-coherent), or the blocks folded before ONE transform
 //                       (coherent); finally max / first-argmax / sum / count-of-max reductions.
 //                       == utils.py:77-108 + the reductions of acquisition.py:180-189.
+//   corr_cells_pipe_kernel  the same non-coherent cell for K == 8 (8.184 Msps, the acquisition search of the headline
+//                       workload), software-pipelined: one workgroup per CU, 256 VGPRs, double-buffered rows in LDS,
+//                       next block's samples prefetched during the transforms, replica spectrum resident in registers.
+//   grid_fold_kernel / grid_cells[_wave]_kernel   flat grids whose satellites share the Doppler bins: wipe-off and
+//                       pre-sum once per (stream, bin), then transform-only workgroups / wavefronts per satellite.
 //   track_step_kernel   same core for one explicit millisecond of one tracking channel, plus the early/late taps
 //                       and the rolled-PRN argmax of tracker.py:284-313.
 //   track_block_kernel  persistent per-channel loop over many milliseconds with the DLL / Costas / lock-detector

@@ -353,7 +353,9 @@ int gyp_ingest_next_dev(gyp_ingest* ing, const float** iq_dev_out, int64_t* firs
 int gyp_ingest_times(const gyp_ingest* ing, int64_t first_ms, int32_t n_ms, double* start_out, double* end_out);
 
 /* Debug: per-phase shader-cycle counters of workgroup 0 of gyp_track_block_dev (correlate, reduce, loop update,
- * barrier, ms count).  enable != 0 arms it; out8 (may be NULL) receives the counters of the last launch. */
+ * barrier, ms count) or, for the pipelined 8.184 Msps non-coherent cells kernel behind gyp_correlate_cells_dev /
+ * gyp_acquire_dev, (stage, row load + forward, spectrum + prefetch, inverse + accumulate, barrier, iterations).
+ * enable != 0 arms it; out8 (may be NULL) receives the counters of the last launch. */
 int gyp_debug_track_profile(gyp_ctx* ctx, int enable, long long* out8);
 /* Debug: time `iters` forward+inverse wavefront transform pairs per wavefront, `wgs` workgroups of `waves_per_wg`
  * wavefronts (LDS-resident data, no global traffic): the floor the correlator kernels are measured against. */
