@@ -661,6 +661,14 @@ __device__ __forceinline__ Best wave_best(Best b) {
         r = better(r, Best{readlane_f(b.v, 16 * row), __builtin_amdgcn_readlane(b.key, 16 * row)});
     return r;
 }
+// maximum over the wavefront, uniform result
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_f<kDppXor1>(v));
+    v = fmaxf(v, dpp_f<kDppXor2>(v));
+    v = fmaxf(v, dpp_f<kDppHalfMirror>(v));
+    v = fmaxf(v, dpp_f<kDppMirror>(v));
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
+}
 __device__ __forceinline__ double wave_sum(double v) {
     v += dpp_d<kDppXor1>(v);
     v += dpp_d<kDppXor2>(v);

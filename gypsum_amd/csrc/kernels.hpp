@@ -697,6 +697,100 @@ __device__ __forceinline__ void epl_round(const cf (&c)[16], int rho, int s, Lan
     lane_stats_update<K, true>(ls, pw, c, rho, tid, [s](int idx) { int k = idx - s; return k < 0 ? k + N : k; });
 }
 
+// Single-round (K <= 8) form of epl_round + epl_finish with the profile statistics taken per WAVEFRONT instead of per
+// lane: one vector pass for the lane maxima of |c|^2 and the lane sums of |c|, one DPP max, then a scalar walk
+// (v_readlane + SALU compares) over the lanes that hold the wavefront maximum -- normally exactly one -- for the
+// first-index key, the complex value there and the count of equal maxima.  Same results as the per-lane running
+// statistics (same float summation order, ties by lowest key), ~200 fewer VALU instructions per millisecond.
+template <int K>
+__device__ __forceinline__ void epl_round_wave(const cf (&c)[16], int s, RedScratch* red, float* profile_row, int tid) {
+    static_assert(Geom<K>::R == 1, "single round only");
+    constexpr int N = K * kChips;
+    constexpr int W = Geom<K>::W;
+    const int ie = mod_n(s - 1, N), il = mod_n(s + 1, N);
+    float pw[16];   // squared magnitudes
+#pragma unroll
+    for (int j = 0; j < 16; ++j) pw[j] = fmaf(c[j].x, c[j].x, c[j].y * c[j].y);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int idx = t ? il : ie, q = idx / K, r = idx % K;
+        if ((tid >> 6) == r % W && (tid & 63) == (q & 31) + 32 * (q >> 9)) {
+            const int slot = (q >> 5) & 15;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j == slot) { red->taps[2 * t] = c[j].x; red->taps[2 * t + 1] = c[j].y; }
+        }
+    }
+    if (profile_row) {
+        const int base = lag_base<K>(tid, 0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (slot_valid(j, tid)) { int k = base + 32 * K * j - s; profile_row[k < 0 ? k + N : k] = __builtin_amdgcn_sqrtf(pw[j]); }
+    }
+    float m = -1.0f, sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const bool valid = slot_valid(j, tid);
+        m = fmaxf(m, valid ? pw[j] : -1.0f);
+        sum += valid ? __builtin_amdgcn_sqrtf(pw[j]) : 0.0f;
+    }
+    const float wmax = wave_max(m);
+    const double wsum = wave_sum((double)sum);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned wbits = __float_as_uint(wmax);   // magnitudes are >= +0: bit equality == float equality
+    unsigned long long owners = __ballot(m == wmax);
+    int best_key = 0x7fffffff, cnt = 0;
+    float bre = 0.f, bim = 0.f;
+    while (owners) {   // wave-uniform
+        const int L = __builtin_ctzll(owners);
+        owners &= owners - 1;
+        const int base = K * ((L & 31) + 512 * (L >> 5)) + wave;   // lag_base of lane L, round 0
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const unsigned vb = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(pw[j]), L);
+            if (vb == wbits && !(j == 15 && L == 63)) {
+                ++cnt;
+                int k = base + 32 * K * j - s;
+                k = k < 0 ? k + N : k;
+                if (k < best_key) {
+                    best_key = k;
+                    bre = readlane_f(c[j].x, L);
+                    bim = readlane_f(c[j].y, L);
+                }
+            }
+        }
+    }
+    if ((tid & 63) == 0) {
+        WaveCand wc;
+        wc.v = wmax; wc.key = best_key; wc.re = bre; wc.im = bim; wc.sum = wsum; wc.cnt = cnt; wc.pad = 0;
+        red->cand[wave] = wc;
+    }
+}
+template <int K>
+__device__ __forceinline__ EplResult epl_finish_wave(RedScratch* red) {
+    constexpr int W = Geom<K>::W;
+    __syncthreads();   // candidates and taps published
+    WaveCand g = red->cand[0];
+    double sum = g.sum;
+#pragma unroll
+    for (int w = 1; w < W; ++w) {
+        const WaveCand o = red->cand[w];
+        sum += o.sum;
+        if (o.v > g.v || (o.v == g.v && o.key < g.key)) g = o;
+    }
+    int n_max = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) n_max += (red->cand[w].v == g.v) ? red->cand[w].cnt : 0;
+    EplResult r;
+    r.early = make_float2(red->taps[0], red->taps[1]);
+    r.late = make_float2(red->taps[2], red->taps[3]);
+    r.peak = make_float2(g.re, g.im);
+    r.best = Best{__builtin_amdgcn_sqrtf(g.v), g.key};
+    r.sum = sum;
+    r.n_max = n_max;
+    return r;
+}
+
 template <int K>
 __device__ __forceinline__ EplResult epl_finish(const LaneStats& ls, RedScratch* red, int tid) {
     const ProfileStats st = lane_stats_finish<K, true>(ls, red, tid);   // its barrier also publishes the taps
@@ -716,6 +810,12 @@ __device__ __forceinline__ EplResult track_ms(const cf* __restrict__ block, doub
                                               int code_phase, const Smem& sm, const cf* __restrict__ rep, float* profile_row) {
     constexpr int N = K * kChips;
     const int s = mod_n(code_phase, N);
+    if constexpr (Geom<K>::R == 1) {
+        cf c[16];
+        correlate_round<K>(block, 0, u0, du, cs, sm, rep, c);
+        epl_round_wave<K>(c, s, sm.red, profile_row, launder(threadIdx.x));
+        return epl_finish_wave<K>(sm.red);
+    }
     LaneStats ls = lane_stats_init();
 #pragma unroll 1
     for (int rho = 0; rho < Geom<K>::R; ++rho) {
