@@ -113,8 +113,8 @@ struct gyp_ctx {
     uint8_t* d_chips = nullptr;  // [32][1023], synthetic generator only
     long long* d_prof = nullptr; // debug: per-phase cycle counters of track_block workgroup 0
     // growable scratch for the host-buffer entry points and the acquisition driver
-    void* scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_cap[6] = {0, 0, 0, 0, 0, 0};
+    void* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 struct gyp_bank {
@@ -187,7 +187,7 @@ void gyp_destroy(gyp_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 8; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->d_replicas) (void)hipFree(ctx->d_replicas);
     if (ctx->d_tw) (void)hipFree(ctx->d_tw);
@@ -476,10 +476,24 @@ int gyp_correlate_grid_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams,
     switch (ctx->k) {
 #define X(K)                                                                                                                  \
     case K: {                                                                                                                 \
-        const dim3 fgrid((unsigned)n_units, (unsigned)n_blk, (unsigned)Geom<K>::R);                                            \
-        if (coh) hipLaunchKernelGGL((grid_fold_kernel<K, true>), fgrid, dim3(threads_for(K)), 0, ctx->stream, p);             \
-        else hipLaunchKernelGGL((grid_fold_kernel<K, false>), fgrid, dim3(threads_for(K)), 0, ctx->stream, p);                \
-        HIP_TRY(ctx, hipGetLastError());                                                                                      \
+        if (K > 8) { /* wide rates: coalesced wipe-off into z, then the K-sample boxcar out of LDS tiles */                 \
+            const size_t zbytes = (size_t)n_units * n_blk * (K * kChips) * sizeof(cf);                                         \
+            int rcz;                                                                                                           \
+            if ((rcz = ensure_scratch(ctx, 6, zbytes))) return rcz;                                                            \
+            cf* zbuf = (cf*)ctx->scratch[6];                                                                                    \
+            const dim3 wgrid((unsigned)((K * kChips + 255) / 256), (unsigned)n_blk, (unsigned)n_units);                        \
+            if (coh) hipLaunchKernelGGL((grid_wipe_kernel<K, true>), wgrid, dim3(256), 0, ctx->stream, p, zbuf);              \
+            else hipLaunchKernelGGL((grid_wipe_kernel<K, false>), wgrid, dim3(256), 0, ctx->stream, p, zbuf);                 \
+            HIP_TRY(ctx, hipGetLastError());                                                                                  \
+            hipLaunchKernelGGL(grid_boxcar_kernel<K>, dim3(8, (unsigned)n_blk, (unsigned)n_units), dim3(128), 0, ctx->stream,   \
+                               p, (const cf*)zbuf, n_blk);                                                                     \
+            HIP_TRY(ctx, hipGetLastError());                                                                                  \
+        } else {                                                                                                              \
+            const dim3 fgrid((unsigned)n_units, (unsigned)n_blk, (unsigned)Geom<K>::R);                                        \
+            if (coh) hipLaunchKernelGGL((grid_fold_kernel<K, true>), fgrid, dim3(threads_for(K)), 0, ctx->stream, p);         \
+            else hipLaunchKernelGGL((grid_fold_kernel<K, false>), fgrid, dim3(threads_for(K)), 0, ctx->stream, p);            \
+            HIP_TRY(ctx, hipGetLastError());                                                                                  \
+        }                                                                                                                     \
         if (n_blk == 1 && K <= 8) { /* one wavefront per cell, no barriers */                                                \
             const size_t lds = kTablesBytes + 8 * kXchWaveBytes;                                                               \
             const int wgrid = std::max(1, std::min((n_cells + 7) / 8, ctx->n_cus * 2));                                        \

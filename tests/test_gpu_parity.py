@@ -262,3 +262,32 @@ def test_config5_grid_slice_against_oracle(engine_factory):
             assert g["peak"][si, bi] == pytest.approx(ref.max(), rel=RTOL_MAG)
             assert eng.cell_strength(g[si, bi:bi + 1])[0] == pytest.approx(orc.peak_strength(ref), rel=RTOL_MAG)
     assert g["argmax"][0, 1] == s0.code_phase and g["peak"][0, 1] == g["peak"][0].max()
+
+
+@pytest.mark.parametrize("fs", [16_368_000, 49_104_000])
+def test_wide_rate_grid_fold_equals_per_cell_path(engine_factory, fs):
+    """K > 8: the coalesced wipe + LDS boxcar fold of the grid entry point against the per-cell kernels (which stage
+    per chip), both integration kinds, several blocks, two streams."""
+    from gypsum_amd import synth
+
+    n = fs // 1000
+    eng = engine_factory(fs, n)
+    scene = synth.random_scene(fs, 3, 2, 777, max_doppler=9000.0, with_nav_bits=False)
+    iq = synth.render(scene)
+    iq2 = np.concatenate([iq, np.conj(iq[::-1])]).astype(np.complex64)
+    sats = [scene.sats[0].sat_id, scene.sats[1].sat_id, 17]
+    dopp = [round(scene.sats[0].doppler_hz), -2750.0, 0.0, 8999.0]
+    for integ in (GYP_NON_COHERENT, GYP_COHERENT):
+        g = eng.correlate_grid(iq2, 2, 3, sats, dopp, integ)
+        cells = np.zeros((2, len(sats), len(dopp)), dtype=CELL_DESC)
+        cells["stream"] = np.arange(2)[:, None, None]
+        cells["sat_id"] = np.array(sats)[None, :, None]
+        cells["doppler_hz"] = np.array(dopp)[None, None, :]
+        cells["tap_index"] = -1
+        c, _ = eng.correlate_cells(iq2, 2, 3, cells.reshape(-1), integ)
+        c = c.reshape(g.shape)
+        assert np.array_equal(g["argmax"], c["argmax"])
+        np.testing.assert_allclose(g["peak"], c["peak"], rtol=3e-6)
+        np.testing.assert_allclose(g["sum"], c["sum"], rtol=3e-6)
+        assert np.array_equal(g["n_max"], c["n_max"])
+    assert g["argmax"][0, 0, 0] == scene.sats[0].code_phase
