@@ -249,6 +249,57 @@ __device__ __forceinline__ ProfileStats lane_stats_finish(const LaneStats& ls, R
     return st;
 }
 
+// Per-WAVEFRONT statistics of one round's 16 values per lane: one vector pass for the lane maxima and lane sums, one
+// DPP max, then a scalar walk (v_readlane + SALU compares) over the lanes holding the wavefront maximum -- normally
+// exactly one -- for the lowest key among the equal maxima, their count, and the complex value at the winner.
+// `sum_of(j)` is what slot j adds to the sum (|c| where vals are squared magnitudes); `key_of(L, j)` is wave-uniform.
+// Same answers as LaneStats (same per-lane float summation order, ties by lowest key) for ~1/4 of the VALU work.
+struct WaveProfile {
+    float vmax;
+    int key, cnt;
+    float re, im;
+    double sum;
+};
+template <typename SumOf, typename KeyOf>
+__device__ __forceinline__ WaveProfile wave_profile(const float (&vals)[16], const cf* cvals, int tid, SumOf sum_of, KeyOf key_of) {
+    float m = -1.0f, sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const bool valid = slot_valid(j, tid);
+        m = fmaxf(m, valid ? vals[j] : -1.0f);
+        sum += valid ? sum_of(j) : 0.0f;
+    }
+    WaveProfile r;
+    r.vmax = wave_max(m);
+    r.sum = wave_sum((double)sum);
+    r.key = 0x7fffffff;
+    r.cnt = 0;
+    r.re = 0.f;
+    r.im = 0.f;
+    const unsigned wbits = __float_as_uint(r.vmax);   // values are >= +0: bit equality == float equality
+    unsigned long long owners = __ballot(m == r.vmax);
+    while (owners) {   // wave-uniform
+        const int L = __builtin_ctzll(owners);
+        owners &= owners - 1;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const unsigned vb = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(vals[j]), L);
+            if (vb == wbits && !(j == 15 && L == 63)) {
+                ++r.cnt;
+                const int k = key_of(L, j);
+                if (k < r.key) {
+                    r.key = k;
+                    if (cvals) {
+                        r.re = readlane_f(cvals[j].x, L);
+                        r.im = readlane_f(cvals[j].y, L);
+                    }
+                }
+            }
+        }
+    }
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // correlation cells (acquisition building block)
 // ---------------------------------------------------------------------------------------------------------
@@ -652,9 +703,11 @@ __global__ __launch_bounds__(512, 4) void grid_cells_wave_kernel(GridParams p) {
     float* tile_half = reinterpret_cast<float*>(tiles + wave * kXchWave) + h * kXchTile;
     const LdsTables t{tw1024, p.tw_tables + 1024};
     for (int v = blockIdx.x * 8 + wave; v < n_cells; v += gridDim.x * 8) {
-        // consecutive wavefronts of a workgroup take consecutive bins of one satellite: one replica, neighbouring inputs
+        // satellites vary fastest: the 32 satellites of one (stream, bin) unit run back to back inside one XCD's slice, so
+        // a unit's folded rows come from HBM once and from L1/L2 31 times (the 512 KB of replicas always hit L2)
         const int cell = (n_cells & 7) ? v : xcd_contiguous(v >> 3, n_cells >> 3) * 8 + (v & 7);
-        const int bin = cell % p.n_bins, sat = (cell / p.n_bins) % p.n_sats, stream = cell / (p.n_bins * p.n_sats);
+        const int sat = cell % p.n_sats, bin = (cell / p.n_sats) % p.n_bins, stream = cell / (p.n_bins * p.n_sats);
+        const int out_index = (stream * p.n_sats + sat) * p.n_bins + bin;
         const cf* rep = replica_of(p.replica_table, p.sat_ids[sat] - 1);
         const cf* unit = p.folded + (int64_t)(stream * p.n_bins + bin) * K * 1024;
         // running statistics are reduced over the wavefront after every branch and kept wave-uniform (scalar
@@ -672,30 +725,20 @@ __global__ __launch_bounds__(512, 4) void grid_cells_wave_kernel(GridParams p) {
             wave_fft_fwd(x, tile_half, t, l, h);
             spectrum_mul_from(x, rep, lane);
             wave_fft_inv(x, c, tile_half, t, l, h);
-            const int base = K * (l + 512 * h) + r;          // lag index of slot j: base + 32*K*j
-            LaneStats ls = lane_stats_init();
+            float mag[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const bool valid = slot_valid(j, tid);
-                const float m = __builtin_amdgcn_sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
-                const float vv = valid ? m : -1.0f;
-                const int key = base + 32 * K * j;
-                ls.sum += valid ? m : 0.0f;
-                const bool gt = vv > ls.b.v, eq = vv == ls.b.v;
-                ls.cnt = gt ? 1 : ls.cnt + (eq ? 1 : 0);
-                ls.b.key = (gt || (eq && key < ls.b.key)) ? key : ls.b.key;
-                ls.b.v = gt ? vv : ls.b.v;
-            }
-            const Best rb = wave_best(ls.b);
-            const int rc = wave_sum(ls.b.v == rb.v ? ls.cnt : 0);
-            sum += wave_sum((double)ls.sum);
-            if (rb.v > wb.v) { wb = rb; cnt = rc; }
-            else if (rb.v == wb.v) { cnt += rc; wb.key = rb.key < wb.key ? rb.key : wb.key; }
+            for (int j = 0; j < 16; ++j) mag[j] = __builtin_amdgcn_sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
+            const WaveProfile wp = wave_profile(
+                mag, nullptr, tid, [&](int j) { return mag[j]; },
+                [&](int L, int j) { return K * ((L & 31) + 512 * (L >> 5)) + r + 32 * K * j; });   // lag index
+            sum += wp.sum;
+            if (wp.vmax > wb.v) { wb = Best{wp.vmax, wp.key}; cnt = wp.cnt; }
+            else if (wp.vmax == wb.v) { cnt += wp.cnt; wb.key = wp.key < wb.key ? wp.key : wb.key; }
         }
         if (lane == 0) {
             gyp_cell o;
             o.peak = wb.v; o.argmax = wb.key; o.sum = sum; o.n_max = cnt; o.reserved = 0; o.tap_re = 0.f; o.tap_im = 0.f;
-            p.out[cell] = o;
+            p.out[out_index] = o;
         }
     }
 }
@@ -792,42 +835,16 @@ __device__ __forceinline__ void epl_round_wave(const cf (&c)[16], int s, RedScra
         for (int j = 0; j < 16; ++j)
             if (slot_valid(j, tid)) { int k = base + 32 * K * j - s; profile_row[k < 0 ? k + N : k] = __builtin_amdgcn_sqrtf(pw[j]); }
     }
-    float m = -1.0f, sum = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const bool valid = slot_valid(j, tid);
-        m = fmaxf(m, valid ? pw[j] : -1.0f);
-        sum += valid ? __builtin_amdgcn_sqrtf(pw[j]) : 0.0f;
-    }
-    const float wmax = wave_max(m);
-    const double wsum = wave_sum((double)sum);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned wbits = __float_as_uint(wmax);   // magnitudes are >= +0: bit equality == float equality
-    unsigned long long owners = __ballot(m == wmax);
-    int best_key = 0x7fffffff, cnt = 0;
-    float bre = 0.f, bim = 0.f;
-    while (owners) {   // wave-uniform
-        const int L = __builtin_ctzll(owners);
-        owners &= owners - 1;
-        const int base = K * ((L & 31) + 512 * (L >> 5)) + wave;   // lag_base of lane L, round 0
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const unsigned vb = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(pw[j]), L);
-            if (vb == wbits && !(j == 15 && L == 63)) {
-                ++cnt;
-                int k = base + 32 * K * j - s;
-                k = k < 0 ? k + N : k;
-                if (k < best_key) {
-                    best_key = k;
-                    bre = readlane_f(c[j].x, L);
-                    bim = readlane_f(c[j].y, L);
-                }
-            }
-        }
-    }
+    const WaveProfile wp = wave_profile(
+        pw, c, tid, [&](int j) { return __builtin_amdgcn_sqrtf(pw[j]); },
+        [&](int L, int j) {
+            int k = K * ((L & 31) + 512 * (L >> 5)) + wave + 32 * K * j - s;   // lag_base of lane L, round 0
+            return k < 0 ? k + N : k;
+        });
     if ((tid & 63) == 0) {
         WaveCand wc;
-        wc.v = wmax; wc.key = best_key; wc.re = bre; wc.im = bim; wc.sum = wsum; wc.cnt = cnt; wc.pad = 0;
+        wc.v = wp.vmax; wc.key = wp.key; wc.re = wp.re; wc.im = wp.im; wc.sum = wp.sum; wc.cnt = wp.cnt; wc.pad = 0;
         red->cand[wave] = wc;
     }
 }
