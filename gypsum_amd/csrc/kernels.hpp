@@ -743,6 +743,83 @@ __global__ __launch_bounds__(512, 4) void grid_cells_wave_kernel(GridParams p) {
     }
 }
 
+// The same one-wavefront-per-cell scheme with the 256-VGPR budget (8 wavefronts per CU): the next branch's row is
+// requested before the current branch is transformed, the satellite's replica spectrum stays in registers for all K
+// branches, both twiddle tables live in LDS -- no load latency is exposed between transform pairs.  Used for the wide
+// rates (K > 8: 16 / 48 pairs per cell).
+template <int K>
+__global__ __launch_bounds__(512, 2) void grid_cells_wave_pipe_kernel(GridParams p) {
+    static_assert(K % 2 == 0, "two branches per loop iteration");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cf* tw1024 = reinterpret_cast<cf*>(smem_raw);
+    cf* tw2048 = tw1024 + 1024;
+    cf* tiles = tw2048 + 1024;
+    for (int i = threadIdx.x; i < 2048; i += 512) tw1024[i] = p.tw_tables[i];
+    __syncthreads();
+    const int n_cells = p.n_streams * p.n_sats * p.n_bins;
+    const int tid = launder(threadIdx.x);
+    const int wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
+    float* tile_half = reinterpret_cast<float*>(tiles + wave * kXchWave) + h * kXchTile;
+    const LdsTables t{tw1024, tw2048};
+    for (int v = blockIdx.x * 8 + wave; v < n_cells; v += gridDim.x * 8) {
+        const int cell = (n_cells & 7) ? v : xcd_contiguous(v >> 3, n_cells >> 3) * 8 + (v & 7);
+        const int sat = cell % p.n_sats, bin = (cell / p.n_sats) % p.n_bins, stream = cell / (p.n_bins * p.n_sats);
+        const int out_index = (stream * p.n_sats + sat) * p.n_bins + bin;
+        const cf* unit = p.folded + (int64_t)(stream * p.n_bins + bin) * K * 1024 + launder(l);
+        cf prn[32];
+        {
+            const cf* row = replica_of(p.replica_table, p.sat_ids[sat] - 1) + launder(lane);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) prn[i] = row[64 * i];
+        }
+        Best wb{-1.0f, 0x7fffffff};
+        int cnt = 0;
+        double sum = 0.0;
+        auto branch = [&](cf (&x)[32], int r) {
+            cf c[16];
+            wave_fft_fwd(x, tile_half, t, l, h);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) x[i] = cmul(x[i], prn[i]);
+            __builtin_amdgcn_sched_barrier(0);
+            wave_fft_inv(x, c, tile_half, t, l, h);
+            float mag[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) mag[j] = __builtin_amdgcn_sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
+            const WaveProfile wp = wave_profile(
+                mag, nullptr, tid, [&](int j) { return mag[j]; },
+                [&](int L, int j) { return K * ((L & 31) + 512 * (L >> 5)) + r + 32 * K * j; });
+            sum += wp.sum;
+            if (wp.vmax > wb.v) { wb = Best{wp.vmax, wp.key}; cnt = wp.cnt; }
+            else if (wp.vmax == wb.v) { cnt += wp.cnt; wb.key = wp.key < wb.key ? wp.key : wb.key; }
+        };
+        cf xa[32], xb[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) xa[j] = unit[32 * j];
+#pragma unroll 1
+        for (int r = 0; r < K; r += 2) {
+            {
+                const cf* yw = unit + (int64_t)(r + 1) * 1024;
+#pragma unroll
+                for (int j = 0; j < 32; ++j) xb[j] = yw[32 * j];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            branch(xa, r);
+            if (r + 2 < K) {
+                const cf* yw = unit + (int64_t)(r + 2) * 1024;
+#pragma unroll
+                for (int j = 0; j < 32; ++j) xa[j] = yw[32 * j];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            branch(xb, r + 1);
+        }
+        if (lane == 0) {
+            gyp_cell o;
+            o.peak = wb.v; o.argmax = wb.key; o.sum = sum; o.n_max = cnt; o.reserved = 0; o.tap_re = 0.f; o.tap_im = 0.f;
+            p.out[out_index] = o;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // tracking, one explicit millisecond
 // ---------------------------------------------------------------------------------------------------------
