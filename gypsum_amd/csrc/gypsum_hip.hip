@@ -494,12 +494,12 @@ int gyp_correlate_grid_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams,
             else hipLaunchKernelGGL((grid_fold_kernel<K, false>), fgrid, dim3(threads_for(K)), 0, ctx->stream, p);            \
             HIP_TRY(ctx, hipGetLastError());                                                                                  \
         }                                                                                                                     \
-        if (n_blk == 1 && K > 8 && !ctx->no_pipe) { /* one wavefront per cell, 256 VGPRs, next row prefetched */              \
+        if (n_blk == 1 && K >= 2 && !ctx->no_pipe) { /* one wavefront per cell, 256 VGPRs, next row prefetched */              \
             const size_t lds = 2 * kTablesBytes + 8 * kXchWaveBytes;                                                           \
             const int wgrid = std::max(1, std::min((n_cells + 7) / 8, ctx->n_cus));                                            \
-            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(grid_cells_wave_pipe_kernel<(K > 8 ? K : 16)>),     \
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(grid_cells_wave_pipe_kernel<(K >= 2 ? K : 16)>),     \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
-            hipLaunchKernelGGL(grid_cells_wave_pipe_kernel<(K > 8 ? K : 16)>, dim3(wgrid), dim3(512), lds, ctx->stream, p);     \
+            hipLaunchKernelGGL(grid_cells_wave_pipe_kernel<(K >= 2 ? K : 16)>, dim3(wgrid), dim3(512), lds, ctx->stream, p);     \
             HIP_TRY(ctx, hipGetLastError());                                                                                  \
             return GYP_OK;                                                                                                    \
         }                                                                                                                     \

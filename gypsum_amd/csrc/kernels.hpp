@@ -745,8 +745,8 @@ __global__ __launch_bounds__(512, 4) void grid_cells_wave_kernel(GridParams p) {
 
 // The same one-wavefront-per-cell scheme with the 256-VGPR budget (8 wavefronts per CU): the next branch's row is
 // requested before the current branch is transformed, the satellite's replica spectrum stays in registers for all K
-// branches, both twiddle tables live in LDS -- no load latency is exposed between transform pairs.  Used for the wide
-// rates (K > 8: 16 / 48 pairs per cell).
+// branches, both twiddle tables live in LDS -- no load latency is exposed between the transform pairs of a cell.
+// Used for every even K; K == 1 keeps grid_cells_wave_kernel.
 template <int K>
 __global__ __launch_bounds__(512, 2) void grid_cells_wave_pipe_kernel(GridParams p) {
     static_assert(K % 2 == 0, "two branches per loop iteration");
@@ -758,14 +758,25 @@ __global__ __launch_bounds__(512, 2) void grid_cells_wave_pipe_kernel(GridParams
     __syncthreads();
     const int n_cells = p.n_streams * p.n_sats * p.n_bins;
     const int tid = launder(threadIdx.x);
-    const int wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the cell bookkeeping below stays on the SALU
+    const int lane = tid & 63, l = lane & 31, h = lane >> 5;
     float* tile_half = reinterpret_cast<float*>(tiles + wave * kXchWave) + h * kXchTile;
     const LdsTables t{tw1024, tw2048};
-    for (int v = blockIdx.x * 8 + wave; v < n_cells; v += gridDim.x * 8) {
-        const int cell = (n_cells & 7) ? v : xcd_contiguous(v >> 3, n_cells >> 3) * 8 + (v & 7);
+    // satellites vary fastest (see grid_cells_wave_kernel)
+    auto cell_of = [&](int v) { return (n_cells & 7) ? v : xcd_contiguous(v >> 3, n_cells >> 3) * 8 + (v & 7); };
+    auto unit_of = [&](int cell) {
+        const int bin = (cell / p.n_sats) % p.n_bins, stream = cell / (p.n_bins * p.n_sats);
+        return p.folded + (int64_t)(stream * p.n_bins + bin) * K * 1024 + launder(l);
+    };
+    const int v_step = gridDim.x * 8;
+    for (int v = blockIdx.x * 8 + wave; v < n_cells; v += v_step) {
+        const int cell = cell_of(v);
         const int sat = cell % p.n_sats, bin = (cell / p.n_sats) % p.n_bins, stream = cell / (p.n_bins * p.n_sats);
         const int out_index = (stream * p.n_sats + sat) * p.n_bins + bin;
-        const cf* unit = p.folded + (int64_t)(stream * p.n_bins + bin) * K * 1024 + launder(l);
+        const cf* unit = unit_of(cell);
+        cf xa[32], xb[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) xa[j] = unit[32 * j];
         cf prn[32];
         {
             const cf* row = replica_of(p.replica_table, p.sat_ids[sat] - 1) + launder(lane);
@@ -792,9 +803,6 @@ __global__ __launch_bounds__(512, 2) void grid_cells_wave_pipe_kernel(GridParams
             if (wp.vmax > wb.v) { wb = Best{wp.vmax, wp.key}; cnt = wp.cnt; }
             else if (wp.vmax == wb.v) { cnt += wp.cnt; wb.key = wp.key < wb.key ? wp.key : wb.key; }
         };
-        cf xa[32], xb[32];
-#pragma unroll
-        for (int j = 0; j < 32; ++j) xa[j] = unit[32 * j];
 #pragma unroll 1
         for (int r = 0; r < K; r += 2) {
             {
@@ -804,7 +812,7 @@ __global__ __launch_bounds__(512, 2) void grid_cells_wave_pipe_kernel(GridParams
             }
             __builtin_amdgcn_sched_barrier(0);
             branch(xa, r);
-            if (r + 2 < K) {
+            if (r + 2 < K) {   // (prefetching across the cell boundary as well measured 2-5 % slower)
                 const cf* yw = unit + (int64_t)(r + 2) * 1024;
 #pragma unroll
                 for (int j = 0; j < 32; ++j) xa[j] = yw[32 * j];
