@@ -261,21 +261,28 @@ __device__ __forceinline__ void wave_fft_inv(cf (&x)[32], cf (&c)[16], float* ti
     __builtin_amdgcn_sched_barrier(0);
     fft32_dif<+1>(x);
     __builtin_amdgcn_sched_barrier(0);
-    // lag q = l + 32*qb sits in x[bitrev5(qb)]; the odd half carries exp(+2*pi*i*q/2048)
-    if (h) {
-        const cf* tab = t.tw2048 + launder(l);
+    // lag q = l + 32*qb sits in x[bitrev5(qb)] of both half-waves: the even-bin part in the low half, the odd-bin
+    // part -- still to be multiplied by exp(+2*pi*i*q/2048) -- in the high half.  Registers bitrev5(qb) and
+    // bitrev5(qb+16) = bitrev5(qb)+1 are swapped across the half-waves so that the low half finishes qb = 0..15 and
+    // the high half qb = 16..31, and the twiddle is applied there: c[q] = even[q] + w(q) * odd[q] is four FMAs on ALL
+    // lanes, instead of a 32-element multiply pass that leaves the low half idle followed by the additions.
+    const cf* tab = t.tw2048 + launder(l + 512 * h);
 #pragma unroll
-        for (int b = 0; b < 32; b += kTwBatch) twiddle_batch<true, false>(x, tab, b, [](int qb) { return bitrev5(qb); });
-    }
-    // c[q] = even[q] + odd[q].  Registers bitrev5(qb) and bitrev5(qb+16) = bitrev5(qb)+1 are swapped across the
-    // half-waves so the low half finishes qb = 0..15 and the high half qb = 16..31.
+    for (int b0 = 0; b0 < 16; b0 += kTwBatch) {
+        cf tw[kTwBatch];
 #pragma unroll
-    for (int qb = 0; qb < 16; ++qb) {
-        const int p = bitrev5(qb);
-        auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[p].x), __float_as_uint(x[p + 1].x), false, false);
-        auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[p].y), __float_as_uint(x[p + 1].y), false, false);
-        c[qb] = make_float2(__uint_as_float(rx[0]) + __uint_as_float(rx[1]),
-                            __uint_as_float(ry[0]) + __uint_as_float(ry[1]));
+        for (int j = 0; j < kTwBatch; ++j) tw[j] = tab[32 * (b0 + j)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < kTwBatch; ++j) {
+            const int qb = b0 + j, p = bitrev5(qb);
+            auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[p].x), __float_as_uint(x[p + 1].x), false, false);
+            auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[p].y), __float_as_uint(x[p + 1].y), false, false);
+            const float ex = __uint_as_float(rx[0]), ox = __uint_as_float(rx[1]);
+            const float ey = __uint_as_float(ry[0]), oy = __uint_as_float(ry[1]);
+            c[qb] = make_float2(fmaf(ox, tw[j].x, fmaf(oy, tw[j].y, ex)), fmaf(oy, tw[j].x, fmaf(-ox, tw[j].y, ey)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 

@@ -14,7 +14,7 @@ def main():
     fs, n = (8_184_000, 8184) if "--2046" not in sys.argv else (2_046_000, 2046)
     eng = GypsumEngine(0)
     eng.set_stream_format(fs, n)
-    B, T, C_ = (1 if "--single" in sys.argv else (43 if "--full" in sys.argv else 22)), 200, 12
+    B, T, C_ = (1 if "--single" in sys.argv else (42 if "--full" in sys.argv else 21)), 200, 12
     rng = np.random.default_rng(5)
     sats = np.zeros((B, C_), dtype=SYNTH_SAT)
     for s in range(B):
