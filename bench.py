@@ -327,7 +327,7 @@ def main() -> None:
                        "sample_rate_hz": fs, "streams_total": n_streams, "cells_total": int(len(flat)),
                        "parallelism": f"Doppler bins (x 32 satellites) sharded over {world} GPU(s), all-gather of cell records"},
             "samples_per_step": samples_per_step, "elapsed": elapsed, "fs": fs,
-            "dominant": {"kernel": "grid_fold_kernel<48,true> + grid_cells_kernel<48,true>", "ms": k_ms, "flops": flops,
+            "dominant": {"kernel": "grid_wipe_kernel<48,true> + grid_boxcar_kernel<48> + grid_cells_wave_pipe_kernel<48>", "ms": k_ms, "flops": flops,
                          "bytes": 8 * n * n_ms * n_streams + 32 * len(mine)},
             "extra": {"planted_sats_found_stream0": None if hits is None else f"{hits}/8"},
         }
@@ -392,7 +392,7 @@ def main() -> None:
                        "sample_rate_hz": fs, "streams_per_gpu": B, "grid_ms_per_step": T,
                        "parallelism": f"stream-ms sharded over {world} GPU(s)"},
             "samples_per_step": samples_per_step, "elapsed": elapsed, "fs": fs,
-            "dominant": {"kernel": "grid_fold_kernel<2,false> + grid_cells_kernel<2,false>", "ms": k_ms, "flops": flops,
+            "dominant": {"kernel": "grid_fold_kernel<2,false> + grid_cells_wave_pipe_kernel<2>", "ms": k_ms, "flops": flops,
                          "bytes": (8 * n + 32 * 32 * len(bins)) * n_units},
             "extra": {"visible_sats_found_stream0_ms0": f"{hits}/8"},
         }
