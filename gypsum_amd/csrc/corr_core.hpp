@@ -116,14 +116,6 @@ __device__ __forceinline__ cf twiddle32(cf v, int t) {
                    : make_float2(fmaf(v.x, c, -v.y * s), fmaf(v.y, c, v.x * s));
 }
 
-// Between the radix-2 stages of a register FFT: with GYP_FFT_STAGE_FENCES the machine scheduler may not interleave
-// butterflies of different stages (shorter live ranges of temporaries at the price of less freedom).
-#ifdef GYP_FFT_STAGE_FENCES
-#define GYP_FFT_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define GYP_FFT_STAGE_FENCE() ((void)0)
-#endif
-
 // 32-point DFT, decimation in frequency: natural-order input, X[k] lands in x[bitrev5(k)].
 template <int DIR>
 __device__ __forceinline__ void fft32_dif(cf (&x)[32]) {
@@ -139,7 +131,6 @@ __device__ __forceinline__ void fft32_dif(cf (&x)[32]) {
                 x[g + j + half] = twiddle32<DIR>(csub(a, b), j << s);
             }
         }
-        GYP_FFT_STAGE_FENCE();
     }
 }
 
@@ -159,7 +150,6 @@ __device__ __forceinline__ void fft32_dit(cf (&x)[32]) {
                 x[g + j + half] = csub(a, b);
             }
         }
-        GYP_FFT_STAGE_FENCE();
     }
 }
 
