@@ -20,10 +20,6 @@
 #include "corr_core.hpp"
 #include "../../include/gypsum_hip.h"
 
-#ifndef GYP_CELLS8_WAVES
-#define GYP_CELLS8_WAVES 4
-#endif
-
 namespace gyp {
 
 // ---------------------------------------------------------------------------------------------------------
@@ -318,7 +314,7 @@ struct CellsParams {
 };
 
 template <int K, bool COHERENT>
-__global__ __launch_bounds__(Geom<K>::kThreads, (K == 8 && !COHERENT) ? GYP_CELLS8_WAVES : Geom<K>::kMinWavesPerSimd) void corr_cells_kernel(CellsParams p) {
+__global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void corr_cells_kernel(CellsParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int N = K * kChips;
     constexpr int R = Geom<K>::R;
