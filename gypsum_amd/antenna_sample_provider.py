@@ -79,8 +79,15 @@ class AntennaSampleProviderBackedByFile(_CursorProvider):
     (`gypsum_amd.ingest.IqFileIngest`, host-only mode) instead of opening the file and `np.fromfile`-ing it for
     every millisecond (:112-117); chunks, timestamps and the end-of-data condition are unchanged."""
 
-    def __init__(self, path: Path | str, sample_rate: float, utc_start_time: float = 0.0,
+    def __init__(self, path, sample_rate: float | None = None, utc_start_time: float = 0.0,
                  sample_component_data_type=np.float32, block_ms: int = 0) -> None:
+        if hasattr(path, "sdr_sample_rate"):          # the reference's signature: one InputFileInfo (:80-86)
+            info = path
+            path, sample_rate = info.path, info.sdr_sample_rate
+            utc_start_time = info.utc_start_time.timestamp()
+            sample_component_data_type = info.sample_component_data_type
+        if sample_rate is None:
+            raise TypeError("sample_rate is required when no InputFileInfo is given")
         self.path = Path(path)
         self.cursor = 0
         self.sample_rate = sample_rate

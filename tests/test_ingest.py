@@ -166,3 +166,26 @@ def test_device_blocks_equal_numpy_recombination(tmp_path, dtype):
     first, count, dev = ing.next_device_block()
     assert (first, count) == (50, 7)
     ing.close()
+
+
+def test_provider_accepts_the_reference_descriptor(tmp_path):
+    """AntennaSampleProviderBackedByFile(InputFileInfo) as upstream constructs it (antenna_sample_provider.py:80-86)."""
+    from gypsum_amd.radio_input import (InputFileInfo, InputFileType, get_input_source_by_file_name,
+                                        register_input_source)
+
+    words = write_recording(tmp_path / "rec2x", np.float32, 5, 3, 9)
+    info = InputFileInfo.gnu_radio_recording_2x(tmp_path / "rec2x")
+    assert (info.sdr_sample_rate, info.format, info.sample_component_data_type) == (2_046_000, InputFileType.GnuRadioRecording, np.float32)
+    assert InputFileInfo.gnu_radio_recording_8x(tmp_path / "x").sdr_sample_rate == 8_184_000
+    assert InputFileInfo.gnu_radio_recording_16x(tmp_path / "x").sdr_sample_rate == 16_368_000
+    p = AntennaSampleProviderBackedByFile(info, block_ms=2)
+    assert p.get_attributes().samples_per_prn_transmission == N and p.utc_start_time == info.utc_start_time.timestamp()
+    chunk = p.get_samples(N)
+    assert np.array_equal(chunk.samples, words[0:2 * N:2] + 1j * words[1:2 * N:2])
+    with pytest.raises(FileNotFoundError):
+        get_input_source_by_file_name("rec2x")
+    register_input_source(info)
+    assert get_input_source_by_file_name("rec2x") is info
+    register_input_source(info)
+    with pytest.raises(RuntimeError):
+        get_input_source_by_file_name("rec2x")
