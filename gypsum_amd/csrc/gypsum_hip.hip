@@ -368,6 +368,8 @@ static int launch_track_step(gyp_ctx* ctx, const TrackStepParams& p) {
 template <bool PROF>
 static int launch_track_block_t(gyp_ctx* ctx, const TrackBlockParams& p) {
     const int grid = p.n_chan;
+    if (ctx->k == 8 && p.n_chan <= ctx->n_cus && !ctx->no_pipe)   // lightly loaded chip: one workgroup per CU anyway
+        return launch_k(ctx, track_block_kernel<8, PROF, true>, 8, grid, p, lds_bytes<8>() + kTablesBytes);
     switch (ctx->k) {
 #define X(K) case K: return launch_k(ctx, track_block_kernel<K, PROF>, K, grid, p, lds_bytes<K>());
         GYP_FOR_EACH_RATE(X)

@@ -990,6 +990,41 @@ __device__ __forceinline__ EplResult track_ms(const cf* __restrict__ block, doub
     return epl_finish<K>(ls, sm.red, launder(threadIdx.x));
 }
 
+// Latency form of one tracking millisecond for lightly loaded chips (one workgroup per CU, 256 VGPRs): the samples
+// were requested one loop-filter update earlier (stage_fetch_own), the replica spectrum is resident in registers,
+// and sm.tw2048 points into LDS -- no global-load latency is left on the millisecond's critical path.
+template <int K>
+__device__ __forceinline__ EplResult track_ms_fetched(OwnSamples<K>& smp, double u0, double du, const CarrierSteps& cs,
+                                                      int code_phase, const Smem& sm, const cf (&prn)[32]) {
+    static_assert(kOwnStaging<K>, "halo-free staging only");
+    constexpr int N = K * kChips;
+    constexpr int W = Geom<K>::W;
+    const int s = mod_n(code_phase, N);
+    const int tid = launder(threadIdx.x);
+    const int wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
+    cf* y_rows[W];
+#pragma unroll
+    for (int r = 0; r < W; ++r) y_rows[r] = sm.xch + r * kXchWave;
+    stage_emit_own<K>(smp, u0, du, cs, y_rows, sm.halo, tid);
+    __syncthreads();
+    cf x[32];
+    const cf* yw = sm.xch + wave * kXchWave;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) x[j] = yw[32 * j + l];
+    halo_fixup<K>(x, sm.halo, wave, l);
+    wave_lds_fence();
+    float* tile_half = reinterpret_cast<float*>(sm.xch + wave * kXchWave) + h * kXchTile;
+    const LdsTables t{sm.tw1024, sm.tw2048};
+    cf c[16];
+    wave_fft_fwd(x, tile_half, t, l, h);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) x[i] = cmul(x[i], prn[i]);
+    __builtin_amdgcn_sched_barrier(0);
+    wave_fft_inv(x, c, tile_half, t, l, h);
+    epl_round_wave<K>(c, s, sm.red, nullptr, tid);
+    return epl_finish_wave<K>(sm.red);
+}
+
 template <int K>
 __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void track_step_kernel(TrackStepParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1192,11 +1227,18 @@ __device__ __forceinline__ void workgroup_mem_fence_wave() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <int K, bool PROF>
-__global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void track_block_kernel(TrackBlockParams p) {
+// LAT: latency variant for at most one workgroup per CU (see track_ms_fetched); needs kTablesBytes more LDS.
+template <int K, bool PROF, bool LAT = false>
+__global__ __launch_bounds__(Geom<K>::kThreads, LAT ? 2 : Geom<K>::kMinWavesPerSimd) void track_block_kernel(TrackBlockParams p) {
+    static_assert(!LAT || kOwnStaging<K>, "the latency variant exists for the own-staging rates");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int N = K * kChips;
-    const Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
+    Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
+    if (LAT) {
+        cf* tw2048 = reinterpret_cast<cf*>(smem_raw + lds_bytes<K>());
+        for (int i = threadIdx.x; i < 1024; i += Geom<K>::kThreads) tw2048[i] = p.tw_tables[1024 + i];
+        sm.tw2048 = tw2048;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
     if ((int)blockIdx.x >= p.n_chan) return;
@@ -1219,6 +1261,14 @@ __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void 
     __syncthreads();
     const bool prof = PROF && p.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
     long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    OwnSamples<LAT ? K : 1> smp;   // LAT: the next millisecond's raw samples
+    cf prn[LAT ? 32 : 1];          // LAT: this satellite's replica spectrum
+    if constexpr (LAT) {
+        const cf* row = rep + launder(lane);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) prn[i] = row[64 * i];
+        if (p.n_ms > 0) stage_fetch_own<K>(stream, smp, launder(threadIdx.x));
+    }
     for (int ms = 0; ms < p.n_ms; ++ms) {
         gyp_track_rec* rec = p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + ms : nullptr;
         if (sm.red->istate[1]) {  // a dropped channel stays dropped until the host re-creates it (receiver.py:259-267)
@@ -1235,8 +1285,14 @@ __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void 
             const double t0 = p.start_time[ms];
             const double f = sm.red->dstate[0], phi = sm.red->dstate[1];
             const CarrierSteps cs = sm.red->steps;
-            r = track_ms<K>(stream + (int64_t)ms * N, f * t0 + phi * 0.15915494309189533577, f * p.inv_fs, cs,
-                            sm.red->istate[0], sm, rep, nullptr);
+            if constexpr (LAT) {
+                r = track_ms_fetched<K>(smp, f * t0 + phi * 0.15915494309189533577, f * p.inv_fs, cs, sm.red->istate[0], sm, prn);
+                // request the next millisecond now: the loads fly while wavefront 0 runs the loop filters below
+                if (ms + 1 < p.n_ms) stage_fetch_own<K>(stream + (int64_t)(ms + 1) * N, smp, launder(threadIdx.x));
+            } else {
+                r = track_ms<K>(stream + (int64_t)ms * N, f * t0 + phi * 0.15915494309189533577, f * p.inv_fs, cs,
+                                sm.red->istate[0], sm, rep, nullptr);
+            }
         }
         long long t_b = t_a;
         long long t_c = prof ? (long long)__builtin_readcyclecounter() : 0;
