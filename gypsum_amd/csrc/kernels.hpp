@@ -1110,11 +1110,14 @@ __device__ __forceinline__ LockVerdict lock_from_sums(const LockSums& s, int64_t
     const bool var_ok = ve < 900.0, i_ok = iv < 2.0;
     out.marginal = near(ve, 900.0) || near(iv, 2.0);
     bool rot_ok = true;
-    if (var_ok && i_ok) {
-        const double ang = 180.0 - pymod((atan2(s.ni * rn, s.nr * rn) / 6.283185307179586) * 360.0, 180.0);
-        const double centered = ang < 90.0 ? ang : 180.0 - ang;
-        rot_ok = centered < 6.0;                               // abs(bool) quirk, tracker.py:197
-        out.marginal = out.marginal || near(centered, 6.0);
+    if (var_ok && i_ok && s.cn >= 2) {
+        // tracker.py:190-197: the mean of the negative pole must lie within 6 degrees of the real axis (mod 180; the
+        // `abs(bool)` quirk makes it one-sided).  distance(angle, 180Z) < 6  <=>  |im| < tan(6 deg) * |re|: no atan2
+        // on the per-millisecond path; a decision within 1e-9 of the boundary goes to the exact evaluation like the
+        // variances do (with cn < 2 upstream's mean is 0+0j, angle 0: locked)
+        const double lhs = fabs(s.ni), rhs = 0.10510423526567646 * fabs(s.nr);   // tan(pi/30)
+        rot_ok = lhs < rhs;
+        out.marginal = out.marginal || fabs(lhs - rhs) <= 1e-9 * (lhs + rhs);
     }
     out.locked = var_ok && i_ok && rot_ok;
     return out;
