@@ -198,14 +198,14 @@ __device__ __forceinline__ void transpose32(cf (&x)[32], float* tile_half, int l
 // x[reg_of(g)] *= table[32*g + l] (or its conjugate) for the kTwBatch rows g = b .. b+kTwBatch-1: every load of the
 // batch is issued before the first multiply (one exposed latency per batch instead of one per element -- left to
 // itself the scheduler serialises load, wait, multiply under the 128-VGPR budget).  Row 0 of a table is 1.
-template <bool CONJ, bool SKIP_ROW0, typename RegOf>
+template <bool CONJ, bool SKIP_ROW0, int B, typename RegOf>
 __device__ __forceinline__ void twiddle_batch(cf (&x)[32], const cf* __restrict__ table_lane, int b, RegOf reg_of) {
-    cf tw[kTwBatch];
+    cf tw[B];
 #pragma unroll
-    for (int j = 0; j < kTwBatch; ++j) tw[j] = table_lane[32 * (b + j)];
+    for (int j = 0; j < B; ++j) tw[j] = table_lane[32 * (b + j)];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < kTwBatch; ++j) {
+    for (int j = 0; j < B; ++j) {
         if (SKIP_ROW0 && b + j == 0) continue;
         cf& v = x[reg_of(b + j)];
         v = CONJ ? cmulc(v, tw[j]) : cmul(v, tw[j]);
@@ -215,11 +215,12 @@ __device__ __forceinline__ void twiddle_batch(cf (&x)[32], const cf* __restrict_
 
 // Forward transform.  In: x[j] = y[32*j + l] (identical in both half-waves; y[1023] must be 0).
 // Out: physical register i holds bin f = 2*(l + 32*bitrev5(i)) + h.
+template <int B = kTwBatch>
 __device__ __forceinline__ void wave_fft_fwd(cf (&x)[32], float* tile_half, const LdsTables& t, int l, int h) {
     if (h) {
         const cf* tab = t.tw2048 + launder(l);
 #pragma unroll
-        for (int b = 0; b < 32; b += kTwBatch) twiddle_batch<false, false>(x, tab, b, [](int g) { return g; });
+        for (int b = 0; b < 32; b += B) twiddle_batch<false, false, B>(x, tab, b, [](int g) { return g; });
     }
     __builtin_amdgcn_sched_barrier(0);
     fft32_dif<-1>(x);
@@ -227,7 +228,7 @@ __device__ __forceinline__ void wave_fft_fwd(cf (&x)[32], float* tile_half, cons
     {
         const cf* tab = t.tw1024 + l;
 #pragma unroll
-        for (int b = 0; b < 32; b += kTwBatch) twiddle_batch<false, true>(x, tab, b, [](int g) { return bitrev5(g); });
+        for (int b = 0; b < 32; b += B) twiddle_batch<false, true, B>(x, tab, b, [](int g) { return bitrev5(g); });
     }
     transpose32(x, tile_half, l, [](int g) { return bitrev5(g); });
     __builtin_amdgcn_sched_barrier(0);
@@ -238,6 +239,7 @@ __device__ __forceinline__ void wave_fft_fwd(cf (&x)[32], float* tile_half, cons
 // Inverse transform (un-normalised; the 1/2048 lives in the PRN spectrum table) + half-wave combine.
 // In: physical register i holds bin f = 2*(l + 32*bitrev5(i)) + h.
 // Out: c[j], j = 0..15: lag q = l + 32*(j + 16*h).
+template <int B = kTwBatch>
 __device__ __forceinline__ void wave_fft_inv(cf (&x)[32], cf (&c)[16], float* tile_half, const LdsTables& t, int l, int h) {
     __builtin_amdgcn_sched_barrier(0);
     fft32_dit<+1>(x);
@@ -245,7 +247,7 @@ __device__ __forceinline__ void wave_fft_inv(cf (&x)[32], cf (&c)[16], float* ti
     {
         const cf* tab = t.tw1024 + l;
 #pragma unroll
-        for (int b = 0; b < 32; b += kTwBatch) twiddle_batch<true, true>(x, tab, b, [](int q) { return q; });
+        for (int b = 0; b < 32; b += B) twiddle_batch<true, true, B>(x, tab, b, [](int q) { return q; });
     }
     transpose32(x, tile_half, l, [](int q) { return q; });
     __builtin_amdgcn_sched_barrier(0);
@@ -258,13 +260,13 @@ __device__ __forceinline__ void wave_fft_inv(cf (&x)[32], cf (&c)[16], float* ti
     // lanes, instead of a 32-element multiply pass that leaves the low half idle followed by the additions.
     const cf* tab = t.tw2048 + launder(l + 512 * h);
 #pragma unroll
-    for (int b0 = 0; b0 < 16; b0 += kTwBatch) {
-        cf tw[kTwBatch];
+    for (int b0 = 0; b0 < 16; b0 += B) {
+        cf tw[B];
 #pragma unroll
-        for (int j = 0; j < kTwBatch; ++j) tw[j] = tab[32 * (b0 + j)];
+        for (int j = 0; j < B; ++j) tw[j] = tab[32 * (b0 + j)];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < kTwBatch; ++j) {
+        for (int j = 0; j < B; ++j) {
             const int qb = b0 + j, p = bitrev5(qb);
             auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[p].x), __float_as_uint(x[p + 1].x), false, false);
             auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[p].y), __float_as_uint(x[p + 1].y), false, false);

@@ -474,7 +474,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, 2) void corr_cells_pipe_kernel(C
             wave_lds_fence();
             float* tile_half = reinterpret_cast<float*>(cur + wave * kXchWave) + h * kXchTile;
             cf c[16];
-            wave_fft_fwd(x, tile_half, tables, l, h);
+            wave_fft_fwd<16>(x, tile_half, tables, l, h);   // 256 VGPRs: twiddle batches of 16
             GYP_TICK(t_c);
 #pragma unroll
             for (int i = 0; i < 32; ++i) x[i] = cmul(x[i], prn[i]);
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, 2) void corr_cells_pipe_kernel(C
             if (ms + 2 < p.n_ms) stage_fetch_own<K>(stream + (int64_t)(ms + 2) * N, smp, launder(tid));
             __builtin_amdgcn_sched_barrier(0);
             GYP_TICK(t_d);
-            wave_fft_inv(x, c, tile_half, tables, l, h);
+            wave_fft_inv<16>(x, c, tile_half, tables, l, h);
 #pragma unroll
             for (int j = 0; j < 16; ++j) mag[j] += __builtin_amdgcn_sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
             GYP_TICK(t_e);
