@@ -12,7 +12,8 @@ from gypsum_amd.engine import GypsumEngine  # noqa: E402
 from oracle import gypsum_oracle as orc  # noqa: E402
 
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-fs, n = 2_046_000, 2046
+fs = int(sys.argv[2]) if len(sys.argv) > 2 else 2_046_000
+n = fs // 1000
 eng = GypsumEngine(0)
 eng.set_stream_format(fs, n)
 chips = orc.generate_ca_codes()
@@ -20,7 +21,7 @@ tot = dop_bad = cp_bad = 0
 worst = []
 t0 = time.time()
 for k in range(n_scenes):
-    scene = synth.random_scene(fs, 10, 6, 5000 + k, with_nav_bits=False)
+    scene = synth.random_scene(fs, 10, 6, 5000 + k, with_nav_bits=False, max_code_phase=(2046 if n > 2046 else None))
     iq = synth.render(scene)
     ids = [s.sat_id for s in scene.sats]
     got = eng.acquire(iq, 1, 10, ids)
