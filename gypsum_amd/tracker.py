@@ -258,30 +258,35 @@ class TrackerBank:
                       end_times: Sequence[float]) -> List[List[EmittedPseudosymbol]]:
         n_ms = len(start_times)
         rec = self._bank.track_block(iq, n_streams, n_ms, start_times)
+        t0 = np.asarray(start_times, dtype=np.float64)
+        t1 = np.asarray(end_times, dtype=np.float64)
         out: List[List[EmittedPseudosymbol]] = []
         for i, p in enumerate(self.params):
-            emitted: List[EmittedPseudosymbol] = []
-            for ms in range(n_ms):
-                r = rec[i, ms]
-                if r["status"] == 2:
-                    break
-                peak = complex(r["peak_re"], r["peak_im"])
-                p.discriminators.append(float(r["discriminator"]))
-                p.discriminators.append(0)
-                p.correlation_peaks_rolling_buffer.append(peak)
-                p.correlation_peak_strengths_rolling_buffer.append(float(r["strength"]))
-                p.carrier_wave_phase_errors.append(float(r["error"]))
-                p.correlation_peak_angles.append(np.angle(peak))
-                p.doppler_shifts.append(float(r["doppler_hz"]))
-                p.carrier_wave_phases.append(float(r["carrier_phase"]))
-                p.current_prn_code_phase_shift = int(r["code_phase"])
-                if r["status"] == 1:
-                    self.lost[i] = True
-                    break
-                delay = (int(r["code_phase"]) / _DLL_MODULUS) * ONE_MILLISECOND
-                emitted.append(EmittedPseudosymbol(start_times[ms] + delay, end_times[ms] + delay,
-                                                   NavigationBitPseudosymbol.from_val(int(r["pseudosymbol"])), 0))
-            out.append(emitted)
+            r = rec[i]
+            status = r["status"]
+            # records up to and including the millisecond that raised (status 1); nothing after a channel is lost (2)
+            stop = np.flatnonzero(status != 0)
+            n_hist = n_ms if len(stop) == 0 else int(stop[0]) + (1 if status[stop[0]] == 1 else 0)
+            n_emit = n_ms if len(stop) == 0 else int(stop[0])
+            if len(stop) and status[stop[0]] == 1:
+                self.lost[i] = True
+            h = r[:n_hist]
+            peaks = h["peak_re"].astype(np.complex128) + 1j * h["peak_im"].astype(np.complex128)
+            # whole-block extends: the deques end up exactly as n_hist per-millisecond appends would leave them
+            p.discriminators.extend(v for d in h["discriminator"].astype(np.float64).tolist() for v in (d, 0))   # value, then 0
+            p.correlation_peaks_rolling_buffer.extend(peaks.tolist())
+            p.correlation_peak_strengths_rolling_buffer.extend(h["strength"].astype(np.float64).tolist())
+            p.carrier_wave_phase_errors.extend(h["error"].tolist())
+            p.correlation_peak_angles.extend(np.angle(peaks).tolist())
+            p.doppler_shifts.extend(h["doppler_hz"].tolist())
+            p.carrier_wave_phases.extend(h["carrier_phase"].tolist())
+            if n_hist:
+                p.current_prn_code_phase_shift = int(h["code_phase"][-1])
+            e = r[:n_emit]
+            delay = (e["code_phase"].astype(np.int64) / _DLL_MODULUS) * ONE_MILLISECOND
+            starts, ends = (t0[:n_emit] + delay).tolist(), (t1[:n_emit] + delay).tolist()
+            symbols = [NavigationBitPseudosymbol.from_val(v) for v in e["pseudosymbol"].tolist()]   # 0 -> KeyError, as upstream
+            out.append([EmittedPseudosymbol(a, b, sym, 0) for a, b, sym in zip(starts, ends, symbols)])
         state = self._bank.state()
         for i, p in enumerate(self.params):
             p.current_doppler_shift = float(state["doppler_hz"][i])
