@@ -51,7 +51,7 @@ EXPORTS = (
     "gyp_timer_stop gyp_set_stream_format gyp_prn_chips gyp_prn_spectrum_lane_layout gyp_malloc gyp_free "
     "gyp_memcpy_h2d gyp_memcpy_d2h gyp_cell_strength gyp_correlate_cells_dev gyp_correlate_cells gyp_correlate_grid_dev "
     "gyp_correlate_grid gyp_acquire_dev "
-    "gyp_acquire gyp_track_step_dev gyp_track_step gyp_bank_create gyp_bank_destroy gyp_bank_size "
+    "gyp_acquire gyp_track_step_dev gyp_track_step gyp_bank_create gyp_bank_destroy gyp_bank_size gyp_bank_set_channel gyp_bank_drop_channel "
     "gyp_track_block_dev gyp_track_block gyp_bank_get_state gyp_synth_iq_dev gyp_synth_nav_bit gyp_bank_reset_dev gyp_debug_track_profile gyp_debug_fft_bench "
     "gyp_bits_create gyp_bits_destroy gyp_bits_reset gyp_bits_push gyp_bits_push_block gyp_bits_drain gyp_bits_get_state "
     "gyp_ingest_open gyp_ingest_close gyp_ingest_total_ms gyp_ingest_set_scale gyp_ingest_seek gyp_ingest_next_host gyp_ingest_next_dev gyp_ingest_times"
@@ -107,6 +107,8 @@ def load() -> C.CDLL:
         "gyp_bank_create": (C.c_int, [vp, vp, i32, C.POINTER(vp)]),
         "gyp_bank_destroy": (None, [vp]),
         "gyp_bank_size": (C.c_int, [vp]),
+        "gyp_bank_set_channel": (C.c_int, [vp, i32, vp]),
+        "gyp_bank_drop_channel": (C.c_int, [vp, i32]),
         "gyp_track_block_dev": (C.c_int, [vp, vp, i64, i32, vp, vp]),
         "gyp_track_block": (C.c_int, [vp, vp, i32, i32, vp, vp]),
         "gyp_bank_get_state": (C.c_int, [vp, vp, vp, vp, vp]),

@@ -65,6 +65,21 @@ class _CursorProvider(AntennaSampleProvider):
         self.cursor += sample_count
         return chunk
 
+    def get_block(self, n_ms: int) -> AntennaSampleChunk:
+        """Up to `n_ms` whole milliseconds in one chunk (fewer at the end of the data; NoMoreSamplesError when none):
+        what n_ms successive get_samples(N) calls would return, concatenated.  Not part of the reference's ABC."""
+        n = int(self.sample_rate // PRN_REPETITIONS_PER_SECOND)
+        parts = []
+        start = self.seconds_since_start()
+        for _ in range(n_ms):
+            try:
+                parts.append(self.get_samples(n).samples)
+            except NoMoreSamplesError:
+                if not parts:
+                    raise
+                break
+        return AntennaSampleChunk(start_time=start, end_time=self.seconds_since_start(), samples=np.concatenate(parts))
+
     def get_attributes(self) -> SampleProviderAttributes:
         return SampleProviderAttributes(
             samples_per_second=int(self.sample_rate),
@@ -142,6 +157,15 @@ class AntennaSampleProviderBackedByArray(_CursorProvider):
         self.cursor = 0
         self.sample_rate = sample_rate
         self.utc_start_time = utc_start_time
+
+    def get_block(self, n_ms: int) -> AntennaSampleChunk:
+        n = int(self.sample_rate // PRN_REPETITIONS_PER_SECOND)
+        k = min(n_ms, (len(self.iq) - self.cursor) // n)
+        if k <= 0:
+            raise NoMoreSamplesError(f"Ran out of samples at {self.seconds_since_start():.2f}s")
+        chunk = self.peek_samples(k * n)
+        self.cursor += k * n
+        return chunk
 
     def peek_samples(self, sample_count: int) -> AntennaSampleChunk:
         if self.cursor + sample_count > len(self.iq):

@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <complex>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -715,6 +716,36 @@ void gyp_bank_destroy(gyp_bank* bank) {
 }
 
 int gyp_bank_size(const gyp_bank* bank) { return bank ? bank->n_chan : GYP_E_BAD_ARG; }
+
+int gyp_bank_set_channel(gyp_bank* bank, int32_t index, const gyp_chan_init* in) {
+    if (!bank) return GYP_E_BAD_ARG;
+    gyp_ctx* ctx = bank->ctx;
+    if (!in || index < 0 || index >= bank->n_chan || in->stream < 0 || in->sat_id < 1 || in->sat_id > 32)
+        return fail(ctx, GYP_E_BAD_ARG, "gyp_bank_set_channel: bad argument");
+    std::vector<ChanState> one(1);
+    ChanState& s = one[0];
+    std::memset(&s, 0, sizeof(s));
+    s.stream = in->stream;
+    s.sat_id = in->sat_id;
+    s.doppler = in->doppler_hz;
+    s.carrier_phase = in->carrier_phase;
+    s.code_phase = in->code_phase;
+    s.dll_phase = (double)in->code_phase;  // tracker.py:224
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(bank->d_states + index, &s, sizeof(ChanState), hipMemcpyHostToDevice));
+    return GYP_OK;
+}
+
+int gyp_bank_drop_channel(gyp_bank* bank, int32_t index) {
+    if (!bank) return GYP_E_BAD_ARG;
+    gyp_ctx* ctx = bank->ctx;
+    if (index < 0 || index >= bank->n_chan) return fail(ctx, GYP_E_BAD_ARG, "gyp_bank_drop_channel: index out of range");
+    const int32_t one = 1;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(reinterpret_cast<char*>(bank->d_states + index) + offsetof(ChanState, lost), &one, sizeof(one),
+                           hipMemcpyHostToDevice));
+    return GYP_OK;
+}
 
 int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stride_samples, int32_t n_ms,
                         const double* start_time_dev, gyp_track_rec* rec_out_dev) {

@@ -225,6 +225,15 @@ class ChannelBank:
         e._check(e.lib.gyp_track_block_dev(self.handle, C.c_void_p(iq_ptr), stream_stride, n_ms,
                                            C.c_void_p(start_times_ptr), C.c_void_p(rec_ptr or None)))
 
+    def set_channel(self, index: int, init) -> None:
+        """(Re)start one slot from an acquisition result (fresh loop state and histories)."""
+        one = np.zeros(1, dtype=CHAN_INIT)
+        one[0] = init
+        self.engine._check(self.engine.lib.gyp_bank_set_channel(self.handle, int(index), ptr(one)))
+
+    def drop_channel(self, index: int) -> None:
+        self.engine._check(self.engine.lib.gyp_bank_drop_channel(self.handle, int(index)))
+
     def reset_dev(self, inits_ptr: int) -> None:
         self.engine._check(self.engine.lib.gyp_bank_reset_dev(self.handle, C.c_void_p(inits_ptr)))
 

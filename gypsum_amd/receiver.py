@@ -16,7 +16,7 @@ from typing import Any, Callable, Dict, List, Optional
 import numpy as np
 
 from .acquisition import GpsSatelliteDetector
-from .antenna_sample_provider import AntennaSampleChunk, AntennaSampleProvider
+from .antenna_sample_provider import AntennaSampleChunk, AntennaSampleProvider, NoMoreSamplesError
 from .gps_ca_prn_codes import GpsSatelliteId, generate_replica_prn_signals
 from .satellite import ALL_SATELLITE_IDS, GpsSatellite
 from .satellite_signal_processing_pipeline import GpsSatelliteSignalProcessingPipeline
@@ -108,3 +108,129 @@ class GpsReceiver:
             raise ValueError(f"Tried to drop an untracked satellite {satellite_id}")
         del self.tracked_satellite_ids_to_processing_pipelines[satellite_id]
         self.satellite_ids_eligible_for_acquisition.append(satellite_id)
+
+
+class BatchedGpsReceiver:
+    """The receiver loop of `gypsum/receiver.py:85-267` advanced a block of milliseconds per call:
+    acquisition scans at exactly the milliseconds `GpsReceiver.step()` would run them (first when ten chunks are
+    buffered, then whenever ACQUISITION_SCAN_FREQUENCY seconds have passed and a satellite is eligible), tracking of
+    all acquired satellites between scans in device-resident loops (`gyp_track_block`, one bank slot per satellite),
+    pseudosymbols integrated into navigation bits natively (`gyp_bits_push_block`).
+
+    Equivalent to calling `step()` once per millisecond as long as no satellite loses lock inside a block; a dropped
+    satellite is handed back to the search when its block ends, i.e. at most `block_ms` later than upstream would.
+    """
+
+    def __init__(self, antenna_samples_provider: AntennaSampleProvider,
+                 only_acquire_satellite_ids: Optional[List[GpsSatelliteId]] = None, block_ms: int = 250, device: int = 0) -> None:
+        from .engine import default_engine
+        from .navigation_bit_intergrator import NavigationBitIntegratorBank
+        from ._lib import CHAN_INIT
+
+        self.antenna_samples_provider = antenna_samples_provider
+        self.attrs = antenna_samples_provider.get_attributes()
+        self.block_ms = int(block_ms)
+        n = self.attrs.samples_per_prn_transmission
+        self.satellites_by_id = {
+            sid: GpsSatellite(satellite_id=sid, prn_code=code, scale_factor=n // PRN_CHIP_COUNT)
+            for sid, code in generate_replica_prn_signals().items()
+        }
+        self.satellite_ids_eligible_for_acquisition = (deepcopy(ALL_SATELLITE_IDS) if only_acquire_satellite_ids is None
+                                                       else list(only_acquire_satellite_ids))
+        self.satellite_detector = GpsSatelliteDetector(self.satellites_by_id)
+        self.tracked_satellite_ids_to_tracking_params: Dict[GpsSatelliteId, Any] = {}
+        self.emitted_pseudosymbols: Dict[GpsSatelliteId, List[Any]] = {}
+        self.steps_done = 0
+        self._time_of_last_scan: Optional[float] = None
+        self._recent = np.zeros(0, dtype=np.complex64)     # the last (up to) 9 chunks before the current block
+        self._engine = default_engine(self.attrs.samples_per_second, n, device)
+        inits = np.zeros(32, dtype=CHAN_INIT)
+        for k in range(32):
+            inits[k] = (0, k + 1, 0.0, 0.0, 0, 0)
+        self._bank = self._engine.create_bank(inits)        # slot k belongs to satellite k+1; all parked until acquired
+        for k in range(32):
+            self._bank.drop_channel(k)
+        self._bits = NavigationBitIntegratorBank(32)
+
+    # the provider's clock: round(cursor / fs, 6) after `k` whole chunks (antenna_sample_provider.py:88-96)
+    def _time_after(self, k: int) -> float:
+        return round(k * self.attrs.samples_per_prn_transmission / self.attrs.samples_per_second, 6)
+
+    def _next_scan_step(self, i: int) -> Optional[int]:
+        """First step j >= i at which step() would run an acquisition scan, with the current eligible list."""
+        if not self.satellite_ids_eligible_for_acquisition:
+            return None
+        j = max(i, ACQUISITION_INTEGRATION_PERIOD_MS - 1)          # ten chunks buffered (receiver.py:148-152)
+        if self._time_of_last_scan is not None:                    # and the scan period has passed (receiver.py:158-163)
+            j = max(j, int((self._time_of_last_scan + ACQUISITION_SCAN_FREQUENCY) * 1000) - 3)
+            while self._time_after(j + 1) - self._time_of_last_scan < ACQUISITION_SCAN_FREQUENCY:
+                j += 1
+        return j
+
+    def _scan(self, samples: np.ndarray, now: float) -> None:
+        from .tracker import GpsSatelliteTrackingParameters
+        self._time_of_last_scan = now
+        results = self.satellite_detector.detect_satellites_in_antenna_data(
+            self.satellite_ids_eligible_for_acquisition, samples, self.attrs)
+        for r in results:
+            sid = r.satellite_id
+            slot = sid.id - 1
+            self._bank.set_channel(slot, (0, sid.id, float(r.doppler_shift), float(r.carrier_wave_phase_shift),
+                                          int(r.prn_phase_shift), 0))
+            self._bits.reset(slot)                           # a new pipeline starts with a new integrator (pipeline.py:70)
+            self.tracked_satellite_ids_to_tracking_params[sid] = GpsSatelliteTrackingParameters(
+                satellite=self.satellites_by_id[sid], current_doppler_shift=r.doppler_shift,
+                current_carrier_wave_phase_shift=r.carrier_wave_phase_shift,
+                current_prn_code_phase_shift=r.prn_phase_shift, doppler_shifts=[])
+            self.emitted_pseudosymbols.setdefault(sid, [])
+        acquired = [r.satellite_id for r in results]
+        self.satellite_ids_eligible_for_acquisition = [s for s in self.satellite_ids_eligible_for_acquisition if s not in acquired]
+
+    def run(self, n_ms: int) -> Dict[GpsSatelliteId, List[Any]]:
+        """Advance `n_ms` milliseconds (fewer if the provider runs dry; NoMoreSamplesError if it is already dry).
+        Returns the navigation-bit events per satellite, in emission order."""
+        from .navigation_bit_intergrator import _events_from
+        from .tracker import replay_track_records
+
+        n = self.attrs.samples_per_prn_transmission
+        events: Dict[GpsSatelliteId, List[Any]] = {}
+        remaining = n_ms
+        while remaining > 0:
+            i = self.steps_done
+            s = self._next_scan_step(i)
+            length = min(remaining, self.block_ms)
+            if s is not None and s > i:
+                length = min(length, s - i)                  # stop right before the millisecond that scans
+            try:
+                block = self.antenna_samples_provider.get_block(length)
+            except NoMoreSamplesError:
+                if remaining == n_ms:
+                    raise
+                break
+            iq = np.ascontiguousarray(block.samples, dtype=np.complex64)
+            length = len(iq) // n
+            if s == i:                                       # step i scans with the ten newest chunks, i included
+                self._scan(np.concatenate([self._recent, iq[:n]])[-ACQUISITION_INTEGRATION_PERIOD_MS * n:], self._time_after(i + 1))
+            t0 = np.array([self._time_after(i + k) for k in range(length)])
+            t1 = np.array([self._time_after(i + k + 1) for k in range(length)])
+            if self.tracked_satellite_ids_to_tracking_params:
+                rec = self._bank.track_block(iq, 1, length, t0)
+                for c, ev in self._bits.push_block_events(rec, t0, t1):
+                    events.setdefault(GpsSatelliteId(c + 1), []).append(ev)
+                state = self._bank.state()
+                for sid in list(self.tracked_satellite_ids_to_tracking_params):
+                    p = self.tracked_satellite_ids_to_tracking_params[sid]
+                    emitted, lost = replay_track_records(p, rec[sid.id - 1], t0, t1)
+                    self.emitted_pseudosymbols[sid].extend(emitted)
+                    if lost:                                 # receiver.py:248-267
+                        del self.tracked_satellite_ids_to_tracking_params[sid]
+                        self.satellite_ids_eligible_for_acquisition.append(sid)
+                    else:
+                        k = sid.id - 1
+                        p.current_doppler_shift = float(state["doppler_hz"][k])
+                        p.current_carrier_wave_phase_shift = float(state["carrier_phase"][k])
+                        p.current_prn_code_phase_shift = int(state["code_phase"][k])
+            self._recent = np.concatenate([self._recent, iq])[-(ACQUISITION_INTEGRATION_PERIOD_MS - 1) * n:]
+            self.steps_done += length
+            remaining -= length
+        return events

@@ -262,31 +262,9 @@ class TrackerBank:
         t1 = np.asarray(end_times, dtype=np.float64)
         out: List[List[EmittedPseudosymbol]] = []
         for i, p in enumerate(self.params):
-            r = rec[i]
-            status = r["status"]
-            # records up to and including the millisecond that raised (status 1); nothing after a channel is lost (2)
-            stop = np.flatnonzero(status != 0)
-            n_hist = n_ms if len(stop) == 0 else int(stop[0]) + (1 if status[stop[0]] == 1 else 0)
-            n_emit = n_ms if len(stop) == 0 else int(stop[0])
-            if len(stop) and status[stop[0]] == 1:
-                self.lost[i] = True
-            h = r[:n_hist]
-            peaks = h["peak_re"].astype(np.complex128) + 1j * h["peak_im"].astype(np.complex128)
-            # whole-block extends: the deques end up exactly as n_hist per-millisecond appends would leave them
-            p.discriminators.extend(v for d in h["discriminator"].astype(np.float64).tolist() for v in (d, 0))   # value, then 0
-            p.correlation_peaks_rolling_buffer.extend(peaks.tolist())
-            p.correlation_peak_strengths_rolling_buffer.extend(h["strength"].astype(np.float64).tolist())
-            p.carrier_wave_phase_errors.extend(h["error"].tolist())
-            p.correlation_peak_angles.extend(np.angle(peaks).tolist())
-            p.doppler_shifts.extend(h["doppler_hz"].tolist())
-            p.carrier_wave_phases.extend(h["carrier_phase"].tolist())
-            if n_hist:
-                p.current_prn_code_phase_shift = int(h["code_phase"][-1])
-            e = r[:n_emit]
-            delay = (e["code_phase"].astype(np.int64) / _DLL_MODULUS) * ONE_MILLISECOND
-            starts, ends = (t0[:n_emit] + delay).tolist(), (t1[:n_emit] + delay).tolist()
-            symbols = [NavigationBitPseudosymbol.from_val(v) for v in e["pseudosymbol"].tolist()]   # 0 -> KeyError, as upstream
-            out.append([EmittedPseudosymbol(a, b, sym, 0) for a, b, sym in zip(starts, ends, symbols)])
+            emitted, lost = replay_track_records(p, rec[i], t0, t1)
+            out.append(emitted)
+            self.lost[i] = self.lost[i] or lost
         state = self._bank.state()
         for i, p in enumerate(self.params):
             p.current_doppler_shift = float(state["doppler_hz"][i])
@@ -296,3 +274,35 @@ class TrackerBank:
 
     def close(self) -> None:
         self._bank.close()
+
+
+def replay_track_records(p: GpsSatelliteTrackingParameters, r: np.ndarray, t0: np.ndarray, t1: np.ndarray):
+    """Append to `p` what process_samples would have appended for the milliseconds recorded in `r` (one channel's
+    gyp_track_rec row) and return (emitted pseudosymbols, raised-lost-lock flag)."""
+    n_ms = len(r)
+    status = r["status"]
+    # records up to and including the millisecond that raised (status 1); nothing after a channel is lost (2)
+    stop = np.flatnonzero(status != 0)
+    n_hist = n_ms if len(stop) == 0 else int(stop[0]) + (1 if status[stop[0]] == 1 else 0)
+    n_emit = n_ms if len(stop) == 0 else int(stop[0])
+    lost = bool(len(stop) and status[stop[0]] == 1)
+    h = r[:n_hist]
+    peaks = h["peak_re"].astype(np.complex128) + 1j * h["peak_im"].astype(np.complex128)
+    # whole-block extends: the deques end up exactly as n_hist per-millisecond appends would leave them
+    p.discriminators.extend(v for d in h["discriminator"].astype(np.float64).tolist() for v in (d, 0))   # value, then 0
+    p.correlation_peaks_rolling_buffer.extend(peaks.tolist())
+    p.correlation_peak_strengths_rolling_buffer.extend(h["strength"].astype(np.float64).tolist())
+    p.carrier_wave_phase_errors.extend(h["error"].tolist())
+    p.correlation_peak_angles.extend(np.angle(peaks).tolist())
+    p.doppler_shifts.extend(h["doppler_hz"].tolist())
+    p.carrier_wave_phases.extend(h["carrier_phase"].tolist())
+    if n_hist:
+        p.current_prn_code_phase_shift = int(h["code_phase"][-1])
+    e = r[:n_emit]
+    delay = (e["code_phase"].astype(np.int64) / _DLL_MODULUS) * ONE_MILLISECOND
+    starts, ends = (t0[:n_emit] + delay).tolist(), (t1[:n_emit] + delay).tolist()
+    symbols = [NavigationBitPseudosymbol.from_val(v) for v in e["pseudosymbol"].tolist()]   # 0 -> KeyError, as upstream
+    if n_hist:
+        p.current_doppler_shift = float(h["doppler_hz"][-1])
+        p.current_carrier_wave_phase_shift = float(h["carrier_phase"][-1])
+    return [EmittedPseudosymbol(a, b, sym, 0) for a, b, sym in zip(starts, ends, symbols)], lost

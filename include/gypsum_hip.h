@@ -220,6 +220,12 @@ typedef struct gyp_track_rec {
 int gyp_bank_create(gyp_ctx* ctx, const gyp_chan_init* chans_host, int32_t n_chan, gyp_bank** out);
 void gyp_bank_destroy(gyp_bank* bank);
 int gyp_bank_size(const gyp_bank* bank);
+/* (Re)start channel `index` from an acquisition result: fresh loop state, empty histories, not lost -- what building a
+ * new GpsSatelliteSignalProcessingPipeline for the satellite does (pipeline.py:56-63).  Synchronises the stream. */
+int gyp_bank_set_channel(gyp_bank* bank, int32_t index, const gyp_chan_init* init_host);
+/* Stop advancing channel `index` (the receiver dropping a satellite, receiver.py:259-267): later blocks only write
+ * status-2 records for it until gyp_bank_set_channel revives the slot.  Synchronises the stream. */
+int gyp_bank_drop_channel(gyp_bank* bank, int32_t index);
 /* Advance every channel n_ms milliseconds.  iq_dev: n_streams x n_ms x N (stream stride given);
  * start_time_dev/end_time_dev: n_ms doubles (shared by all streams): chunk.start_time / chunk.end_time;
  * rec_out_dev: n_chan x n_ms records (channel-major), may be NULL. */
