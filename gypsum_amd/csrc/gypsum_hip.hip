@@ -95,6 +95,18 @@ static void make_replica_lane_layout(const uint8_t* chips, float* out /*32*64*2*
 // ---------------------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------------------
+// samples per chip (multiples of 1.023 MHz) the kernels are instantiated for
+#define GYP_FOR_EACH_RATE(X) X(1) X(2) X(3) X(4) X(5) X(6) X(8) X(10) X(12) X(16) X(20) X(48)
+static bool rate_supported(int k) {
+    switch (k) {
+#define X(K) case K:
+        GYP_FOR_EACH_RATE(X)
+#undef X
+        return true;
+    }
+    return false;
+}
+
 static thread_local std::string g_create_error;
 
 struct gyp_ctx {
@@ -255,8 +267,8 @@ int gyp_set_stream_format(gyp_ctx* ctx, int64_t fs_hz, int32_t samples_per_ms) {
     if (samples_per_ms % kChips != 0)
         return fail(ctx, GYP_E_BAD_RATE, "sample rate must be an integer multiple of 1.023 MHz (the replica is np.repeat(chips, N // 1023))");
     const int k = samples_per_ms / kChips;
-    if (k != 1 && k != 2 && k != 4 && k != 8 && k != 16 && k != 48)
-        return fail(ctx, GYP_E_BAD_RATE, "supported rates this release: 1.023, 2.046, 4.092, 8.184, 16.368, 49.104 Msps");
+    if (!rate_supported(k))
+        return fail(ctx, GYP_E_BAD_RATE, "supported multiples of 1.023 MHz: 1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 48");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->d_replicas) {
         std::vector<uint8_t> chips(32 * kChips);
@@ -327,7 +339,7 @@ double gyp_cell_strength(const gyp_cell* c, int32_t samples_per_ms) {
 // ---------------------------------------------------------------------------------------------------------
 // wavefronts a CU hosts for this rate (LDS tiles and VGPR budgets are sized for it), in workgroups
 static int blocks_per_cu(int k) { return k > 8 ? 1 : 16 / k; }
-static int threads_for(int k) { return 64 * (k < 8 ? k : 8); }
+static int threads_for(int k) { return 64 * largest_divisor_up_to_8(k); }
 
 template <typename KernelT, typename ParamsT>
 static int launch_k(gyp_ctx* ctx, KernelT kernel, int k, int grid, const ParamsT& p, size_t lds) {
@@ -337,7 +349,6 @@ static int launch_k(gyp_ctx* ctx, KernelT kernel, int k, int grid, const ParamsT
     return GYP_OK;
 }
 
-#define GYP_FOR_EACH_RATE(X) X(1) X(2) X(4) X(8) X(16) X(48)
 
 static int launch_cells(gyp_ctx* ctx, const CellsParams& p, int integration) {
     const int grid = std::max(1, std::min(p.n_cells, ctx->n_cus * blocks_per_cu(ctx->k)) & ~7);
@@ -497,12 +508,12 @@ int gyp_correlate_grid_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams,
             else hipLaunchKernelGGL((grid_fold_kernel<K, false>), fgrid, dim3(threads_for(K)), 0, ctx->stream, p);            \
             HIP_TRY(ctx, hipGetLastError());                                                                                  \
         }                                                                                                                     \
-        if (n_blk == 1 && K >= 2 && !ctx->no_pipe) { /* one wavefront per cell, 256 VGPRs, next row prefetched */              \
+        if (n_blk == 1 && K % 2 == 0 && !ctx->no_pipe) { /* one wavefront per cell, 256 VGPRs, next row prefetched */              \
             const size_t lds = 2 * kTablesBytes + 8 * kXchWaveBytes;                                                           \
             const int wgrid = std::max(1, std::min((n_cells + 7) / 8, ctx->n_cus));                                            \
-            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(grid_cells_wave_pipe_kernel<(K >= 2 ? K : 16)>),     \
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(grid_cells_wave_pipe_kernel<(K % 2 == 0 ? K : 16)>),     \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
-            hipLaunchKernelGGL(grid_cells_wave_pipe_kernel<(K >= 2 ? K : 16)>, dim3(wgrid), dim3(512), lds, ctx->stream, p);     \
+            hipLaunchKernelGGL(grid_cells_wave_pipe_kernel<(K % 2 == 0 ? K : 16)>, dim3(wgrid), dim3(512), lds, ctx->stream, p);     \
             HIP_TRY(ctx, hipGetLastError());                                                                                  \
             return GYP_OK;                                                                                                    \
         }                                                                                                                     \

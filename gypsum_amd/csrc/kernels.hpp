@@ -30,13 +30,18 @@ constexpr int kPeakHistory = 1000;  // tracker.py:146 (deque maxlen)
 constexpr int kLockRefresh = 1024;  // exact two-pass recomputation of the sliding sums every this many ms
 constexpr int kTablesBytes = 1024 * 8;  // tw1024 (tw2048 stays in global memory / L1)
 constexpr int kRedBytes = 1024;
-// K = samples per chip.  A workgroup has W = min(K, 8) wavefronts; K > 8 is processed in R = K / W rounds of W
-// polyphase branches (branch r = rho*W + wavefront).
+// K = samples per chip.  A workgroup has W wavefronts, W = the largest divisor of K that is <= 8; K > 8 is processed in
+// R = K / W rounds of W polyphase branches (branch r = rho*W + wavefront).
+constexpr int largest_divisor_up_to_8(int k) {
+    for (int w = 8; w > 1; --w)
+        if (k % w == 0) return w;
+    return 1;
+}
 template <int K>
 struct Geom {
-    static constexpr int W = K < 8 ? K : 8;
+    static constexpr int W = largest_divisor_up_to_8(K);   // K itself up to 8; 8 for 16/24/48; 5 for 10/20; 6 for 12 ...
     static constexpr int R = K / W;
-    static_assert(K % W == 0, "samples per chip must be 1, 2, 4, 8 or a multiple of 8");
+    static_assert(K % W == 0, "W divides K");
     static constexpr int kThreads = 64 * W;
     // 16 wavefronts per CU (4 per SIMD, 128 VGPRs) for K == 8, 12 (168 VGPRs) below, 8 (256 VGPRs) for branch rounds
     static constexpr int kMinWavesPerSimd = K > 8 ? 2 : (K == 8 ? 4 : 3);

@@ -62,8 +62,8 @@ int gyp_timer_stop(gyp_ctx* ctx, float* elapsed_ms);
 
 /* Stream descriptor -- replaces SampleProviderAttributes (antenna_sample_provider.py:24-28) and the PRN
  * replica construction of receiver.py:45-53 / satellite.py:20-31.  Requires samples_per_ms == fs_hz/1000 and
- * samples_per_ms == K*1023 with K in {1,2,4,8,16,48} (the reference needs an integer multiple of
- * 1.023 MHz; 2x / 8x / 16x are its recording formats, 48x is BASELINE config 5).  Builds the
+ * samples_per_ms == K*1023 with K in {1,2,3,4,5,6,8,10,12,16,20,48} (the reference needs an integer
+ * multiple of 1.023 MHz; 2x / 8x / 16x are its recording formats, 48x is BASELINE config 5).  Builds the
  * on-device PRN spectrum table (32 satellites) and the FFT twiddle tables. */
 int gyp_set_stream_format(gyp_ctx* ctx, int64_t fs_hz, int32_t samples_per_ms);
 

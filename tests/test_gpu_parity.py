@@ -148,10 +148,12 @@ def test_track_block_closed_loop(engine_factory, tag):
     bank.close()
 
 
-@pytest.mark.parametrize("fs,n_ms", [(16_368_000, 3), (49_104_000, 10), (4_092_000, 4), (1_023_000, 5)])
+@pytest.mark.parametrize("fs,n_ms", [(16_368_000, 3), (49_104_000, 10), (4_092_000, 4), (1_023_000, 5), (3_069_000, 4),
+                                      (5_115_000, 3), (6_138_000, 3), (10_230_000, 3), (12_276_000, 3), (20_460_000, 3)])
 def test_other_sample_rates_against_oracle(engine_factory, fs, n_ms):
-    """K = N/1023 of 16 and 48 run as rounds of 8 polyphase branches; config 5 (49.104 Msps, 10 ms coherent,
-    100-Hz Doppler grid) is one of the cases.  Coherent cells use the pre-folded single transform."""
+    """Every instantiated multiple of 1.023 MHz: K > 8 runs as rounds of W polyphase branches (W = the largest divisor of
+    K up to 8); config 5 (49.104 Msps, 10 ms coherent, 100-Hz Doppler grid) is one of the cases.  Coherent cells use the
+    pre-folded single transform."""
     from gypsum_amd import synth
 
     n = fs // 1000
@@ -201,7 +203,7 @@ def test_unsupported_rates_are_rejected(engine_factory):
     from gypsum_amd.engine import GypsumEngine
 
     eng = GypsumEngine(0)
-    for fs, n in ((2_048_000, 2048), (50_000_000, 50_000), (2_046_000, 2047), (3_069_000, 3069)):
+    for fs, n in ((2_048_000, 2048), (50_000_000, 50_000), (2_046_000, 2047), (7_161_000, 7161), (9_207_000, 9207)):
         with pytest.raises(GypsumHipError) as e:
             eng.set_stream_format(fs, n)        # the reference itself cannot run 2.048 / 50 Msps
         assert e.value.code == GYP_E_BAD_RATE
@@ -264,7 +266,7 @@ def test_config5_grid_slice_against_oracle(engine_factory):
     assert g["argmax"][0, 1] == s0.code_phase and g["peak"][0, 1] == g["peak"][0].max()
 
 
-@pytest.mark.parametrize("fs", [16_368_000, 49_104_000])
+@pytest.mark.parametrize("fs", [16_368_000, 49_104_000, 3_069_000, 5_115_000, 6_138_000, 10_230_000, 12_276_000, 20_460_000])
 def test_wide_rate_grid_fold_equals_per_cell_path(engine_factory, fs):
     """K > 8: the coalesced wipe + LDS boxcar fold of the grid entry point against the per-cell kernels (which stage
     per chip), both integration kinds, several blocks, two streams."""
