@@ -237,7 +237,9 @@ class TrackerBank:
     `process_block` advances every channel over a block of milliseconds in one launch and appends what the
     reference's `process_samples` would have appended, per millisecond, to each channel's tracking parameters.
     It returns, per channel, the list of `EmittedPseudosymbol`s, and raises nothing: channels whose circularity
-    watchdog fired are reported in `lost` (the caller drops them like receiver.py:248-267).
+    watchdog fired are reported in `lost` (the caller drops them like receiver.py:248-267).  The one history the block
+    path does not fill is `non_coherent_correlation_profiles` (250 x N floats per channel, visualiser only): per-ms
+    profiles are an output of the explicit-millisecond entry point (`GpsSatelliteTracker` / `gyp_track_step`).
     """
 
     def __init__(self, tracking_params: Sequence[GpsSatelliteTrackingParameters], stream_attributes: SampleProviderAttributes,
