@@ -123,7 +123,8 @@ struct gyp_ctx {
     int k = 0;
     cf* d_replicas = nullptr;  // [32][32][64]
     cf* d_tw = nullptr;        // tw1024[1024] ++ tw2048[1024]
-    uint8_t* d_chips = nullptr;  // [32][1023], synthetic generator only
+    uint8_t* d_chips = nullptr;  // [32][1023]: synthetic generator, float64 tie-breaks
+    uint16_t* d_ones = nullptr;  // [32][512]: positions of the 512 ones of each code (float64 strength tie-break)
     long long* d_prof = nullptr; // debug: per-phase cycle counters of track_block workgroup 0
     // growable scratch for the host-buffer entry points and the acquisition driver
     void* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -205,6 +206,7 @@ void gyp_destroy(gyp_ctx* ctx) {
     if (ctx->d_replicas) (void)hipFree(ctx->d_replicas);
     if (ctx->d_tw) (void)hipFree(ctx->d_tw);
     if (ctx->d_chips) (void)hipFree(ctx->d_chips);
+    if (ctx->d_ones) (void)hipFree(ctx->d_ones);
     if (ctx->d_prof) (void)hipFree(ctx->d_prof);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -293,6 +295,15 @@ int gyp_set_stream_format(gyp_ctx* ctx, int64_t fs_hz, int32_t samples_per_ms) {
         HIP_TRY(ctx, hipMemcpy(ctx->d_tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_chips, chips.size()));
         HIP_TRY(ctx, hipMemcpy(ctx->d_chips, chips.data(), chips.size(), hipMemcpyHostToDevice));
+        std::vector<uint16_t> ones(32 * 512);   // every C/A code has exactly 512 ones (balanced Gold codes)
+        for (int sv = 0; sv < 32; ++sv) {
+            int k1 = 0;
+            for (int m = 0; m < kChips; ++m)
+                if (chips[(size_t)sv * kChips + m] && k1 < 512) ones[(size_t)sv * 512 + k1++] = (uint16_t)m;
+            if (k1 != 512) return fail(ctx, GYP_E_BAD_ARG, "a generated C/A code does not have 512 ones");
+        }
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_ones, ones.size() * sizeof(uint16_t)));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_ones, ones.data(), ones.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     ctx->fs = fs_hz;
     ctx->n = samples_per_ms;
@@ -581,6 +592,9 @@ int gyp_acquire_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_
     if ((rc = ensure_scratch(ctx, 1, n_cells * sizeof(gyp_cell_desc)))) return rc;
     if ((rc = ensure_scratch(ctx, 2, n_cells * sizeof(gyp_cell)))) return rc;
     if ((rc = ensure_scratch(ctx, 3, n_cells * sizeof(double)))) return rc;
+    const size_t profile_bytes = (size_t)n_states * 2 * ctx->n * sizeof(double);
+    if ((rc = ensure_scratch(ctx, 7, profile_bytes))) return rc;
+    double* d_profiles = (double*)ctx->scratch[7];
     double* d_refined = (double*)ctx->scratch[3];
     AcqSearchState* d_states = (AcqSearchState*)ctx->scratch[4];
     gyp_cell_desc* d_cells = (gyp_cell_desc*)ctx->scratch[1];
@@ -607,6 +621,13 @@ int gyp_acquire_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_
         rp.inv_fs = 1.0 / (double)ctx->fs;
         hipLaunchKernelGGL(acq_refine_kernel, dim3((unsigned)n_cells), dim3(256), 0, ctx->stream, rp);
         hipLaunchKernelGGL(acq_reduce_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_out, d_refined, ctx->n);
+        // cross-level near-ties in strength: float64 profiles for the (few) pending pairs, else immediate exits
+        HIP_TRY(ctx, hipMemsetAsync(d_profiles, 0, profile_bytes, ctx->stream));
+        ExactParams ep;
+        ep.iq = rp.iq; ep.stream_stride = stream_stride_samples; ep.n_ms = n_ms; ep.n_per_ms = ctx->n; ep.k = ctx->k;
+        ep.states = d_states; ep.ones = ctx->d_ones; ep.inv_fs = rp.inv_fs; ep.profiles = d_profiles;
+        hipLaunchKernelGGL(acq_exact_profile_kernel, dim3((unsigned)(ctx->k * n_ms), 2, (unsigned)n_states), dim3(1024), 0, ctx->stream, ep);
+        hipLaunchKernelGGL(acq_exact_decide_kernel, dim3((unsigned)n_states), dim3(256), 0, ctx->stream, ep);
     }
     hipLaunchKernelGGL(acq_plan_coherent_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_cells);
     rc = gyp_correlate_cells_dev(ctx, iq_dev, stream_stride_samples, n_ms, d_cells, n_states, GYP_COHERENT, d_out, nullptr);

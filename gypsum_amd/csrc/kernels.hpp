@@ -1445,6 +1445,8 @@ struct AcqSearchState {
     int32_t best_doppler, best_index;
     double best_strength;
     int32_t bins_lo, bins_step, n_bins, pad;
+    // cross-level near-ties (see acq_exact_*): a level winner whose strength is within kStrengthBand of the incumbent's
+    int32_t pending, cand_doppler, best_is_exact, pad2;
 };
 
 // Fill the descriptors of the current level: range(int(c-s), int(c+s), int(s/10)), padded to kMaxBins.
@@ -1479,6 +1481,7 @@ __device__ __forceinline__ double cell_strength(const gyp_cell& c, int n) {
 //     V = sum_ms | sum_n x[ms, n] * exp(-2*pi*i*f*t(ms, n)) * code[(n - lag) mod N] |
 // which is exactly the profile value the float64 reference compares.  Usually only the finest levels have ties.
 constexpr float kTieBand = 2e-5f;
+constexpr double kStrengthBand = 3e-7;   // cross-level strength near-tie band (see acq_exact_* below)
 
 struct RefineParams {
     const cf* iq;
@@ -1503,11 +1506,12 @@ __global__ __launch_bounds__(256) void acq_refine_kernel(RefineParams p) {
         int n_close = 0;
         for (int b = 0; b < st.n_bins; ++b) m = fmaxf(m, p.out[state * kMaxBins + b].peak);
         for (int b = 0; b < st.n_bins; ++b) n_close += p.out[state * kMaxBins + b].peak >= m * (1.0f - kTieBand) ? 1 : 0;
-        level_max = n_close > 1 ? m : -1.f;     // a lone maximum needs no tie-break
+        (void)n_close;
+        level_max = m;   // the level's top bin is always refined: its float64 peak also sharpens the strength (below)
     }
     __syncthreads();
     const gyp_cell cell = p.out[blockIdx.x];
-    if (level_max < 0.f || cell.peak < level_max * (1.0f - kTieBand)) {
+    if (cell.peak < level_max * (1.0f - kTieBand)) {
         if (threadIdx.x == 0) p.refined[blockIdx.x] = -1.0;
         return;
     }
@@ -1571,15 +1575,143 @@ __global__ void acq_reduce_kernel(AcqSearchState* states, int n_states, const gy
         }
     }
     const gyp_cell c = cells[i * kMaxBins + best_b];
-    const double strength = cell_strength(c, n_samples);
+    // strength (utils.py:111-116) from the float64 peak of the winner and the float32 profile's mean: ~3e-8 accurate
+    const double pk32 = (double)c.peak, pk = refined[i * kMaxBins + best_b] >= 0.0 ? refined[i * kMaxBins + best_b] : pk32;
+    const double strength = pk / ((c.sum - (double)c.n_max * pk32) / (double)(n_samples - c.n_max));
     const int doppler = s.bins_lo + best_b * s.bins_step;
     s.spread /= 2.0;
     s.center = (double)doppler;
-    if (!s.has_best || strength > s.best_strength) {
-        s.has_best = 1; s.best_doppler = doppler; s.best_index = c.argmax; s.best_strength = strength;
+    s.pending = 0;
+    if (!s.has_best) {
+        s.has_best = 1; s.best_doppler = doppler; s.best_index = c.argmax; s.best_strength = strength; s.best_is_exact = 0;
+    } else if (doppler != s.best_doppler) {   // the same bin again has the same profile: never strictly better
+        if (fabs(strength - s.best_strength) <= kStrengthBand * s.best_strength) {
+            s.pending = 1;                    // too close to call in float32: acq_exact_* decides in float64
+            s.cand_doppler = doppler;
+        } else if (strength > s.best_strength) {
+            s.best_doppler = doppler; s.best_index = c.argmax; s.best_strength = strength; s.best_is_exact = 0;
+        }
     }
     s.level += 1;
     states[i] = s;
+}
+
+// ---- float64 strength for cross-level near-ties ----------------------------------------------------------------
+// acquisition.py:92-101 keeps a level's winner only on STRICTLY greater strength.  Near the top of the Doppler lobe two
+// levels' winners (typically adjacent 1-Hz bins) can differ by < 1e-7 relative in strength -- below what the float32
+// profile resolves (about 1 % of visible-satellite acquisitions flipped by 1 Hz).  For those pairs the whole
+// non-coherent profile is recomputed in float64 straight from the definition (polyphase form, no FFT):
+//     profile[K*q + r] = sum_ms | sum_m chip[m] * y_r[(m + q) mod 1023] |,   y_r[m] = sum_{j<K} xw[(K*m + r + j) mod N]
+// one workgroup per (state, candidate, ms, branch); magnitudes accumulate with float64 atomics.
+struct ExactParams {
+    const cf* iq;
+    int64_t stream_stride;
+    int32_t n_ms, n_per_ms, k;
+    AcqSearchState* states;
+    const uint16_t* ones;   // [32][512] chip positions holding a one
+    double inv_fs;
+    double* profiles;   // [n_states][2][N]: candidate, incumbent
+};
+
+// grid: (K * n_ms, 2, n_states); block 1024
+__global__ __launch_bounds__(1024) void acq_exact_profile_kernel(ExactParams p) {
+    __shared__ double2 y[1024];
+    __shared__ uint16_t ones[512];
+    __shared__ double tot_re[16], tot_im[16];
+    const int state = blockIdx.z, which = blockIdx.y;
+    const AcqSearchState st = p.states[state];
+    if (!st.pending || (which == 1 && st.best_is_exact)) return;
+    const int K = p.k, N = p.n_per_ms, r = blockIdx.x % K, ms = blockIdx.x / K;
+    const double f = (double)(which == 0 ? st.cand_doppler : st.best_doppler);
+    const cf* block = p.iq + (int64_t)st.stream * p.stream_stride + (int64_t)ms * N;
+    const int m = threadIdx.x;
+    if (m < 512) ones[m] = p.ones[(st.sat_id - 1) * 512 + m];
+    double re = 0.0, im = 0.0;
+    if (m < kChips) {
+        for (int j = 0; j < K; ++j) {
+            int nn = K * m + r + j;
+            nn = nn >= N ? nn - N : nn;
+            const double u = f * (((double)((int64_t)ms * N) + (double)nn) * p.inv_fs);   // utils.py:92-96
+            double sn, cs;
+            sincospi(2.0 * (u - rint(u)), &sn, &cs);                                      // exp(-2*pi*i*u) = (cs, -sn)
+            const cf x = block[nn];
+            re += (double)x.x * cs + (double)x.y * sn;
+            im += (double)x.y * cs - (double)x.x * sn;
+        }
+        y[m] = make_double2(re, im);
+    }
+    // T = sum_m y[m]; with the code in {-1, +1}: sum_m chip[m]*y[m+q] = 2 * sum_{ones} y[m+q] - T  (512 terms, not 1023)
+    const double w_re = wave_sum(re), w_im = wave_sum(im);
+    if ((m & 63) == 0) { tot_re[m >> 6] = w_re; tot_im[m >> 6] = w_im; }
+    __syncthreads();
+    if (m < kChips) {
+        double t_re = 0.0, t_im = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { t_re += tot_re[w]; t_im += tot_im[w]; }
+        double s_re = 0.0, s_im = 0.0;
+#pragma unroll 8
+        for (int i = 0; i < 512; ++i) {
+            int idx = (int)ones[i] + m;          // (position + q) mod 1023 with q = m
+            idx = idx >= kChips ? idx - kChips : idx;
+            const double2 v = y[idx];
+            s_re += v.x;
+            s_im += v.y;
+        }
+        const double c_re = 2.0 * s_re - t_re, c_im = 2.0 * s_im - t_im;
+        atomicAdd(p.profiles + ((int64_t)state * 2 + which) * N + K * m + r, sqrt(c_re * c_re + c_im * c_im));
+    }
+}
+
+// grid: n_states; block 256.  Strength of the float64 profiles, then the strictly-greater rule.
+__global__ __launch_bounds__(256) void acq_exact_decide_kernel(ExactParams p) {
+    __shared__ double s_max[4], s_sum[4];
+    __shared__ int s_arg[4], s_cnt[4];
+    const int state = blockIdx.x;
+    AcqSearchState st = p.states[state];
+    if (!st.pending) return;
+    const int N = p.n_per_ms;
+    double strength[2] = {0.0, st.best_strength};
+    int argmax[2] = {0, st.best_index};
+    for (int which = 0; which < 2; ++which) {
+        if (which == 1 && st.best_is_exact) continue;
+        const double* prof = p.profiles + ((int64_t)state * 2 + which) * N;
+        double mx = -1.0, sum = 0.0;
+        int arg = 0x7fffffff;
+        for (int i = threadIdx.x; i < N; i += 256) {
+            const double v = prof[i];
+            sum += v;
+            if (v > mx) { mx = v; arg = i; }   // ascending i per thread: first index of the thread's maximum
+        }
+        // workgroup maximum, lowest index among equals (np.argmax), sum, and the count of elements equal to the maximum
+        double wmx = mx;
+        for (int off = 32; off; off >>= 1) wmx = fmax(wmx, __shfl_xor(wmx, off));
+        if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = wmx;
+        __syncthreads();
+        const double gmax = fmax(fmax(s_max[0], s_max[1]), fmax(s_max[2], s_max[3]));
+        __syncthreads();
+        int cand = mx == gmax ? arg : 0x7fffffff, cnt = 0;
+        for (int i = threadIdx.x; i < N; i += 256) cnt += prof[i] == gmax ? 1 : 0;
+        double wsum = wave_sum(sum);
+        int wcnt = wave_sum(cnt);
+        for (int off = 32; off; off >>= 1) cand = min(cand, __shfl_xor(cand, off));
+        if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = wsum; s_cnt[threadIdx.x >> 6] = wcnt; s_arg[threadIdx.x >> 6] = cand; }
+        __syncthreads();
+        const double tot = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+        const int n_max = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        argmax[which] = min(min(s_arg[0], s_arg[1]), min(s_arg[2], s_arg[3]));
+        strength[which] = gmax / ((tot - (double)n_max * gmax) / (double)(N - n_max));   // utils.py:111-116
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (strength[0] > strength[1]) {
+            st.best_doppler = st.cand_doppler; st.best_index = argmax[0]; st.best_strength = strength[0];
+        } else {
+            st.best_index = argmax[1]; st.best_strength = strength[1];
+        }
+        st.best_is_exact = 1;
+        st.pending = 0;
+        p.states[state] = st;
+    }
 }
 
 // One coherent cell per (stream, satellite) at the winning Doppler, tapped at the winning code phase (:122-136).

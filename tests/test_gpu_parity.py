@@ -293,3 +293,21 @@ def test_wide_rate_grid_fold_equals_per_cell_path(engine_factory, fs):
         np.testing.assert_allclose(g["sum"], c["sum"], rtol=3e-6)
         assert np.array_equal(g["n_max"], c["n_max"])
     assert g["argmax"][0, 0, 0] == scene.sats[0].code_phase
+
+
+@pytest.mark.parametrize("seed,sv", [(5063, 3), (5068, 7), (5075, 20)])
+def test_cross_level_strength_near_ties_resolve_like_float64(engine_factory, seed, sv):
+    """Two search levels whose winners (adjacent 1-Hz bins) differ by < 1e-7 relative in strength: the strictly-greater
+    rule of acquisition.py:92-101 must come out as in the float64 reference (these three flipped by 1 Hz in float32)."""
+    from gypsum_amd import synth
+
+    fs, n = 2_046_000, 2046
+    eng = engine_factory(fs, n)
+    scene = synth.random_scene(fs, 10, 6, seed, with_nav_bits=False)
+    assert sv in [s.sat_id for s in scene.sats]
+    iq = synth.render(scene)
+    got = eng.acquire(iq, 1, 10, [sv])[0]
+    ref = orc.acquire_satellite(sv, iq, fs, n, orc.prn_as_complex(orc.generate_ca_codes()[sv - 1], n))
+    assert (int(got["doppler_hz"]), int(got["code_phase"])) == (ref.doppler_shift, ref.prn_phase_shift)
+    assert float(got["strength"]) == pytest.approx(ref.correlation_strength, rel=1e-9)      # decided on float64 profiles
+    assert float(got["carrier_phase"]) == pytest.approx(ref.carrier_wave_phase_shift, abs=2e-4)
