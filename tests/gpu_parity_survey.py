@@ -23,7 +23,7 @@ t0 = time.time()
 for k in range(n_scenes):
     scene = synth.random_scene(fs, 10, 6, 5000 + k, with_nav_bits=False, max_code_phase=(2046 if n > 2046 else None))
     iq = synth.render(scene)
-    ids = [s.sat_id for s in scene.sats]
+    ids = [s.sat_id for s in scene.sats] if len(sys.argv) <= 3 else list(range(1, 33))   # 4th argument: all 32, noise-only included
     got = eng.acquire(iq, 1, 10, ids)
     for g, sv in zip(got, ids):
         r = orc.acquire_satellite(sv, iq, fs, n, orc.prn_as_complex(chips[sv - 1], n))
@@ -33,6 +33,6 @@ for k in range(n_scenes):
             worst.append((k, sv, int(g["doppler_hz"]), r.doppler_shift, float(g["strength"]), r.correlation_strength))
         if int(g["code_phase"]) != r.prn_phase_shift:
             cp_bad += 1
-print(f"{tot} visible-satellite acquisitions in {time.time() - t0:.0f} s: Doppler mismatches {dop_bad}, code-phase mismatches {cp_bad}")
+print(f"{tot} {'visible-satellite' if len(sys.argv) <= 3 else 'full-sky (visible + noise-only)'} acquisitions in {time.time() - t0:.0f} s: Doppler mismatches {dop_bad}, code-phase mismatches {cp_bad}")
 for w in worst[:20]:
     print("  scene %d sv %d: gpu %d Hz vs oracle %d Hz (strength %.4f vs %.4f)" % w)
