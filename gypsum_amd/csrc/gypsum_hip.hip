@@ -624,9 +624,9 @@ int gyp_acquire_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_
         // cross-level near-ties in strength: float64 profiles for the (few) pending pairs, else immediate exits
         HIP_TRY(ctx, hipMemsetAsync(d_profiles, 0, profile_bytes, ctx->stream));
         ExactParams ep;
-        ep.iq = rp.iq; ep.stream_stride = stream_stride_samples; ep.n_ms = n_ms; ep.n_per_ms = ctx->n; ep.k = ctx->k;
+        ep.iq = rp.iq; ep.stream_stride = stream_stride_samples; ep.n_ms = n_ms; ep.n_per_ms = ctx->n; ep.k = ctx->k; ep.n_states = n_states;
         ep.states = d_states; ep.ones = ctx->d_ones; ep.inv_fs = rp.inv_fs; ep.profiles = d_profiles;
-        hipLaunchKernelGGL(acq_exact_profile_kernel, dim3((unsigned)(ctx->k * n_ms), 2, (unsigned)n_states), dim3(1024), 0, ctx->stream, ep);
+        hipLaunchKernelGGL(acq_exact_profile_kernel, dim3((unsigned)(ctx->k * n_ms), 2, (unsigned)std::min(n_states, 32)), dim3(1024), 0, ctx->stream, ep);
         hipLaunchKernelGGL(acq_exact_decide_kernel, dim3((unsigned)n_states), dim3(256), 0, ctx->stream, ep);
     }
     hipLaunchKernelGGL(acq_plan_coherent_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_cells);

@@ -1606,21 +1606,22 @@ __global__ void acq_reduce_kernel(AcqSearchState* states, int n_states, const gy
 struct ExactParams {
     const cf* iq;
     int64_t stream_stride;
-    int32_t n_ms, n_per_ms, k;
+    int32_t n_ms, n_per_ms, k, n_states;
     AcqSearchState* states;
     const uint16_t* ones;   // [32][512] chip positions holding a one
     double inv_fs;
     double* profiles;   // [n_states][2][N]: candidate, incumbent
 };
 
-// grid: (K * n_ms, 2, n_states); block 1024
+// grid: (K * n_ms, 2, min(n_states, 32)); block 1024
 __global__ __launch_bounds__(1024) void acq_exact_profile_kernel(ExactParams p) {
     __shared__ double2 y[1024];
     __shared__ uint16_t ones[512];
     __shared__ double tot_re[16], tot_im[16];
-    const int state = blockIdx.z, which = blockIdx.y;
+    const int which = blockIdx.y;
+    for (int state = blockIdx.z; state < p.n_states; state += gridDim.z) {   // few states are pending: a short z grid
     const AcqSearchState st = p.states[state];
-    if (!st.pending || (which == 1 && st.best_is_exact)) return;
+    if (!st.pending || (which == 1 && st.best_is_exact)) continue;           // uniform across the workgroup
     const int K = p.k, N = p.n_per_ms, r = blockIdx.x % K, ms = blockIdx.x / K;
     const double f = (double)(which == 0 ? st.cand_doppler : st.best_doppler);
     const cf* block = p.iq + (int64_t)st.stream * p.stream_stride + (int64_t)ms * N;
@@ -1659,6 +1660,8 @@ __global__ __launch_bounds__(1024) void acq_exact_profile_kernel(ExactParams p) 
         }
         const double c_re = 2.0 * s_re - t_re, c_im = 2.0 * s_im - t_im;
         atomicAdd(p.profiles + ((int64_t)state * 2 + which) * N + K * m + r, sqrt(c_re * c_re + c_im * c_im));
+    }
+    __syncthreads();   // the shared row is rebuilt for the next pending state
     }
 }
 
