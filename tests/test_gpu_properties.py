@@ -108,3 +108,26 @@ def test_device_generated_streams_acquire_and_demodulate(engine_factory):
             assert abs(rec[b, c, -1]["doppler_hz"] - float(sats[b, c]["doppler_hz"])) < 40
     assert good >= B * C - 2, f"only {good}/{B * C} channels demodulate the generated bits after {T} ms"
     bank.close()
+
+
+def test_acquisition_is_independent_of_batch_composition():
+    """A stream acquired alone, twice, and as one of several streams in a batch gives the same records (the float64
+    tie-break kernels accumulate with atomics: the decisions and the reported numbers must not depend on that)."""
+    from gypsum_amd import synth
+    from gypsum_amd.engine import default_engine
+
+    fs, n = 8_184_000, 8184
+    eng = default_engine(fs, n)
+    scenes = [synth.random_scene(fs, 10, 6, 9100 + k, with_nav_bits=False, max_code_phase=2046) for k in range(3)]
+    iqs = [synth.render(sc) for sc in scenes]
+    ids = list(range(1, 33))
+    alone = [eng.acquire(iq, 1, 10, ids) for iq in iqs]
+    again = eng.acquire(iqs[1], 1, 10, ids)
+    batch = eng.acquire(np.concatenate(iqs), 3, 10, ids).reshape(3, 32)
+    for k in range(3):
+        for field in ("sat_id", "doppler_hz", "code_phase"):
+            assert np.array_equal(alone[k][field], batch[k][field]), (k, field)
+        np.testing.assert_allclose(alone[k]["strength"], batch[k]["strength"], rtol=1e-12)
+        np.testing.assert_allclose(alone[k]["carrier_phase"], batch[k]["carrier_phase"], atol=1e-12)
+    assert np.array_equal(alone[1]["doppler_hz"], again["doppler_hz"]) and np.array_equal(alone[1]["code_phase"], again["code_phase"])
+    np.testing.assert_allclose(alone[1]["strength"], again["strength"], rtol=1e-12)
