@@ -34,17 +34,6 @@ constexpr int kTwBatch = GYP_TW_BATCH;   // twiddle / replica values fetched per
 // Hide a thread-id-derived value from the optimiser so that everything computed from it is re-derived where it
 // is used (a handful of integer instructions) instead of being hoisted out of the per-millisecond loop as a
 // loop invariant and then spilled: every scratch reload is a ~250-cycle stall in these latency-bound kernels.
-// Compiler-level fence: no load or store is moved across it by any pass (sched_barrier only binds the machine
-// scheduler; IR passes still hoist loads over it).
-__device__ __forceinline__ void pin_memory_order() { asm volatile("" ::: "memory"); }
-
-// launder() whose result additionally "depends" on `after`: whatever is addressed through it cannot be issued
-// before `after` has been computed (keeps prefetches where they were written instead of wherever the scheduler
-// hoists them to, which both inflates register pressure and drags their latency under an early s_waitcnt).
-__device__ __forceinline__ int launder_after(int v, float after) {
-    asm volatile("" : "+v"(v) : "v"(after));
-    return v;
-}
 // Forces the 32 values to be materialised at this point of the program: without it LLVM sinks pure VALU work (a
 // whole FFT32 + the spectrum multiply) below a later conditional block, which puts that block's loads -- and the
 // s_waitcnt the register allocator's copies need -- in front of the arithmetic they were meant to overlap.
@@ -408,67 +397,9 @@ __device__ __forceinline__ void stage_ms(const cf* __restrict__ block, double u0
     }
 }
 
-// The two halves of stage_ms as separate steps, for kernels that fetch the next block's samples while the transforms
-// of the current one run (software pipelining; needs the 256-VGPR budget): stage_fetch issues every global load of
-// the block into registers, stage_emit wipes them, pre-sums and writes the K rows (+ the zero of the padding slot).
-template <int K>
-struct StagedSamples {
-    static constexpr int T = 64 * K;
-    static constexpr int CH = (kChips + T - 1) / T;
-    cf w[CH][2 * K - 1];
-};
-template <int K>
-__device__ __forceinline__ void stage_fetch(const cf* __restrict__ block, StagedSamples<K>& s, int tid) {
-#pragma unroll
-    for (int c = 0; c < StagedSamples<K>::CH; ++c) {
-        const int m = tid + c * StagedSamples<K>::T;
-        if (m < kChips) {
-            load_samples<K>(block + K * m, s.w[c]);
-            const int mn = (m + 1 == kChips) ? 0 : m + 1;
-            if (K > 1) load_samples<K - 1>(block + K * mn, s.w[c] + K);
-        }
-    }
-}
-template <int K>
-__device__ __forceinline__ void stage_emit(StagedSamples<K>& s, double u0, double du, const CarrierSteps& cs,
-                                           cf* (&y_rows)[K], int tid) {
-    const cf rot1 = cs.rot1, rot_wrap = cs.rot_wrap;
-#pragma unroll
-    for (int c = 0; c < StagedSamples<K>::CH; ++c) {
-        const int m = tid + c * StagedSamples<K>::T;
-        if (m < kChips) {
-            cf (&w)[2 * K - 1] = s.w[c];
-            cf car = carrier_from_cycles_fast(u0 + du * (double)(K * m));
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                w[i] = cmul(w[i], car);
-                car = cmul(car, rot1);
-            }
-            if (K > 1) {
-                if (m + 1 == kChips) car = cmul(car, rot_wrap);
-#pragma unroll
-                for (int i = 0; i < K - 1; ++i) {
-                    w[K + i] = cmul(w[K + i], car);
-                    car = cmul(car, rot1);
-                }
-            }
-            cf acc = w[0];
-#pragma unroll
-            for (int i = 1; i < K; ++i) acc = cadd(acc, w[i]);
-            y_rows[0][m] = acc;
-#pragma unroll
-            for (int r = 1; r < K; ++r) {
-                acc = cadd(csub(acc, w[r - 1]), w[r + K - 1]);
-                y_rows[r][m] = acc;
-            }
-        } else if (m == kChips) {
-#pragma unroll
-            for (int r = 0; r < K; ++r) y_rows[r][m] = make_float2(0.f, 0.f);
-        }
-    }
-}
-
-// Halo-free variant of the split staging (K >= 2, workgroup of K wavefronts): a thread fetches and wipes ONLY its
+// Split staging for kernels that fetch the next block's samples while the transforms of the current one run
+// (stage_fetch_own issues the global loads into registers, stage_emit_own wipes, pre-sums and writes the K rows), in
+// halo-free form (K >= 2, workgroup of K wavefronts): a thread fetches and wipes ONLY its
 // chips' own K samples (half the loads, half the wipes, 2K instead of 4K-2 registers per chip) and forms
 //   y_r[m] = S_r(m) + P_r(m+1),   S_r = sum_{i>=r} w[i]  (suffix sums),  P_r = sum_{i<r} w[i]  (prefix sums),
 // where the neighbour chip's prefix sums arrive from the next lane through the DPP network (wave_shl:1).  Lane 63
