@@ -34,16 +34,16 @@ constexpr int kTwBatch = GYP_TW_BATCH;   // twiddle / replica values fetched per
 // Hide a thread-id-derived value from the optimiser so that everything computed from it is re-derived where it
 // is used (a handful of integer instructions) instead of being hoisted out of the per-millisecond loop as a
 // loop invariant and then spilled: every scratch reload is a ~250-cycle stall in these latency-bound kernels.
+__device__ __forceinline__ int launder(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
 // Forces the 32 values to be materialised at this point of the program: without it LLVM sinks pure VALU work (a
 // whole FFT32 + the spectrum multiply) below a later conditional block, which puts that block's loads -- and the
 // s_waitcnt the register allocator's copies need -- in front of the arithmetic they were meant to overlap.
 __device__ __forceinline__ void pin_values(cf (&x)[32]) {
 #pragma unroll
     for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(x[i].x), "+v"(x[i].y));
-}
-__device__ __forceinline__ int launder(int v) {
-    asm volatile("" : "+v"(v));
-    return v;
 }
 
 __device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
