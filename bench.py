@@ -150,6 +150,12 @@ def cpu_baseline_cfg2(fs: int, n: int) -> dict:
 
 
 def main() -> None:
+    # stdout carries exactly one line, the JSON result of rank 0: RCCL / HIP print banners to the C-level stdout (and
+    # flush them at exit, i.e. after anything Python printed), so file descriptor 1 is pointed at stderr for the whole
+    # run and the JSON goes to a private duplicate of the original stdout.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -476,7 +482,7 @@ def main() -> None:
             line["cpu_baseline"] = result["cpu_baseline"]
         if "cpu_baseline_all_cores" in result:
             line["cpu_baseline_all_cores"] = result["cpu_baseline_all_cores"]
-        print(json.dumps(line), flush=True)
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
