@@ -264,7 +264,7 @@ def main() -> None:
         trk_ms /= reps
         acq_ms /= reps
         # --- sanity: the last step's records must demodulate the generated navigation bits
-        sym_ok = None
+        sym_ok = spec_fast = None
         state = bank.state()
         if rec_dev is not None:
             rec = rec_dev.download(TRACK_REC, B * C * T).reshape(B, C, T)
@@ -278,6 +278,7 @@ def main() -> None:
                     got = rec[s, c, tail]["pseudosymbol"].astype(np.int64)
                     agree.append(max(np.mean(got == truth), np.mean(got == -truth)))
             sym_ok = float(np.mean(np.array(agree) > 0.95))
+            spec_fast = float(np.mean((rec["path_info"] & 3) == 1))
         samples_per_step = B * T * n
         f_trk = C * (2 * fft_flops(n) + 18 * n)                       # SURVEY 8(d5), per stream-ms
         trk_flops = f_trk * B * T
@@ -296,7 +297,7 @@ def main() -> None:
             "extra": {"acquire_ms_per_step": round(acq_ms, 3), "track_ms_per_step": round(trk_ms, 3),
                       "acquire_ms_per_stream_32sat": round(acq_ms / A, 3),
                       "acquisition_seed_hits": f"{acq_ok}/{B * C}", "channels_lost": int(state["lost"].sum()),
-                      "symbol_agreement_ok_fraction": sym_ok, **per_stream_ms},
+                      "symbol_agreement_ok_fraction": sym_ok, "speculative_fast_path_fraction": spec_fast, **per_stream_ms},
         }
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_cfg3(fs, n)

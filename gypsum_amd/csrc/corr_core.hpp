@@ -312,6 +312,46 @@ __device__ __forceinline__ cf carrier_from_cycles_fast(double u) {
     const float c = (qi & 2) ? -c1 : c1, s = (qi & 2) ? -s1 : s1;    // and by 180 if bit 1 set
     return make_float2(c, -s);
 }
+// float64 carrier exp(-2*pi*i*u): the same reduction, Taylor series of sin / cos(t), |t| <= pi/4, through t^15 / t^16
+// (truncation < 5e-17).  Used where a result feeds int(): the early/late boundary sums behind the DLL discriminator
+// (tracker.py:293-301), whose float32 evaluation put int(self.phase) on the wrong side of an integer once per ~1e6 ms.
+__device__ __forceinline__ double2 carrier64(double u) {
+    const double x = u - rint(u);
+    const double qf = rint(4.0 * x);
+    const double t = 6.283185307179586476925 * fma(qf, -0.25, x);
+    const double z = t * t;
+    double sn = fma(z, -1.0 / 1307674368000.0, 1.0 / 6227020800.0);
+    sn = fma(sn, z, -1.0 / 39916800.0);
+    sn = fma(sn, z, 1.0 / 362880.0);
+    sn = fma(sn, z, -1.0 / 5040.0);
+    sn = fma(sn, z, 1.0 / 120.0);
+    sn = fma(sn, z, -1.0 / 6.0);
+    sn = fma(sn * z, t, t);
+    double cs = fma(z, 1.0 / 20922789888000.0, -1.0 / 87178291200.0);
+    cs = fma(cs, z, 1.0 / 479001600.0);
+    cs = fma(cs, z, -1.0 / 3628800.0);
+    cs = fma(cs, z, 1.0 / 40320.0);
+    cs = fma(cs, z, -1.0 / 720.0);
+    cs = fma(cs, z, 1.0 / 24.0);
+    cs = fma(cs, z, -0.5);
+    cs = fma(cs, z, 1.0);
+    const int qi = (int)qf & 3;
+    const double c1 = (qi & 1) ? -sn : cs, s1 = (qi & 1) ? cs : sn;
+    const double c = (qi & 2) ? -c1 : c1, s = (qi & 2) ? -s1 : s1;
+    return make_double2(c, -s);
+}
+// exp(-2*pi*i*u) for |u| <= 1e-3 cycles (one sample of carrier at any Doppler the search covers): three Taylor terms
+// each, truncation < 1e-19.
+__device__ __forceinline__ double2 carrier64_small(double u) {
+    const double t = 6.283185307179586476925 * u, z = t * t;
+    const double sn = t * fma(z, fma(z, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+    const double cs = fma(z, fma(z, fma(z, -1.0 / 720.0, 1.0 / 24.0), -0.5), 1.0);
+    return make_double2(cs, -sn);
+}
+__device__ __forceinline__ double2 cmul64(double2 a, double2 b) {
+    return make_double2(fma(a.x, b.x, -a.y * b.y), fma(a.x, b.y, a.y * b.x));
+}
+
 // The two per-millisecond rotation constants of the wipe-off recurrence.
 struct CarrierSteps {
     cf rot1;      // exp(-2*pi*i*du): one sample
@@ -428,16 +468,17 @@ __device__ __forceinline__ cf next_lane(cf v) {   // lane i <- lane i+1, lane 63
     return make_float2(__uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v.x), 0x130, 0xF, 0xF, false)),
                        __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v.y), 0x130, 0xF, 0xF, false)));
 }
+// `anchor[c]`: the carrier at the first sample of the thread's c-th chip.
 template <int K>
-__device__ __forceinline__ void stage_emit_own(OwnSamples<K>& s, double u0, double du, const CarrierSteps& cs,
-                                               cf* (&y_rows)[K], cf* __restrict__ halo, int tid) {
+__device__ __forceinline__ void stage_emit_own_anchored(OwnSamples<K>& s, const cf (&anchor)[OwnSamples<K>::CH], const CarrierSteps& cs,
+                                                        cf* (&y_rows)[K], cf* __restrict__ halo, int tid) {
     const cf rot1 = cs.rot1;
     const int lane = tid & 63;
 #pragma unroll
     for (int c = 0; c < OwnSamples<K>::CH; ++c) {
         const int m = tid + c * OwnSamples<K>::T;   // m == kChips (padding chip) carries zeros: writes y_r[1023] = 0
         cf (&w)[K] = s.w[c];
-        cf car = carrier_from_cycles_fast(u0 + du * (double)(K * m));
+        cf car = anchor[c];
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             w[i] = cmul(w[i], car);
@@ -459,6 +500,15 @@ __device__ __forceinline__ void stage_emit_own(OwnSamples<K>& s, double u0, doub
         }
         y_rows[0][m] = cadd(suf, w[0]);
     }
+}
+template <int K>
+__device__ __forceinline__ void stage_emit_own(OwnSamples<K>& s, double u0, double du, const CarrierSteps& cs,
+                                               cf* (&y_rows)[K], cf* __restrict__ halo, int tid) {
+    cf anchor[OwnSamples<K>::CH];
+#pragma unroll
+    for (int c = 0; c < OwnSamples<K>::CH; ++c)
+        anchor[c] = carrier_from_cycles_fast(u0 + du * (double)(K * (tid + c * OwnSamples<K>::T)));
+    stage_emit_own_anchored<K>(s, anchor, cs, y_rows, halo, tid);
 }
 // Row loader side: x[j] holds y[32*j + l] of branch `r`; chips 63 + 64*k (k = 0..14) take P_r of chip 64*(k+1),
 // chip 1022 takes P_r of chip 0 (the block is circular; the wipe-off of a wrapped sample is the one of its index).
@@ -605,6 +655,13 @@ __device__ __forceinline__ double wave_sum(double v) {
     v += dpp_d<kDppHalfMirror>(v);
     v += dpp_d<kDppMirror>(v);
     return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_f<kDppXor1>(v);
+    v += dpp_f<kDppXor2>(v);
+    v += dpp_f<kDppHalfMirror>(v);
+    v += dpp_f<kDppMirror>(v);
+    return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
 }
 __device__ __forceinline__ int wave_sum(int v) {
     v += dpp_i<kDppXor1>(v);

@@ -125,6 +125,11 @@ struct gyp_ctx {
     cf* d_tw = nullptr;        // tw1024[1024] ++ tw2048[1024]
     uint8_t* d_chips = nullptr;  // [32][1023]: synthetic generator, float64 tie-breaks
     uint16_t* d_ones = nullptr;  // [32][512]: positions of the 512 ones of each code (float64 strength tie-break)
+    uint16_t* d_trans = nullptr; // [32][kMaxTrans]: chip transitions (float64 early/late boundary sums)
+    int32_t* d_ntrans = nullptr; // [32]
+    float* d_chipf = nullptr;    // [32][2048]: +-1.0f codes, twice over (window correlations of the speculative tracker)
+    bool no_spec = false;        // GYP_NO_SPEC=1: A/B switch back to the non-speculative latency kernel
+    float spec_kappa = 20.0f;    // GYP_SPEC_KAPPA: confidence threshold of the speculative tracker
     long long* d_prof = nullptr; // debug: per-phase cycle counters of track_block workgroup 0
     // growable scratch for the host-buffer entry points and the acquisition driver
     void* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -135,6 +140,15 @@ struct gyp_bank {
     gyp_ctx* ctx = nullptr;
     int n_chan = 0;
     ChanState* d_states = nullptr;
+    // speculative block tracking: state checkpoint, per-(channel, ms) hand-over records, failed-verification flags
+    ChanState* d_ckpt = nullptr;
+    SpecIn* d_spec = nullptr;
+    size_t spec_cap = 0;         // in records
+    int32_t* d_bad = nullptr;
+    float* d_dbg = nullptr;      // GYP_SPEC_DEBUG: per-ms window dump of the last block
+    size_t dbg_cap = 0;
+    hipStream_t verify_stream = nullptr;
+    hipEvent_t ev_spec = nullptr, ev_verify = nullptr;
 };
 
 static int fail(gyp_ctx* ctx, int code, const std::string& msg) {
@@ -187,6 +201,8 @@ int gyp_create(int device_ordinal, gyp_ctx** out) {
     ctx->device = device_ordinal;
     ctx->n_cus = prop.multiProcessorCount;
     ctx->no_pipe = std::getenv("GYP_NO_PIPE") != nullptr;
+    ctx->no_spec = std::getenv("GYP_NO_SPEC") != nullptr;
+    if (const char* kv = std::getenv("GYP_SPEC_KAPPA")) ctx->spec_kappa = (float)std::atof(kv);
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         delete ctx;
@@ -207,6 +223,9 @@ void gyp_destroy(gyp_ctx* ctx) {
     if (ctx->d_tw) (void)hipFree(ctx->d_tw);
     if (ctx->d_chips) (void)hipFree(ctx->d_chips);
     if (ctx->d_ones) (void)hipFree(ctx->d_ones);
+    if (ctx->d_trans) (void)hipFree(ctx->d_trans);
+    if (ctx->d_ntrans) (void)hipFree(ctx->d_ntrans);
+    if (ctx->d_chipf) (void)hipFree(ctx->d_chipf);
     if (ctx->d_prof) (void)hipFree(ctx->d_prof);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -304,6 +323,27 @@ int gyp_set_stream_format(gyp_ctx* ctx, int64_t fs_hz, int32_t samples_per_ms) {
         }
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_ones, ones.size() * sizeof(uint16_t)));
         HIP_TRY(ctx, hipMemcpy(ctx->d_ones, ones.data(), ones.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        // chip transitions m (chip[m-1] != chip[m], indices mod 1023) with the sign of chip[m-1] - chip[m] as +-1 codes,
+        // and the +-1 codes themselves laid out twice so that chip[(j - q) mod 1023] is chipf[j - q + 1023]
+        std::vector<uint16_t> trans((size_t)32 * kMaxTrans, 0);
+        std::vector<int32_t> ntrans(32, 0);
+        std::vector<float> chipf((size_t)32 * 2048);
+        for (int sv = 0; sv < 32; ++sv) {
+            const uint8_t* c = chips.data() + (size_t)sv * kChips;
+            int nt = 0;
+            for (int m = 0; m < kChips; ++m) {
+                const int prev = c[(m + kChips - 1) % kChips], cur = c[m];
+                if (prev != cur) trans[(size_t)sv * kMaxTrans + nt++] = (uint16_t)(m | (prev < cur ? 0x8000 : 0));
+            }
+            ntrans[sv] = nt;
+            for (int i = 0; i < 2048; ++i) chipf[(size_t)sv * 2048 + i] = c[i % kChips] ? 1.0f : -1.0f;
+        }
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_trans, trans.size() * sizeof(uint16_t)));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_trans, trans.data(), trans.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_ntrans, ntrans.size() * sizeof(int32_t)));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_ntrans, ntrans.data(), ntrans.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_chipf, chipf.size() * sizeof(float)));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_chipf, chipf.data(), chipf.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     ctx->fs = fs_hz;
     ctx->n = samples_per_ms;
@@ -389,19 +429,29 @@ static int launch_track_step(gyp_ctx* ctx, const TrackStepParams& p) {
 }
 
 template <bool PROF>
-static int launch_track_block_t(gyp_ctx* ctx, const TrackBlockParams& p) {
+static int launch_track_block_t(gyp_ctx* ctx, const TrackBlockParams& p, int mode) {
     const int grid = p.n_chan;
-    if (ctx->k == 8 && p.n_chan <= ctx->n_cus && !ctx->no_pipe)   // lightly loaded chip: one workgroup per CU anyway
-        return launch_k(ctx, track_block_kernel<8, PROF, true>, 8, grid, p, lds_bytes<8>() + kTablesBytes);
+    if (mode == 2) return launch_k(ctx, track_block_kernel<8, PROF, 2>, 8, grid, p, lds_bytes_spec<8>());
+    if (mode == 1) return launch_k(ctx, track_block_kernel<8, PROF, 1>, 8, grid, p, lds_bytes<8>() + kTablesBytes);
     switch (ctx->k) {
-#define X(K) case K: return launch_k(ctx, track_block_kernel<K, PROF>, K, grid, p, lds_bytes<K>());
+#define X(K) case K: return launch_k(ctx, track_block_kernel<K, PROF, 0>, K, grid, p, lds_bytes<K>());
         GYP_FOR_EACH_RATE(X)
 #undef X
     }
     return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
 }
-static int launch_track_block(gyp_ctx* ctx, const TrackBlockParams& p) {
-    return p.prof ? launch_track_block_t<true>(ctx, p) : launch_track_block_t<false>(ctx, p);
+// mode 0: throughput kernel; 1: latency variant (at most one workgroup per CU); 2: latency variant + speculation
+static int launch_track_block(gyp_ctx* ctx, const TrackBlockParams& p, int mode) {
+    return p.prof ? launch_track_block_t<true>(ctx, p, mode) : launch_track_block_t<false>(ctx, p, mode);
+}
+static int launch_track_verify(gyp_ctx* ctx, const TrackVerifyParams& p, hipStream_t stream) {
+    const int n_units = p.n_chan * (p.ms_end - p.ms_begin);
+    const int grid = std::max(8, std::min(n_units, ctx->n_cus * blocks_per_cu(8)) & ~7);
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(track_verify_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_bytes<8>()));
+    hipLaunchKernelGGL(track_verify_kernel<8>, dim3(grid), dim3(threads_for(8)), lds_bytes<8>(), stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    return GYP_OK;
 }
 
 extern "C" {
@@ -674,6 +724,9 @@ int gyp_track_step_dev(gyp_ctx* ctx, const float* iq_dev, int64_t stream_stride_
     p.replica_table = ctx->d_replicas;
     p.tw_tables = ctx->d_tw;
     p.inv_fs = 1.0 / (double)ctx->fs;
+    p.trans = ctx->d_trans;
+    p.n_trans = ctx->d_ntrans;
+    p.chipf = ctx->d_chipf;
     return launch_track_step(ctx, p);
 }
 
@@ -744,6 +797,13 @@ void gyp_bank_destroy(gyp_bank* bank) {
     if (!bank) return;
     (void)hipStreamSynchronize(bank->ctx->stream);
     if (bank->d_states) (void)hipFree(bank->d_states);
+    if (bank->d_ckpt) (void)hipFree(bank->d_ckpt);
+    if (bank->d_spec) (void)hipFree(bank->d_spec);
+    if (bank->d_bad) (void)hipFree(bank->d_bad);
+    if (bank->d_dbg) (void)hipFree(bank->d_dbg);
+    if (bank->verify_stream) { (void)hipStreamSynchronize(bank->verify_stream); (void)hipStreamDestroy(bank->verify_stream); }
+    if (bank->ev_spec) (void)hipEventDestroy(bank->ev_spec);
+    if (bank->ev_verify) (void)hipEventDestroy(bank->ev_verify);
     delete bank;
 }
 
@@ -779,6 +839,72 @@ int gyp_bank_drop_channel(gyp_bank* bank, int32_t index) {
     return GYP_OK;
 }
 
+// Speculative block tracking (8.184 Msps, at most one channel per CU): the tracking kernel advances on window maxima
+// (track_block_kernel MODE 2) in sub-blocks; each sub-block's full profiles are verified by track_verify_kernel on a
+// second stream while the next sub-block is being tracked; channels that failed verification are re-run from the
+// checkpoint by the transform kernel.  Everything is enqueued; nothing synchronises with the host.
+static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
+    gyp_ctx* ctx = bank->ctx;
+    const size_t n_rec = (size_t)bank->n_chan * p.n_ms;
+    if (!bank->d_ckpt) {
+        HIP_TRY(ctx, hipMalloc((void**)&bank->d_ckpt, (size_t)bank->n_chan * sizeof(ChanState)));
+        HIP_TRY(ctx, hipMalloc((void**)&bank->d_bad, (size_t)bank->n_chan * sizeof(int32_t)));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&bank->verify_stream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&bank->ev_spec, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&bank->ev_verify, hipEventDisableTiming));
+    }
+    if (bank->spec_cap < n_rec) {
+        if (bank->d_spec) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(bank->verify_stream));
+            HIP_TRY(ctx, hipFree(bank->d_spec));
+            bank->d_spec = nullptr;
+            bank->spec_cap = 0;
+        }
+        HIP_TRY(ctx, hipMalloc((void**)&bank->d_spec, n_rec * sizeof(SpecIn)));
+        bank->spec_cap = n_rec;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(bank->d_ckpt, bank->d_states, (size_t)bank->n_chan * sizeof(ChanState), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(bank->d_bad, 0, (size_t)bank->n_chan * sizeof(int32_t), ctx->stream));
+    p.spec_out = bank->d_spec;
+    p.spec_kappa = ctx->spec_kappa;
+    if (std::getenv("GYP_SPEC_DEBUG")) {
+        if (bank->dbg_cap < n_rec * 20) {
+            if (bank->d_dbg) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(bank->d_dbg)); }
+            HIP_TRY(ctx, hipMalloc((void**)&bank->d_dbg, n_rec * 20 * sizeof(float)));
+            bank->dbg_cap = n_rec * 20;
+        }
+        p.dbg = bank->d_dbg;
+    }
+    TrackVerifyParams v;
+    v.iq = p.iq; v.stream_stride = p.stream_stride; v.n_ms = p.n_ms; v.start_time = p.start_time;
+    v.states = bank->d_states; v.n_chan = bank->n_chan; v.spec = bank->d_spec; v.rec_out = p.rec_out; v.bad = bank->d_bad;
+    v.replica_table = ctx->d_replicas; v.tw_tables = ctx->d_tw; v.inv_fs = p.inv_fs; v.tie_tol = 4e-6f;
+    const int n_sub = p.n_ms >= 256 ? 4 : 1;
+    const int sub = (p.n_ms + n_sub - 1) / n_sub;
+    int rc;
+    for (int b0 = 0; b0 < p.n_ms; b0 += sub) {
+        p.ms_begin = b0;
+        p.ms_end = std::min(p.n_ms, b0 + sub);
+        if ((rc = launch_track_block(ctx, p, 2))) return rc;
+        HIP_TRY(ctx, hipEventRecord(bank->ev_spec, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(bank->verify_stream, bank->ev_spec, 0));
+        v.ms_begin = p.ms_begin;
+        v.ms_end = p.ms_end;
+        if ((rc = launch_track_verify(ctx, v, bank->verify_stream))) return rc;
+    }
+    HIP_TRY(ctx, hipEventRecord(bank->ev_verify, bank->verify_stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, bank->ev_verify, 0));
+    // channels whose window maximum was not the global one (never observed on real signals; any count is handled)
+    p.ms_begin = 0;
+    p.ms_end = p.n_ms;
+    p.spec_out = nullptr;
+    p.dbg = nullptr;
+    p.only_if = bank->d_bad;
+    p.restore_from = bank->d_ckpt;
+    return launch_track_block(ctx, p, 0);
+}
+
 int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stride_samples, int32_t n_ms,
                         const double* start_time_dev, gyp_track_rec* rec_out_dev) {
     if (!bank) return GYP_E_BAD_ARG;
@@ -789,6 +915,8 @@ int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stri
     p.iq = reinterpret_cast<const cf*>(iq_dev);
     p.stream_stride = stream_stride_samples;
     p.n_ms = n_ms;
+    p.ms_begin = 0;
+    p.ms_end = n_ms;
     p.start_time = start_time_dev;
     p.states = bank->d_states;
     p.n_chan = bank->n_chan;
@@ -798,7 +926,15 @@ int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stri
     p.inv_fs = 1.0 / (double)ctx->fs;
     p.fs = (double)ctx->fs;
     p.prof = ctx->d_prof;
-    return launch_track_block(ctx, p);
+    p.codes = CodeTables{ctx->d_trans, ctx->d_ntrans, ctx->d_chipf};
+    p.spec_out = nullptr;
+    p.spec_kappa = ctx->spec_kappa;
+    p.only_if = nullptr;
+    p.restore_from = nullptr;
+    p.dbg = nullptr;
+    const bool light = ctx->k == 8 && p.n_chan <= ctx->n_cus && !ctx->no_pipe;   // one workgroup per CU anyway
+    if (light && !ctx->no_spec) return track_block_speculative(bank, p);
+    return launch_track_block(ctx, p, light ? 1 : 0);
 }
 
 int gyp_track_block(gyp_bank* bank, const float* iq_host, int32_t n_streams, int32_t n_ms, const double* start_time_host,
@@ -820,6 +956,15 @@ int gyp_track_block(gyp_bank* bank, const float* iq_host, int32_t n_streams, int
     if (rc) return rc;
     if (rec_out_host) HIP_TRY(ctx, hipMemcpyAsync(rec_out_host, ctx->scratch[5], rec_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GYP_OK;
+}
+
+int gyp_debug_spec_read(gyp_bank* bank, float* out, int32_t n_floats, int32_t* bad_out) {
+    if (!bank) return GYP_E_BAD_ARG;
+    gyp_ctx* ctx = bank->ctx;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (out && bank->d_dbg) HIP_TRY(ctx, hipMemcpy(out, bank->d_dbg, std::min((size_t)n_floats, bank->dbg_cap) * sizeof(float), hipMemcpyDeviceToHost));
+    if (bad_out && bank->d_bad) HIP_TRY(ctx, hipMemcpy(bad_out, bank->d_bad, (size_t)bank->n_chan * sizeof(int32_t), hipMemcpyDeviceToHost));
     return GYP_OK;
 }
 

@@ -78,7 +78,8 @@ struct LoopState {
 
 struct RedScratch {
     WaveCand cand[16];
-    float taps[4];      // early re/im, late re/im
+    float taps[6];      // early re/im, late re/im, probe re/im (the value at one more lag of the caller's choice)
+    double eldelta[4];  // float64 boundary sums c0[s] - c0[s-1] and c0[s+1] - c0[s] (re, im each), see el_delta_partial
     double dstate[4];   // new doppler, new carrier phase
     int istate[4];      // new code phase, lost flag
     CarrierSteps steps; // rotation constants of the next millisecond's wipe-off
@@ -843,6 +844,9 @@ struct TrackStepParams {
     const cf* replica_table;
     const cf* tw_tables;
     double inv_fs;
+    const uint16_t* trans;     // CodeTables
+    const int32_t* n_trans;
+    const float* chipf;
 };
 
 __device__ __forceinline__ int mod_n(int v, int n) {
@@ -853,7 +857,7 @@ __device__ __forceinline__ int mod_n(int v, int n) {
 // E/P/L of one millisecond given the un-rolled correlation c0:
 //   early = c0[(s-1) mod N], late = c0[(s+1) mod N], prompt profile[k] = c0[(s+k) mod N].
 struct EplResult {
-    cf early, late, peak;
+    cf early, late, peak, probe;
     Best best;   // best.key = peak offset in the rolled profile, best.v = |peak|
     double sum;
     int n_max;
@@ -862,7 +866,7 @@ struct EplResult {
 // One round's 16 lags per lane: publish the early / late taps if this lane owns them, feed the running profile
 // statistics (keys = index in the profile of the PRN rolled by s, so ties resolve like np.argmax on that profile).
 template <int K>
-__device__ __forceinline__ void epl_round(const cf (&c)[16], int rho, int s, LaneStats& ls, RedScratch* red,
+__device__ __forceinline__ void epl_round(const cf (&c)[16], int rho, int s, int probe, LaneStats& ls, RedScratch* red,
                                           float* profile_row, int tid) {
     constexpr int N = K * kChips;
     constexpr int W = Geom<K>::W;
@@ -873,8 +877,8 @@ __device__ __forceinline__ void epl_round(const cf (&c)[16], int rho, int s, Lan
     // Lag index idx lives in round (idx % K) / W, wavefront (idx % K) % W, lane (q & 31) + 32*(q >> 9),
     // slot (q >> 5) & 15 with q = idx / K: all wave-uniform.
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int idx = t ? il : ie, q = idx / K, r = idx % K;
+    for (int t = 0; t < 3; ++t) {
+        const int idx = t == 0 ? ie : (t == 1 ? il : probe), q = idx / K, r = idx % K;
         if (r / W == rho && (tid >> 6) == r % W && (tid & 63) == (q & 31) + 32 * (q >> 9)) {
             const int slot = (q >> 5) & 15;
 #pragma unroll
@@ -897,7 +901,7 @@ __device__ __forceinline__ void epl_round(const cf (&c)[16], int rho, int s, Lan
 // first-index key, the complex value there and the count of equal maxima.  Same results as the per-lane running
 // statistics (same float summation order, ties by lowest key), ~200 fewer VALU instructions per millisecond.
 template <int K>
-__device__ __forceinline__ void epl_round_wave(const cf (&c)[16], int s, RedScratch* red, float* profile_row, int tid) {
+__device__ __forceinline__ void epl_round_wave(const cf (&c)[16], int s, int probe, RedScratch* red, float* profile_row, int tid) {
     static_assert(Geom<K>::R == 1, "single round only");
     constexpr int N = K * kChips;
     constexpr int W = Geom<K>::W;
@@ -906,8 +910,8 @@ __device__ __forceinline__ void epl_round_wave(const cf (&c)[16], int s, RedScra
 #pragma unroll
     for (int j = 0; j < 16; ++j) pw[j] = fmaf(c[j].x, c[j].x, c[j].y * c[j].y);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int idx = t ? il : ie, q = idx / K, r = idx % K;
+    for (int t = 0; t < 3; ++t) {
+        const int idx = t == 0 ? ie : (t == 1 ? il : probe), q = idx / K, r = idx % K;
         if ((tid >> 6) == r % W && (tid & 63) == (q & 31) + 32 * (q >> 9)) {
             const int slot = (q >> 5) & 15;
 #pragma unroll
@@ -952,6 +956,7 @@ __device__ __forceinline__ EplResult epl_finish_wave(RedScratch* red) {
     EplResult r;
     r.early = make_float2(red->taps[0], red->taps[1]);
     r.late = make_float2(red->taps[2], red->taps[3]);
+    r.probe = make_float2(red->taps[4], red->taps[5]);
     r.peak = make_float2(g.re, g.im);
     r.best = Best{__builtin_amdgcn_sqrtf(g.v), g.key};
     r.sum = sum;
@@ -965,6 +970,7 @@ __device__ __forceinline__ EplResult epl_finish(const LaneStats& ls, RedScratch*
     EplResult r;
     r.early = make_float2(red->taps[0], red->taps[1]);
     r.late = make_float2(red->taps[2], red->taps[3]);
+    r.probe = make_float2(red->taps[4], red->taps[5]);
     r.peak = st.peak;
     r.best = st.best;
     r.sum = st.sum;
@@ -973,15 +979,16 @@ __device__ __forceinline__ EplResult epl_finish(const LaneStats& ls, RedScratch*
 }
 
 // One tracking millisecond of one channel: all rounds, then the reductions.
+// `probe`: one more lag (0 <= probe < N) whose complex value is returned in EplResult::probe.
 template <int K>
 __device__ __forceinline__ EplResult track_ms(const cf* __restrict__ block, double u0, double du, const CarrierSteps& cs,
-                                              int code_phase, const Smem& sm, const cf* __restrict__ rep, float* profile_row) {
+                                              int code_phase, int probe, const Smem& sm, const cf* __restrict__ rep, float* profile_row) {
     constexpr int N = K * kChips;
     const int s = mod_n(code_phase, N);
     if constexpr (Geom<K>::R == 1) {
         cf c[16];
         correlate_round<K>(block, 0, u0, du, cs, sm, rep, c);
-        epl_round_wave<K>(c, s, sm.red, profile_row, launder(threadIdx.x));
+        epl_round_wave<K>(c, s, probe, sm.red, profile_row, launder(threadIdx.x));
         return epl_finish_wave<K>(sm.red);
     }
     LaneStats ls = lane_stats_init();
@@ -989,7 +996,7 @@ __device__ __forceinline__ EplResult track_ms(const cf* __restrict__ block, doub
     for (int rho = 0; rho < Geom<K>::R; ++rho) {
         cf c[16];
         correlate_round<K>(block, rho, u0, du, cs, sm, rep, c);
-        epl_round<K>(c, rho, s, ls, sm.red, profile_row, launder(threadIdx.x));
+        epl_round<K>(c, rho, s, probe, ls, sm.red, profile_row, launder(threadIdx.x));
         if (Geom<K>::R > 1) __syncthreads();   // tiles are re-staged by the next round
     }
     return epl_finish<K>(ls, sm.red, launder(threadIdx.x));
@@ -1026,8 +1033,115 @@ __device__ __forceinline__ EplResult track_ms_fetched(OwnSamples<K>& smp, double
     for (int i = 0; i < 32; ++i) x[i] = cmul(x[i], prn[i]);
     __builtin_amdgcn_sched_barrier(0);
     wave_fft_inv(x, c, tile_half, t, l, h);
-    epl_round_wave<K>(c, s, sm.red, nullptr, tid);
+    epl_round_wave<K>(c, s, s, sm.red, nullptr, tid);
     return epl_finish_wave<K>(sm.red);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// float64 early / late taps.  The reference's DLL (tracker.py:293-301) integrates (|E|^2 - |L|^2)/2 * 0.002 and
+// takes int() of the accumulator, so an error of ~1e-6 in the taps lands int(self.phase) on the other side of an
+// integer once per ~1e6 channel-ms.  E and L are single lags either side of the prompt lag s, and neighbouring lags
+// differ only where the replica changes sign inside the sample window:
+//     c0[L+1] - c0[L] = sum_m (chip[m-1] - chip[m]) * xw[(L + K*m) mod N]        (chips as +-1, m mod 1023)
+// -- one sample per chip TRANSITION (~512 of the 1023 chips of a C/A code).  Those two boundary sums are formed in
+// float64 from the raw samples with a float64 carrier; E = P - (c0[s] - c0[s-1]), L = P + (c0[s+1] - c0[s]) with the
+// prompt value P = c0[s].  An error dP in P enters the discriminator only through Re(dP * conj(L - E)), i.e. scaled by
+// the (small) difference of the taps, not by their magnitude.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kMaxTrans = 1024;
+struct CodeTables {
+    const uint16_t* trans;    // [32][kMaxTrans]: bits 0..9 = m, bit 15 set where chip[m-1] - chip[m] == -2 (else +2)
+    const int32_t* n_trans;   // [32]
+    const float* chipf;       // [32][2048]: +-1.0f, chipf[i] = chip[i mod 1023]
+};
+
+// Per-thread partial sums over the transitions e = tid, tid + T, ...:
+//   acc[0..1] = c0[s] - c0[s-1] (re, im),  acc[2..3] = c0[s+1] - c0[s].
+// Split in two so that a latency-bound caller can request the samples (el_fetch) long before it consumes them
+// (el_accumulate); a thread handles at most kElMax transitions (1023 <= kElMax * T for every workgroup size used: the
+// smallest is one wavefront, K == 1, which loops instead -- see el_delta_partial).
+struct ElSample {
+    cf xl, xe;      // raw samples at (s + K*m) mod N and one before
+    int nl;         // (s + K*m) mod N, or -1: nothing to do
+    float g;        // chip[m-1] - chip[m]: +-2
+};
+template <int K>
+__device__ __forceinline__ ElSample el_fetch(const cf* __restrict__ block, int sN, const uint16_t* trans, int nt, int e) {
+    constexpr int N = K * kChips;
+    ElSample s;
+    s.nl = -1; s.g = 0.f; s.xl = s.xe = make_float2(0.f, 0.f);
+    if (e < nt) {
+        const unsigned t = trans[e];
+        const int m = (int)(t & 0x3ffu);
+        s.g = (t & 0x8000u) ? -2.0f : 2.0f;
+        int nl = sN + K * m;
+        nl = nl >= N ? nl - N : nl;
+        s.nl = nl;
+        s.xl = block[nl];
+        s.xe = block[nl == 0 ? N - 1 : nl - 1];
+    }
+    return s;
+}
+template <int K>
+__device__ __forceinline__ void el_accumulate(const ElSample& s, double u0, double du, double (&acc)[4]) {
+    constexpr int N = K * kChips;
+    if (s.nl < 0) return;
+    const double2 cl = carrier64(u0 + du * (double)s.nl);
+    // carrier(n-1) = carrier(n) * exp(+2*pi*i*du); the sample before sample 0 is sample N-1 of the same block
+    const double2 ce = s.nl == 0 ? carrier64(u0 + du * (double)(N - 1)) : cmul64(cl, carrier64_small(-du));
+    const double2 pl = cmul64(make_double2((double)s.xl.x, (double)s.xl.y), cl);
+    const double2 pe = cmul64(make_double2((double)s.xe.x, (double)s.xe.y), ce);
+    const double g = (double)s.g;
+    acc[0] = fma(g, pe.x, acc[0]); acc[1] = fma(g, pe.y, acc[1]);
+    acc[2] = fma(g, pl.x, acc[2]); acc[3] = fma(g, pl.y, acc[3]);
+}
+template <int K>
+__device__ __forceinline__ void el_delta_partial(const cf* __restrict__ block, double u0, double du, int sN,
+                                                 const uint16_t* __restrict__ trans, int nt, int tid, double (&acc)[4]) {
+    constexpr int T = Geom<K>::kThreads;
+    acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
+    for (int e = tid; e < nt; e += T) {
+        const ElSample s = el_fetch<K>(block, sN, trans, nt, e);
+        el_accumulate<K>(s, u0, du, acc);
+    }
+}
+// Sum NV values whose per-thread partials sit at part[v*T + tid], in a fixed order (the result does not depend on
+// timing): value v is summed by wavefront (first_wave + v) mod W; fin[v] is valid after the caller's next barrier.
+template <int K, int NV>
+__device__ __forceinline__ void sum_partials64(const double* part, double* fin, int first_wave, int tid) {
+    constexpr int T = Geom<K>::kThreads, W = Geom<K>::W;
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        if ((first_wave + v) % W != wave) continue;   // wave-uniform
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) a += part[v * T + lane + 64 * k];
+        a = wave_sum(a);
+        if (lane == 0) fin[v] = a;
+    }
+}
+// tracker.py:297: ((E.re^2 + E.im^2) - (L.re^2 + L.im^2)) / 2 from the prompt value and the boundary sums.
+__device__ __forceinline__ double dll_discriminator(double p_re, double p_im, const double* d) {
+    const double er = p_re - d[0], ei = p_im - d[1], lr = p_re + d[2], li = p_im + d[3];
+    return ((er * er + ei * ei) - (lr * lr + li * li)) / 2.0;
+}
+// After a track_ms(): every wavefront is past the transforms, so the tile region is free to hold the partials.
+// Two workgroup barriers; red->eldelta[0..3] valid in every thread afterwards.
+template <int K>
+__device__ __forceinline__ void el_delta_workgroup(const cf* __restrict__ block, double u0, double du, int code_phase,
+                                                   const CodeTables& ct, int sat_index, const Smem& sm) {
+    constexpr int N = K * kChips;
+    constexpr int T = Geom<K>::kThreads;
+    const int tid = launder(threadIdx.x);
+    double acc[4];
+    el_delta_partial<K>(block, u0, du, mod_n(code_phase, N), ct.trans + sat_index * kMaxTrans, ct.n_trans[sat_index], tid, acc);
+    double* part = reinterpret_cast<double*>(sm.xch);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) part[v * T + tid] = acc[v];
+    __syncthreads();
+    sum_partials64<K, 4>(part, sm.red->eldelta, 0, tid);
+    __syncthreads();
 }
 
 template <int K>
@@ -1043,12 +1157,17 @@ __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void 
         // tracker.py:271-281: carrier = exp(-1j*(2*pi*f*t + phi)), t = n/fs + chunk.start_time
         const double du = in.doppler_hz * p.inv_fs;
         const double u0 = in.doppler_hz * p.start_time[in.stream] + in.carrier_phase * 0.15915494309189533577;
-        const EplResult r = track_ms<K>(p.iq + (int64_t)in.stream * p.stream_stride, u0, du, carrier_steps<K>(du), in.code_phase,
+        const cf* block = p.iq + (int64_t)in.stream * p.stream_stride;
+        const EplResult r = track_ms<K>(block, u0, du, carrier_steps<K>(du), in.code_phase, mod_n(in.code_phase, N),
                                         sm, rep, p.profile_out ? p.profile_out + (int64_t)ch * N : nullptr);
+        el_delta_workgroup<K>(block, u0, du, in.code_phase, CodeTables{p.trans, p.n_trans, p.chipf}, in.sat_id - 1, sm);
         if (threadIdx.x == 0) {
             gyp_chan_out o;
             o.early_re = r.early.x; o.early_im = r.early.y;
             o.late_re = r.late.x; o.late_im = r.late.y;
+            const double* d = sm.red->eldelta;
+            o.early64_re = (double)r.probe.x - d[0]; o.early64_im = (double)r.probe.y - d[1];
+            o.late64_re = (double)r.probe.x + d[2]; o.late64_im = (double)r.probe.y + d[3];
             o.peak_re = r.peak.x; o.peak_im = r.peak.y;
             o.peak_mag = r.best.v;
             o.peak_offset = r.best.key;
@@ -1099,21 +1218,24 @@ struct LockVerdict {
 
 __device__ __forceinline__ bool near(double v, double thr) { return fabs(v - thr) <= 1e-9 * thr; }
 
-// is_locked() from the sliding sums (any lane; pure scalar math).
+// is_locked() from the sliding sums (any lane; pure scalar math, no divisions: every comparison is multiplied through
+// by its positive denominators).  Anything within 1e-9 (relative) of a threshold is re-decided by the exact two-pass
+// evaluation.
 __device__ __forceinline__ LockVerdict lock_from_sums(const LockSums& s, int64_t n_err) {
     LockVerdict out{false, false};
     if (n_err < kLockWindow) return out;                       // tracker.py:164-167
-    // one-pass moments with reciprocal multiplies (no float64 divides on the per-ms path); anything within 1e-9 of
-    // a threshold is re-decided by the exact two-pass evaluation
-    const double rw = 1.0 / kLockWindow;
-    const double me = s.se * rw;
-    const double ve = s.see * rw - me * me;
-    const double rn = s.cn >= 2 ? 1.0 / (double)s.cn : 0.0, rp = s.cp >= 2 ? 1.0 / (double)s.cp : 0.0;
-    const double vneg = s.nrr * rn - (s.nr * rn) * (s.nr * rn);
-    const double vpos = s.prr * rp - (s.pr * rp) * (s.pr * rp);
-    const double iv = (vneg + vpos) / 2.0;
-    const bool var_ok = ve < 900.0, i_ok = iv < 2.0;
-    out.marginal = near(ve, 900.0) || near(iv, 2.0);
+    constexpr double W = (double)kLockWindow;
+    // var(errors) = see/W - (se/W)^2 < 900   <=>   see*W - se^2 < 900*W^2
+    const double xe = s.see * W - s.se * s.se, te = 900.0 * W * W;
+    const bool var_ok = xe < te;
+    // mean of the two pole variances < 2, a pole with fewer than two members counting 0 (tracker.py:176-186):
+    //   A/cn^2 + B/cp^2 < 4  with A = nrr*cn - nr^2, B = prr*cp - pr^2
+    const double cn = (double)s.cn, cp = (double)s.cp;
+    const double a = s.cn >= 2 ? s.nrr * cn - s.nr * s.nr : 0.0, b = s.cp >= 2 ? s.prr * cp - s.pr * s.pr : 0.0;
+    const double cn2 = s.cn >= 2 ? cn * cn : 1.0, cp2 = s.cp >= 2 ? cp * cp : 1.0;
+    const double xi = a * cp2 + b * cn2, ti = 4.0 * cn2 * cp2;
+    const bool i_ok = xi < ti;
+    out.marginal = fabs(xe - te) <= 1e-9 * te || fabs(xi - ti) <= 1e-9 * ti;
     bool rot_ok = true;
     if (var_ok && i_ok && s.cn >= 2) {
         // tracker.py:190-197: the mean of the negative pole must lie within 6 degrees of the real axis (mod 180; the
@@ -1214,10 +1336,19 @@ __device__ __forceinline__ void constellation_stats_wave(const ChanState* st, in
     out[2] = 1.0;
 }
 
+// What the speculative kernel hands to the verify kernel for one millisecond of one channel.
+struct SpecIn {
+    double doppler, carrier_phase;   // loop state the millisecond was processed with
+    int32_t code_phase;
+    int32_t key;                     // window arg-max as an index into the rolled profile; < 0: the millisecond took the
+                                     // full-transform path inside the tracking kernel (its record is already complete)
+};
+
 struct TrackBlockParams {
     const cf* iq;
     int64_t stream_stride;
-    int32_t n_ms;
+    int32_t n_ms;              // milliseconds in the caller's block (row length of rec_out / spec_out)
+    int32_t ms_begin, ms_end;  // the part of it this launch advances through
     const double* start_time;  // [n_ms]
     ChanState* states;
     int32_t n_chan;
@@ -1227,6 +1358,14 @@ struct TrackBlockParams {
     double inv_fs;
     double fs;
     long long* prof;           // optional: per-phase cycle counters of workgroup 0 (debug)
+    CodeTables codes;
+    // speculative mode (MODE 2)
+    SpecIn* spec_out;          // [n_chan][n_ms]
+    float spec_kappa;          // window peak^2 must reach spec_kappa * (energy of the millisecond's samples)
+    // re-run mode: only channels with only_if[ch] != 0 run, after restoring their state from restore_from[ch]
+    const int32_t* only_if;
+    const ChanState* restore_from;
+    float* dbg;                // optional [n_chan][n_ms][20]: |window|^2 x 16, sample energy, code phase mod N, 0, 0 (debug)
 };
 
 __device__ __forceinline__ void workgroup_mem_fence_wave() {
@@ -1235,25 +1374,272 @@ __device__ __forceinline__ void workgroup_mem_fence_wave() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// LAT: latency variant for at most one workgroup per CU (see track_ms_fetched); needs kTablesBytes more LDS.
-template <int K, bool PROF, bool LAT = false>
-__global__ __launch_bounds__(Geom<K>::kThreads, LAT ? 2 : Geom<K>::kMinWavesPerSimd) void track_block_kernel(TrackBlockParams p) {
-    static_assert(!LAT || kOwnStaging<K>, "the latency variant exists for the own-staging rates");
+// One millisecond's correlator outputs, as the loop filters consume them.
+struct MsMeasure {
+    cf peak;          // coherent prompt correlation at the arg-max of |prompt|
+    float peak_mag;
+    int key;          // arg-max as an index into the profile of the PRN rolled by the code phase
+    double sum;       // sum |prompt|   (not available on the speculative path: strength_pending)
+    int n_max;
+    double disc;      // (|E|^2 - |L|^2) / 2
+    bool strength_pending;
+    int path_info;    // gyp_track_rec::path_info
+};
+
+// tracker.py:297-303 code loop, :246-262 Costas loop with the is_locked() bandwidth switch, :346-389 histories and
+// circularity watchdog, for one millisecond of one channel; executed by wavefront 0 (all lanes, uniform values; the
+// exact lock / constellation evaluations use the lanes).  Loop state lives in `red` (LDS) and the rings in `st`.
+// The ring entries that leave the 250-ms lock-detector windows in the coming update: {error, peak re, peak im}.  They
+// were written >= 250 ms ago, so a latency-bound caller asks for them at the start of the millisecond.
+__device__ __forceinline__ void fetch_leaving(const ChanState* st, const RedScratch* red, double (&leave)[3]) {
+    leave[0] = leave[1] = leave[2] = 0.0;
+    const int64_t n = red->loop.n_steps;
+    if (n >= kLockWindow) {
+        const int pos_e = red->loop.pos_e, pos_p = red->loop.pos_p;
+        const int pos_leave = pos_p >= kLockWindow ? pos_p - kLockWindow : pos_p - kLockWindow + kPeakHistory;
+        leave[0] = st->err_ring[pos_e];
+        leave[1] = st->peak_re[pos_leave];
+        leave[2] = st->peak_im[pos_leave];
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void loop_filter_update(const TrackBlockParams& p, ChanState* st, RedScratch* red, double t0, int lane,
+                                                   const MsMeasure& r, const double (&leave)[3], gyp_track_rec* rec) {
+    constexpr int N = K * kChips;
+    const double f = red->dstate[0], phi = red->dstate[1];
+    int lost = 0;
+    LoopState ls = red->loop;                       // uniform: every lane reads the same words
+    const int64_t n = ls.n_steps;
+    double dll_phase = ls.dll_phase, last_watchdog = ls.last_watchdog;
+    LockSums sums = ls.sums;
+    int pos_e = ls.pos_e, pos_p = ls.pos_p, pos_refresh = ls.pos_refresh;
+    const double leave_e = leave[0], leave_pr = leave[1], leave_pi = leave[2];
+    // ---- code loop, tracker.py:297-303
+    const double disc = r.disc;
+    double dll = dll_phase + disc * 0.002;
+    const int new_code_phase = (int)dll;           // int() truncates toward zero, before the wrap
+    dll = pymod(dll, 2046.0);
+    if (dll < 0.0) dll += 2046.0;
+    // ---- histories, tracker.py:346-347 (the peak joins the window before is_locked() looks at it)
+    const double pr = (double)r.peak.x, pim = (double)r.peak.y;
+    if (lane == 0) { st->peak_re[pos_p] = pr; st->peak_im[pos_p] = pim; }
+    if (n >= kLockWindow) {
+        if (leave_pr < 0.0) { sums.nr -= leave_pr; sums.ni -= leave_pi; sums.nrr -= leave_pr * leave_pr; --sums.cn; }
+        else { sums.pr -= leave_pr; sums.prr -= leave_pr * leave_pr; --sums.cp; }
+    }
+    if (pr < 0.0) { sums.nr += pr; sums.ni += pim; sums.nrr += pr * pr; ++sums.cn; }
+    else { sums.pr += pr; sums.prr += pr * pr; ++sums.cp; }
+    // ---- Costas loop, tracker.py:246-262
+    const double err = pr * pim;
+    LockVerdict lv = lock_from_sums(sums, n);
+    bool locked = lv.locked;
+    if (lv.marginal || pos_refresh == kLockRefresh - 1) {
+        workgroup_mem_fence_wave();                 // lane 0's ring stores -> every lane of this wavefront
+        LockSums fresh;
+        locked = is_locked_exact_wave(st, n, n + 1, lane, fresh);
+        sums = fresh;
+    }
+    const double bw = locked ? 3.0 : 6.0;
+    const double tps = p.inv_fs;                // == 1.0 / samples_per_second, formed on the host
+    const double alpha = 4.0 * (1.0 / sqrt(2.0)) * bw * tps;
+    const double beta = 4.0 * (bw * bw) * tps;
+    double nphi = pymod(phi + err * alpha, 6.283185307179586);
+    double nf = f + err * beta;
+    // the error joins its window after is_locked() has been evaluated (tracker.py:251,261)
+    if (n >= kLockWindow) { sums.se -= leave_e; sums.see -= leave_e * leave_e; }
+    sums.se += err; sums.see += err * err;
+    if (lane == 0) st->err_ring[pos_e] = err;
+    pos_e = pos_e + 1 == kLockWindow ? 0 : pos_e + 1;
+    pos_p = pos_p + 1 == kPeakHistory ? 0 : pos_p + 1;
+    pos_refresh = pos_refresh + 1 == kLockRefresh ? 0 : pos_refresh + 1;
+    const double rec_f = nf, rec_phi = nphi;
+    // ---- circularity watchdog, tracker.py:370-387
+    int status = 0, nudged = 0;
+    if (t0 - last_watchdog >= 6.0) {
+        workgroup_mem_fence_wave();
+        double cs[3];
+        constellation_stats_wave(st, n + 1, lane, cs);
+        last_watchdog = t0;
+        if (cs[0] >= 0.0) {
+            if (cs[0] < 0.2) { status = 1; lost = 1; }
+            else if (cs[0] < 0.93 && cs[2] != 0.0) {
+                const double sg = cs[1] > 0.0 ? 1.0 : (cs[1] < 0.0 ? -1.0 : 0.0);
+                nf += -sg * 5.0;
+                nphi += sg * (3.141592653589793 / 2.0);
+                nudged = 1;
+            }
+        }
+    }
+    if (lane == 0) {
+        ls.dll_phase = dll; ls.last_watchdog = last_watchdog; ls.n_steps = n + 1; ls.sums = sums;
+        ls.pos_e = pos_e; ls.pos_p = pos_p; ls.pos_refresh = pos_refresh;
+        red->loop = ls;
+        red->dstate[0] = nf; red->dstate[1] = nphi;
+        red->istate[0] = new_code_phase; red->istate[1] = lost;
+        if (kOwnStaging<K>) {   // only the one-sample rotation is used by the halo-free staging
+            const double2 r1 = carrier64_small(nf * p.inv_fs);
+            CarrierSteps cs;
+            cs.rot1 = make_float2((float)r1.x, (float)r1.y);
+            cs.rot_wrap = make_float2(1.f, 0.f);
+            red->steps = cs;
+        } else {
+            red->steps = carrier_steps<K>(nf * p.inv_fs);
+        }
+        if (rec) {
+            gyp_track_rec o;
+            o.peak_re = r.peak.x; o.peak_im = r.peak.y;
+            if (r.strength_pending) {
+                o.strength = 0.0f;                  // filled in by track_verify_kernel
+            } else {
+                const float mean_excl = (float)((r.sum - (double)r.n_max * (double)r.peak_mag) / (double)(N - r.n_max));
+                o.strength = r.peak_mag / mean_excl;
+            }
+            o.discriminator = (float)disc;
+            o.doppler_hz = rec_f; o.carrier_phase = rec_phi; o.error = err;
+            o.code_phase = new_code_phase; o.peak_offset = r.key;
+            o.pseudosymbol = (int8_t)(pr > 0.0 ? 1 : (pr < 0.0 ? -1 : 0));
+            o.locked = locked ? 1 : 0; o.status = (int8_t)status; o.nudged = (int8_t)nudged;
+            o.path_info = r.path_info;
+            *rec = o;
+        }
+    }
+}
+
+// LDS of the speculative mode, after the latency variant's regions.
+constexpr int kSpecPartBytes = 4 * 512 * 8;      // el_delta partials [4][512] float64
+constexpr int kSpecEinBytes = 512 * 4;           // per-thread sample-energy partials
+constexpr int kSpecFinBytes = 256;               // fin64[8], win16 below
+constexpr int kSpecWinBytes = 32 * 8;
+constexpr int kSpecChipBytes = 2048 * 4;
+constexpr int kSpecTransBytes = kMaxTrans * 2;
+template <int K>
+constexpr int lds_bytes_spec() {
+    return lds_bytes<K>() + kTablesBytes + kSpecChipBytes + kSpecTransBytes + kSpecPartBytes + kSpecEinBytes + kSpecFinBytes + kSpecWinBytes;
+}
+struct SpecLds {
+    float* chipf;     // [2048] +-1.0f, this channel's code twice over
+    uint16_t* trans;  // [kMaxTrans] this channel's chip transitions
+    double* part;     // [4][512]
+    float* ein_part;  // [512]
+    double* fin;      // [0..3] boundary sums, [6] (as float) sample energy
+    cf* win;          // [0..15] c0 at the window lags centre-8 .. centre+7, [16] c0 at the prompt lag s
+};
+constexpr int kSpecHalf = 8;   // window: 16 lags centre - 8 .. centre + 7 around the previous millisecond's peak lag
+
+// Window correlations of the speculative path, straight from the staged rows:
+//     c0[K*q + r] = sum_j chip[(j - q) mod 1023] * y_r[j].
+// The window follows the PEAK, not the code phase: the reference's code loop (tracker.py:297-303) is repelled by the peak
+// and parks the code phase ~9 samples to one side of it, so the arg-max of the rolled prompt profile sits at an offset of
+// about +-9 and wanders slowly.  Wavefront w forms the lags centre + w - 8 and centre + w (same polyphase row, code shifted
+// by one chip); wavefront 0 also forms the prompt lag s itself (win[16]), which the discriminator needs.
+template <int K>
+__device__ __forceinline__ void spec_window(const Smem& sm, const SpecLds& sl, int centre, int sN, int tid) {
+    static_assert(K == 8 && Geom<K>::W == 8, "one window lag pair per wavefront");
+    constexpr int N = K * kChips;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    int la = centre + wave - kSpecHalf;
+    la = la < 0 ? la + N : la;
+    const int rw = la % K, qa = la / K;
+    const int qb = qa + 1 == kChips ? 0 : qa + 1;
+    const cf* row = sm.xch + rw * kXchWave + lane;
+    const float* ca = sl.chipf + (kChips - qa) + lane;    // chip[(j - q) mod 1023] = chipf[j - q + 1023]
+    const float* cb = sl.chipf + (kChips - qb) + lane;
+    float ar = 0.f, ai = 0.f, br = 0.f, bi = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const cf y = row[64 * k];
+        const float a = ca[64 * k], b = cb[64 * k];
+        ar = fmaf(a, y.x, ar); ai = fmaf(a, y.y, ai);
+        br = fmaf(b, y.x, br); bi = fmaf(b, y.y, bi);
+    }
+    // the sixteen chips whose neighbour prefix sums live in the halo table (see halo_fixup)
+    const int hk = lane & 15;
+    const int jf = hk < 15 ? 63 + 64 * hk : kChips - 1;
+    const int hrow = (hk < 15 ? hk + 1 : 0) * K;
+    const bool on = lane < 16;
+    {
+        const cf hv = sm.halo[hrow + rw];
+        const float a = on ? sl.chipf[jf - qa + kChips] : 0.f, b = on ? sl.chipf[jf - qb + kChips] : 0.f;
+        ar = fmaf(a, hv.x, ar); ai = fmaf(a, hv.y, ai);
+        br = fmaf(b, hv.x, br); bi = fmaf(b, hv.y, bi);
+    }
+    ar = wave_sum(ar); ai = wave_sum(ai); br = wave_sum(br); bi = wave_sum(bi);
+    if (lane == 0) {
+        sl.win[wave] = make_float2(ar, ai);
+        sl.win[wave + kSpecHalf] = make_float2(br, bi);
+    }
+    if (wave == 0) {
+        const int rs = sN % K, qs = sN / K;
+        const cf* rowp = sm.xch + rs * kXchWave + lane;
+        const float* cp = sl.chipf + (kChips - qs) + lane;
+        float pr = 0.f, pi = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const cf y = rowp[64 * k];
+            const float a = cp[64 * k];
+            pr = fmaf(a, y.x, pr); pi = fmaf(a, y.y, pi);
+        }
+        const cf hv = sm.halo[hrow + rs];
+        const float a = on ? sl.chipf[jf - qs + kChips] : 0.f;
+        pr = fmaf(a, hv.x, pr); pi = fmaf(a, hv.y, pi);
+        pr = wave_sum(pr); pi = wave_sum(pi);
+        if (lane == 0) sl.win[2 * kSpecHalf] = make_float2(pr, pi);
+    }
+}
+
+// MODE 0: throughput form (several workgroups per CU).  MODE 1: latency variant for at most one workgroup per CU
+// (see track_ms_fetched); needs kTablesBytes more LDS.  MODE 2: latency variant + speculation: the millisecond's
+// prompt correlation is evaluated only at the 16 lags around the code phase, directly from the staged rows; if the
+// window maximum is interior and dominates the sample energy (so that no lag outside the window can plausibly exceed
+// it) the loop filters advance on it at once and the full profile -- needed for the strength record, and to PROVE that
+// the window held the global arg-max -- is left to track_verify_kernel, which runs the transforms of all (channel, ms)
+// pairs in parallel afterwards.  Otherwise the millisecond takes the transform path right here, from the same rows.
+template <int K, bool PROF, int MODE = 0>
+__global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPerSimd) void track_block_kernel(TrackBlockParams p) {
+    constexpr bool LAT = MODE >= 1, SPEC = MODE == 2;
+    static_assert(!LAT || kOwnStaging<K>, "the latency variants exist for the own-staging rates");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int N = K * kChips;
     Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
+    SpecLds sl{};
     if (LAT) {
         cf* tw2048 = reinterpret_cast<cf*>(smem_raw + lds_bytes<K>());
         for (int i = threadIdx.x; i < 1024; i += Geom<K>::kThreads) tw2048[i] = p.tw_tables[1024 + i];
         sm.tw2048 = tw2048;
     }
+    if (SPEC) {
+        char* b = smem_raw + lds_bytes<K>() + kTablesBytes;
+        sl.chipf = reinterpret_cast<float*>(b); b += kSpecChipBytes;
+        sl.trans = reinterpret_cast<uint16_t*>(b); b += kSpecTransBytes;
+        sl.part = reinterpret_cast<double*>(b); b += kSpecPartBytes;
+        sl.ein_part = reinterpret_cast<float*>(b); b += kSpecEinBytes;
+        sl.fin = reinterpret_cast<double*>(b); b += kSpecFinBytes;
+        sl.win = reinterpret_cast<cf*>(b);
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
     if ((int)blockIdx.x >= p.n_chan) return;
     const int ch = xcd_contiguous(blockIdx.x, p.n_chan);
+    if (p.only_if && !p.only_if[ch]) return;
     ChanState* st = p.states + ch;
-    const cf* rep = replica_of(p.replica_table, st->sat_id - 1);
+    if (p.restore_from) {   // re-run of a channel whose speculation failed verification: back to the state before the block
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(p.restore_from + ch);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(st);
+        for (int i = threadIdx.x; i < (int)(sizeof(ChanState) / 4); i += Geom<K>::kThreads) dst[i] = src[i];
+        __threadfence();
+        __syncthreads();
+    }
+    const int sat_index = st->sat_id - 1;
+    const cf* rep = replica_of(p.replica_table, sat_index);
     const cf* stream = p.iq + (int64_t)st->stream * p.stream_stride;
+    const uint16_t* trans = p.codes.trans + sat_index * kMaxTrans;
+    const int nt = p.codes.n_trans[sat_index];
+    if (SPEC) {
+        const float* src = p.codes.chipf + sat_index * 2048;
+        for (int i = threadIdx.x; i < 2048; i += Geom<K>::kThreads) sl.chipf[i] = src[i];
+        for (int i = threadIdx.x; i < kMaxTrans; i += Geom<K>::kThreads) sl.trans[i] = trans[i];
+    }
     // Loop state lives in LDS between milliseconds (RedScratch::dstate / istate / steps / loop) and is re-read where
     // it is needed, so that no wavefront carries it in registers across the transforms.
     if (threadIdx.x == 0) {
@@ -1264,142 +1650,171 @@ __global__ __launch_bounds__(Geom<K>::kThreads, LAT ? 2 : Geom<K>::kMinWavesPerS
         sm.red->loop = ls;
         sm.red->dstate[0] = st->doppler; sm.red->dstate[1] = st->carrier_phase;
         sm.red->istate[0] = st->code_phase; sm.red->istate[1] = st->lost;
+        sm.red->istate[2] = mod_n(st->code_phase, N);   // speculative window centre: no peak seen yet in this launch
         sm.red->steps = carrier_steps<K>(st->doppler * p.inv_fs);
     }
     __syncthreads();
     const bool prof = PROF && p.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
     long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    OwnSamples<LAT ? K : 1> smp;   // LAT: the next millisecond's raw samples
-    cf prn[LAT ? 32 : 1];          // LAT: this satellite's replica spectrum
+    OwnSamples<LAT ? K : 1> smp;          // LAT: the next millisecond's raw samples
+    cf prn[MODE == 1 ? 32 : 1];           // MODE 1: this satellite's replica spectrum
     if constexpr (LAT) {
-        const cf* row = rep + launder(lane);
+        if constexpr (MODE == 1) {
+            const cf* row = rep + launder(lane);
 #pragma unroll
-        for (int i = 0; i < 32; ++i) prn[i] = row[64 * i];
-        if (p.n_ms > 0) stage_fetch_own<K>(stream, smp, launder(threadIdx.x));
+            for (int i = 0; i < 32; ++i) prn[i] = row[64 * i];
+        }
+        if (p.ms_begin < p.ms_end) stage_fetch_own<K>(stream + (int64_t)p.ms_begin * N, smp, launder(threadIdx.x));
     }
-    for (int ms = 0; ms < p.n_ms; ++ms) {
+    for (int ms = p.ms_begin; ms < p.ms_end; ++ms) {
         gyp_track_rec* rec = p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + ms : nullptr;
         if (sm.red->istate[1]) {  // a dropped channel stays dropped until the host re-creates it (receiver.py:259-267)
-            if (rec && threadIdx.x == 0) {
-                gyp_track_rec z = {};
-                z.status = 2; z.doppler_hz = sm.red->dstate[0]; z.carrier_phase = sm.red->dstate[1]; z.code_phase = sm.red->istate[0];
-                *rec = z;
+            if (threadIdx.x == 0) {
+                if (rec) {
+                    gyp_track_rec z = {};
+                    z.status = 2; z.doppler_hz = sm.red->dstate[0]; z.carrier_phase = sm.red->dstate[1]; z.code_phase = sm.red->istate[0];
+                    *rec = z;
+                }
+                if (SPEC) p.spec_out[(int64_t)ch * p.n_ms + ms].key = -1;
             }
             continue;
         }
         long long t_a = prof ? (long long)__builtin_readcyclecounter() : 0;
-        EplResult r;
+        long long t_b = t_a, t_c = t_a;
+        MsMeasure m;
+        double leave[3] = {0.0, 0.0, 0.0};
+        const double t0 = p.start_time[launder(ms)];
         {
-            const double t0 = p.start_time[ms];
             const double f = sm.red->dstate[0], phi = sm.red->dstate[1];
             const CarrierSteps cs = sm.red->steps;
-            if constexpr (LAT) {
-                r = track_ms_fetched<K>(smp, f * t0 + phi * 0.15915494309189533577, f * p.inv_fs, cs, sm.red->istate[0], sm, prn);
-                // request the next millisecond now: the loads fly while wavefront 0 runs the loop filters below
-                if (ms + 1 < p.n_ms) stage_fetch_own<K>(stream + (int64_t)(ms + 1) * N, smp, launder(threadIdx.x));
-            } else {
-                r = track_ms<K>(stream + (int64_t)ms * N, f * t0 + phi * 0.15915494309189533577, f * p.inv_fs, cs,
-                                sm.red->istate[0], sm, rep, nullptr);
-            }
-        }
-        long long t_b = t_a;
-        long long t_c = prof ? (long long)__builtin_readcyclecounter() : 0;
-        if (wave == 0) {
-            const double f = sm.red->dstate[0], phi = sm.red->dstate[1];
-            const double t0 = p.start_time[launder(ms)];   // re-read here rather than held across the transforms
-            int lost = 0;
-            LoopState ls = sm.red->loop;                       // uniform: every lane reads the same words
-            const int64_t n = ls.n_steps;
-            double dll_phase = ls.dll_phase, last_watchdog = ls.last_watchdog;
-            LockSums sums = ls.sums;
-            int pos_e = ls.pos_e, pos_p = ls.pos_p, pos_refresh = ls.pos_refresh;
-            // the ring entries that leave the sliding windows this millisecond
-            double leave_e = 0.0, leave_pr = 0.0, leave_pi = 0.0;
-            if (n >= kLockWindow) {
-                const int pos_leave = pos_p >= kLockWindow ? pos_p - kLockWindow : pos_p - kLockWindow + kPeakHistory;
-                leave_e = st->err_ring[pos_e];
-                leave_pr = st->peak_re[pos_leave];
-                leave_pi = st->peak_im[pos_leave];
-            }
-            // ---- code loop, tracker.py:297-303
-            const double er = r.early.x, ei = r.early.y, lr = r.late.x, li = r.late.y;
-            const double disc = ((er * er + ei * ei) - (lr * lr + li * li)) / 2.0;
-            double dll = dll_phase + disc * 0.002;
-            const int new_code_phase = (int)dll;           // int() truncates toward zero, before the wrap
-            dll = pymod(dll, 2046.0);
-            if (dll < 0.0) dll += 2046.0;
-            // ---- histories, tracker.py:346-347 (the peak joins the window before is_locked() looks at it)
-            const double pr = (double)r.peak.x, pim = (double)r.peak.y;
-            if (lane == 0) { st->peak_re[pos_p] = pr; st->peak_im[pos_p] = pim; }
-            if (n >= kLockWindow) {
-                if (leave_pr < 0.0) { sums.nr -= leave_pr; sums.ni -= leave_pi; sums.nrr -= leave_pr * leave_pr; --sums.cn; }
-                else { sums.pr -= leave_pr; sums.prr -= leave_pr * leave_pr; --sums.cp; }
-            }
-            if (pr < 0.0) { sums.nr += pr; sums.ni += pim; sums.nrr += pr * pr; ++sums.cn; }
-            else { sums.pr += pr; sums.prr += pr * pr; ++sums.cp; }
-            // ---- Costas loop, tracker.py:246-262
-            const double err = pr * pim;
-            LockVerdict lv = lock_from_sums(sums, n);
-            bool locked = lv.locked;
-            if (lv.marginal || pos_refresh == kLockRefresh - 1) {
-                workgroup_mem_fence_wave();                 // lane 0's ring stores -> every lane of this wavefront
-                LockSums fresh;
-                locked = is_locked_exact_wave(st, n, n + 1, lane, fresh);
-                sums = fresh;
-            }
-            const double bw = locked ? 3.0 : 6.0;
-            const double tps = p.inv_fs;                // == 1.0 / samples_per_second, formed on the host
-            const double alpha = 4.0 * (1.0 / sqrt(2.0)) * bw * tps;
-            const double beta = 4.0 * (bw * bw) * tps;
-            double nphi = pymod(phi + err * alpha, 6.283185307179586);
-            double nf = f + err * beta;
-            // the error joins its window after is_locked() has been evaluated (tracker.py:251,261)
-            if (n >= kLockWindow) { sums.se -= leave_e; sums.see -= leave_e * leave_e; }
-            sums.se += err; sums.see += err * err;
-            if (lane == 0) st->err_ring[pos_e] = err;
-            pos_e = pos_e + 1 == kLockWindow ? 0 : pos_e + 1;
-            pos_p = pos_p + 1 == kPeakHistory ? 0 : pos_p + 1;
-            pos_refresh = pos_refresh + 1 == kLockRefresh ? 0 : pos_refresh + 1;
-            const float mean_excl = (float)((r.sum - (double)r.n_max * (double)r.best.v) / (double)(N - r.n_max));
-            const double rec_f = nf, rec_phi = nphi;
-            // ---- circularity watchdog, tracker.py:370-387
-            int status = 0, nudged = 0;
-            if (t0 - last_watchdog >= 6.0) {
-                workgroup_mem_fence_wave();
-                double cs[3];
-                constellation_stats_wave(st, n + 1, lane, cs);
-                last_watchdog = t0;
-                if (cs[0] >= 0.0) {
-                    if (cs[0] < 0.2) { status = 1; lost = 1; }
-                    else if (cs[0] < 0.93 && cs[2] != 0.0) {
-                        const double sg = cs[1] > 0.0 ? 1.0 : (cs[1] < 0.0 ? -1.0 : 0.0);
-                        nf += -sg * 5.0;
-                        nphi += sg * (3.141592653589793 / 2.0);
-                        nudged = 1;
+            const int code_phase = sm.red->istate[0];
+            const double u0 = f * t0 + phi * 0.15915494309189533577, du = f * p.inv_fs;
+            const cf* block = stream + (int64_t)ms * N;
+            if constexpr (SPEC) {
+                const int tid = launder(threadIdx.x);
+                const int sN = mod_n(code_phase, N);
+                asm volatile("; MARK_STAGE_BEGIN");
+                // the boundary samples of the float64 early/late sums are requested first, consumed after the staging
+                if (wave == 0) fetch_leaving(st, sm.red, leave);
+                const ElSample el0 = el_fetch<K>(block, sN, sl.trans, nt, tid);
+                const ElSample el1 = el_fetch<K>(block, sN, sl.trans, nt, tid + Geom<K>::kThreads);
+                const float e_in = (smp.w[0][0].x * smp.w[0][0].x + smp.w[0][0].y * smp.w[0][0].y) +
+                                   (smp.w[0][4].x * smp.w[0][4].x + smp.w[0][4].y * smp.w[0][4].y) +
+                                   (smp.w[1][0].x * smp.w[1][0].x + smp.w[1][0].y * smp.w[1][0].y) +
+                                   (smp.w[1][4].x * smp.w[1][4].x + smp.w[1][4].y * smp.w[1][4].y);
+                cf* y_rows[K];
+#pragma unroll
+                for (int r = 0; r < K; ++r) y_rows[r] = sm.xch + r * kXchWave;
+                stage_emit_own<K>(smp, u0, du, cs, y_rows, sm.halo, tid);
+                double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                el_accumulate<K>(el0, u0, du, acc);
+                if (__any(el1.nl >= 0)) el_accumulate<K>(el1, u0, du, acc);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) sl.part[v * Geom<K>::kThreads + tid] = acc[v];
+                sl.ein_part[tid] = e_in;
+                asm volatile("; MARK_STAGE_END");
+                __syncthreads();
+                if (prof) t_b = (long long)__builtin_readcyclecounter();
+                const int centre = sm.red->istate[2];
+                spec_window<K>(sm, sl, centre, sN, tid);
+                sum_partials64<K, 4>(sl.part, sl.fin, 4, tid);
+                if (wave == 3) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) a += sl.ein_part[lane + 64 * k];
+                    a = wave_sum(a);
+                    if (lane == 0) reinterpret_cast<float*>(sl.fin + 6)[0] = 4.0f * a;   // every 4th sample was summed
+                }
+                asm volatile("; MARK_WINDOW_END");
+                __syncthreads();
+                // every wavefront takes the same decision from the same 16 values; ties resolve like np.argmax on the
+                // profile of the PRN rolled by s (lowest rolled index)
+                const int wi = lane & 15;
+                int wlag = centre + wi - kSpecHalf;
+                wlag = wlag < 0 ? wlag + N : (wlag >= N ? wlag - N : wlag);
+                int wkey = wlag - sN;
+                wkey = wkey < 0 ? wkey + N : wkey;
+                const cf wv = sl.win[wi];
+                const Best b = wave_best(Best{fmaf(wv.x, wv.x, wv.y * wv.y), wkey});
+                int blag = b.key + sN;
+                blag = blag >= N ? blag - N : blag;
+                int wbest = blag - centre + kSpecHalf;
+                wbest = wbest < 0 ? wbest + N : (wbest >= N ? wbest - N : wbest);
+                const float energy = reinterpret_cast<const float*>(sl.fin + 6)[0];
+                const bool fast = wbest != 0 && wbest != 2 * kSpecHalf - 1 && b.v >= p.spec_kappa * energy;
+                if (prof) { t_c = (long long)__builtin_readcyclecounter(); tp[5] += fast ? 0 : 1; }
+                if (p.dbg && wave == 0 && lane < 20) {
+                    float* o = p.dbg + ((int64_t)ch * p.n_ms + ms) * 20;
+                    o[lane] = lane < 16 ? fmaf(wv.x, wv.x, wv.y * wv.y) : (lane == 16 ? energy : (lane == 17 ? (float)sN : (lane == 18 ? (float)centre : 0.f)));
+                }
+                m.disc = 0.0;
+                {
+                    const float ratio = energy > 0.f ? b.v / energy : 65535.f;
+                    m.path_info = (fast ? 1 : 0) | (wbest << 8) | ((int)fminf(ratio, 65535.f) << 16);
+                }
+                int next_centre = blag;
+                asm volatile("; MARK_DECIDE_END");
+                if (fast) {
+                    m.peak = sl.win[wbest];
+                    m.peak_mag = __builtin_amdgcn_sqrtf(b.v);
+                    m.key = b.key; m.sum = 0.0; m.n_max = 0; m.strength_pending = true;
+                } else {
+                    // full profile from the rows already staged (track_ms_fetched from its barrier on)
+                    const int l = lane & 31, h = lane >> 5;
+                    cf x[32];
+                    const cf* yw = sm.xch + wave * kXchWave;
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) x[j] = yw[32 * j + l];
+                    halo_fixup<K>(x, sm.halo, wave, l);
+                    wave_lds_fence();
+                    float* tile_half = reinterpret_cast<float*>(sm.xch + wave * kXchWave) + h * kXchTile;
+                    const LdsTables t{sm.tw1024, sm.tw2048};
+                    cf c[16];
+                    wave_fft_fwd(x, tile_half, t, l, h);
+                    spectrum_mul_from(x, rep, lane);
+                    wave_fft_inv(x, c, tile_half, t, l, h);
+                    epl_round_wave<K>(c, sN, sN, sm.red, nullptr, tid);
+                    const EplResult r = epl_finish_wave<K>(sm.red);
+                    m.peak = r.peak; m.peak_mag = r.best.v; m.key = r.best.key; m.sum = r.sum; m.n_max = r.n_max;
+                    m.strength_pending = false;
+                    next_centre = r.best.key + sN;
+                    next_centre = next_centre >= N ? next_centre - N : next_centre;
+                }
+                if (wave == 0) {
+                    const cf pv = sl.win[2 * kSpecHalf];
+                    m.disc = dll_discriminator((double)pv.x, (double)pv.y, sl.fin);
+                    if (lane == 0) {
+                        sm.red->istate[2] = next_centre;
+                        SpecIn si;
+                        si.doppler = f; si.carrier_phase = phi; si.code_phase = code_phase; si.key = fast ? m.key : -1;
+                        p.spec_out[(int64_t)ch * p.n_ms + ms] = si;
                     }
                 }
-            }
-            if (lane == 0) {
-                ls.dll_phase = dll; ls.last_watchdog = last_watchdog; ls.n_steps = n + 1; ls.sums = sums;
-                ls.pos_e = pos_e; ls.pos_p = pos_p; ls.pos_refresh = pos_refresh;
-                sm.red->loop = ls;
-                sm.red->dstate[0] = nf; sm.red->dstate[1] = nphi;
-                sm.red->istate[0] = new_code_phase; sm.red->istate[1] = lost;
-                sm.red->steps = carrier_steps<K>(nf * p.inv_fs);
-                if (rec) {
-                    gyp_track_rec o;
-                    o.peak_re = r.peak.x; o.peak_im = r.peak.y;
-                    o.strength = r.best.v / mean_excl;
-                    o.discriminator = (float)disc;
-                    o.doppler_hz = rec_f; o.carrier_phase = rec_phi; o.error = err;
-                    o.code_phase = new_code_phase; o.peak_offset = r.best.key;
-                    o.pseudosymbol = (int8_t)(pr > 0.0 ? 1 : (pr < 0.0 ? -1 : 0));
-                    o.locked = locked ? 1 : 0; o.status = (int8_t)status; o.nudged = (int8_t)nudged;
-                    o.reserved = 0;
-                    *rec = o;
+                if (ms + 1 < p.ms_end) stage_fetch_own<K>(stream + (int64_t)(ms + 1) * N, smp, launder(threadIdx.x));
+            } else {
+                EplResult r;
+                if constexpr (MODE == 1) {
+                    r = track_ms_fetched<K>(smp, u0, du, cs, code_phase, sm, prn);
+                    // request the next millisecond now: the loads fly while the boundary sums and the loop filters run
+                    if (ms + 1 < p.ms_end) stage_fetch_own<K>(stream + (int64_t)(ms + 1) * N, smp, launder(threadIdx.x));
+                } else {
+                    r = track_ms<K>(block, u0, du, cs, code_phase, mod_n(code_phase, N), sm, rep, nullptr);
                 }
+                if (prof) t_b = (long long)__builtin_readcyclecounter();
+                el_delta_workgroup<K>(block, u0, du, code_phase, p.codes, sat_index, sm);
+                m.peak = r.peak; m.peak_mag = r.best.v; m.key = r.best.key; m.sum = r.sum; m.n_max = r.n_max;
+                m.strength_pending = false;
+                m.path_info = 0;
+                m.disc = dll_discriminator((double)r.probe.x, (double)r.probe.y, sm.red->eldelta);
+                if (prof) t_c = (long long)__builtin_readcyclecounter();
             }
         }
+        asm volatile("; MARK_UPDATE_BEGIN");
+        if (wave == 0) {
+            if constexpr (!SPEC) fetch_leaving(st, sm.red, leave);
+            loop_filter_update<K>(p, st, sm.red, t0, lane, m, leave, rec);
+        }
+        asm volatile("; MARK_UPDATE_END");
         long long t_d = prof ? (long long)__builtin_readcyclecounter() : 0;
         __syncthreads();
         if (prof) {
@@ -1414,6 +1829,63 @@ __global__ __launch_bounds__(Geom<K>::kThreads, LAT ? 2 : Geom<K>::kMinWavesPerS
         st->dll_phase = ls.dll_phase; st->n_steps = ls.n_steps; st->last_watchdog_time = ls.last_watchdog;
         st->sums = ls.sums;
         if (prof) for (int i = 0; i < 8; ++i) p.prof[i] = tp[i];
+    }
+}
+
+// The full-profile half of the speculative path: for every (channel, millisecond) the tracking kernel advanced on its
+// window maximum, run the millisecond's transforms with the loop state it was processed with, check that the global
+// arg-max of |prompt| is the lag the loop used, and complete the record's strength (utils.py:111-116).  A mismatch
+// marks the channel for a re-run of the whole block by the transform kernel (track_block_kernel MODE 0 with only_if).
+// Two lags that the float32 transform cannot order (|c|^2 within tie_tol of each other) count as agreement: the
+// window sums the loop used are the more accurate of the two evaluations.
+struct TrackVerifyParams {
+    const cf* iq;
+    int64_t stream_stride;
+    int32_t n_ms;
+    int32_t ms_begin, ms_end;
+    const double* start_time;
+    const ChanState* states;
+    int32_t n_chan;
+    const SpecIn* spec;
+    gyp_track_rec* rec_out;
+    int32_t* bad;
+    const cf* replica_table;
+    const cf* tw_tables;
+    double inv_fs;
+    float tie_tol;
+};
+
+template <int K>
+__global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void track_verify_kernel(TrackVerifyParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int N = K * kChips;
+    const Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
+    __syncthreads();
+    const int n_units = p.n_chan * (p.ms_end - p.ms_begin);
+    for (int v = blockIdx.x; v < n_units; v += gridDim.x) {
+        const int u = xcd_contiguous(v, n_units);
+        const int ms = p.ms_begin + u / p.n_chan, ch = u % p.n_chan;   // the channels of a millisecond are neighbours: shared IQ
+        const SpecIn in = p.spec[(int64_t)ch * p.n_ms + ms];
+        if (in.key < 0) continue;                                 // uniform
+        const ChanState* st = p.states + ch;
+        const cf* rep = replica_of(p.replica_table, st->sat_id - 1);
+        const cf* block = p.iq + (int64_t)st->stream * p.stream_stride + (int64_t)ms * N;
+        const double du = in.doppler * p.inv_fs;
+        const double u0 = in.doppler * p.start_time[ms] + in.carrier_phase * 0.15915494309189533577;
+        int probe = mod_n(in.code_phase, N) + in.key;
+        probe = probe >= N ? probe - N : probe;
+        const EplResult r = track_ms<K>(block, u0, du, carrier_steps<K>(du), in.code_phase, probe, sm, rep, nullptr);
+        if (threadIdx.x == 0) {
+            if (r.best.key != in.key) {
+                const float vp = fmaf(r.probe.x, r.probe.x, r.probe.y * r.probe.y), vm = r.best.v * r.best.v;
+                if (!(vp >= vm * (1.0f - p.tie_tol))) p.bad[ch] = 1;
+            }
+            if (p.rec_out) {
+                const float mean_excl = (float)((r.sum - (double)r.n_max * (double)r.best.v) / (double)(N - r.n_max));
+                p.rec_out[(int64_t)ch * p.n_ms + ms].strength = r.best.v / mean_excl;
+            }
+        }
+        __syncthreads();
     }
 }
 

@@ -210,7 +210,8 @@ class GpsSatelliteTracker:
         out, prof = self._engine.track_step(receiver_samples_chunk.samples, 1, [receiver_samples_chunk.start_time],
                                             chan, want_profiles=self._keep_profiles)
         o = out[0]
-        self._advance_code_loop(complex(o["early_re"], o["early_im"]), complex(o["late_re"], o["late_im"]))
+        # the float64-accurate taps: int(self.phase) must follow the reference's trajectory (tracker.py:299)
+        self._advance_code_loop(complex(o["early64_re"], o["early64_im"]), complex(o["late64_re"], o["late64_im"]))
         if self._keep_profiles:
             p.non_coherent_correlation_profiles.append(prof[0].astype(np.float64))
         peak_mag = float(o["peak_mag"])

@@ -174,6 +174,12 @@ typedef struct gyp_chan_out {
     double sum;                 /* sum |prompt| */
     int32_t n_max;
     int32_t reserved;
+    /* The same early / late correlations to float64 accuracy of the lag-to-lag differences: prompt-lag value (float32
+     * transform) -/+ the float64 sums over the chip-transition samples that separate neighbouring lags.  Feed THESE
+     * to the DLL discriminator (tracker.py:297): int(self.phase) follows the reference's trajectory with them, which
+     * the float32 pair above cannot guarantee near an integer boundary. */
+    double early64_re, early64_im;
+    double late64_re, late64_im;
 } gyp_chan_out;
 
 /* iq_dev: n_streams x N samples of the current millisecond (stream stride given); start_time_host[n_streams]:
@@ -214,7 +220,11 @@ typedef struct gyp_track_rec {
     int8_t locked;                /* is_locked() as evaluated inside the Costas loop this millisecond */
     int8_t status;                /* 0 ok, 1 LostSatelliteLockError raised this ms (circularity < 0.2), 2 already lost */
     int8_t nudged;                /* circularity watchdog adjusted doppler/phase after this ms */
-    int32_t reserved;
+    /* How the millisecond was evaluated (diagnostic; the record's other fields do not depend on it):
+     *   bits 0..1  0 = full transform profile; 1 = window maximum (speculative tracker), confirmed by the verify pass;
+     *   bits 8..15 window index of the maximum (lag code_phase - 8 + index), speculative tracker only;
+     *   bits 16..31 min(65535, peak^2 / sample energy) the confidence test saw, speculative tracker only. */
+    int32_t path_info;
 } gyp_track_rec;
 
 int gyp_bank_create(gyp_ctx* ctx, const gyp_chan_init* chans_host, int32_t n_chan, gyp_bank** out);
@@ -363,6 +373,11 @@ int gyp_ingest_times(const gyp_ingest* ing, int64_t first_ms, int32_t n_ms, doub
  * gyp_acquire_dev, (stage, row load + forward, spectrum + prefetch, inverse + accumulate, barrier, iterations).
  * enable != 0 arms it; out8 (may be NULL) receives the counters of the last launch. */
 int gyp_debug_track_profile(gyp_ctx* ctx, int enable, long long* out8);
+/* Debug (speculative block tracker, 8.184 Msps banks of at most one channel per CU): with GYP_SPEC_DEBUG set in the
+ * environment the last gyp_track_block(_dev) call leaves, per (channel, ms), 20 floats: |c0|^2 at the 16 window lags
+ * code_phase-8 .. code_phase+7, the sample-energy estimate, code_phase mod N, 0, 0.  bad_out (may be NULL): per
+ * channel, 1 if the verify pass sent the channel back through the transform kernel.  Synchronises the stream. */
+int gyp_debug_spec_read(gyp_bank* bank, float* out, int32_t n_floats, int32_t* bad_out);
 /* Debug: time `iters` forward+inverse wavefront transform pairs per wavefront, `wgs` workgroups of `waves_per_wg`
  * wavefronts (LDS-resident data, no global traffic): the floor the correlator kernels are measured against. */
 int gyp_debug_fft_bench(gyp_ctx* ctx, int waves_per_wg, int wgs, int iters, float* ms_out);

@@ -49,6 +49,23 @@ def main():
     for i, nm in enumerate(names):
         print(f"  {nm:32s} {out[i] / steps:10.0f} cycles/ms  ({100.0 * out[i] / tot:5.1f} %)")
     print(f"  total {tot / steps:.0f} cycles/ms (constant 100 MHz counter if s_memrealtime, else shader clock)")
+    print(f"  speculative mode: phases are stage | window + decision | transform path (if taken) + loop update | barrier; "
+          f"{out[5]} of {steps} ms took the transform path in workgroup 0")
+    r = rec.download(TRACK_REC, B * C_ * T).reshape(B * C_, T)
+    pi = r["path_info"]
+    print("  fast-path fraction", float((pi & 3).mean()), "window index histogram", np.bincount(((pi >> 8) & 255).ravel(), minlength=16)[:16].tolist(),
+          "ratio min/median", int((pi >> 16).min()), float(np.median(pi >> 16)), "per-channel fast", (pi & 3).mean(axis=1).round(2).tolist())
+    import os
+    if os.environ.get("GYP_SPEC_DEBUG"):
+        dbg = np.zeros((B * C_, T, 20), dtype=np.float32)
+        bad = np.zeros(B * C_, dtype=np.int32)
+        eng._check(eng.lib.gyp_debug_spec_read(bank.handle, C.c_void_p(dbg.ctypes.data), dbg.size, C.c_void_p(bad.ctypes.data)))
+        np.set_printoptions(linewidth=220, precision=1, suppress=True)
+        print("  bad flags", bad.tolist())
+        for c in range(3):
+            for ms in (0, 1, 50):
+                print(f"  ch {c} ms {ms}: win {dbg[c, ms, :16]} energy {dbg[c, ms, 16]:.2f} sN {int(dbg[c, ms, 17])} peak_offset {int(r[c, ms]['peak_offset'])} code_phase {int(r[c, ms]['code_phase'])}")
+    print("  strength range", float(r["strength"].min()), float(r["strength"].max()), "locked frac", float(r["locked"].mean()))
 
 
 if __name__ == "__main__":
