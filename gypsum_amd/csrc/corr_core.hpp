@@ -663,6 +663,46 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_f<kDppMirror>(v);
     return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
 }
+// Sum over the wavefront, valid in LANE 63 ONLY: the row_bcast forms fold the four 16-lane rows into the last lane
+// without the scalar round trip of wave_sum (7 VALU instructions instead of 4 + 4 v_readlane + 5).
+__device__ __forceinline__ float wave_sum_last(float v) {
+    v += dpp_f<kDppXor1>(v);
+    v += dpp_f<kDppXor2>(v);
+    v += dpp_f<kDppHalfMirror>(v);
+    v += dpp_f<kDppMirror>(v);
+    // row_bcast:15 -> rows 1 and 3 add the last lane of the previous row; row_bcast:31 -> rows 2, 3 add lane 31
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x142, 0xA, 0xF, false));
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x143, 0xC, 0xF, false));
+    return v;
+}
+__device__ __forceinline__ double dpp_d_masked(double v, const int ctrl_is_bcast31) {   // row_bcast:15 (rows 1, 3) / row_bcast:31 (rows 2, 3)
+    unsigned lo, hi;
+    if (ctrl_is_bcast31) {
+        lo = __builtin_amdgcn_update_dpp(0u, (unsigned)__double2loint(v), 0x143, 0xC, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(0u, (unsigned)__double2hiint(v), 0x143, 0xC, 0xF, false);
+    } else {
+        lo = __builtin_amdgcn_update_dpp(0u, (unsigned)__double2loint(v), 0x142, 0xA, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(0u, (unsigned)__double2hiint(v), 0x142, 0xA, 0xF, false);
+    }
+    return __hiloint2double((int)hi, (int)lo);   // +0.0 in the rows the mask leaves out
+}
+__device__ __forceinline__ double wave_sum_last(double v) {   // valid in lane 63 only, see the float form
+    v += dpp_d<kDppXor1>(v);
+    v += dpp_d<kDppXor2>(v);
+    v += dpp_d<kDppHalfMirror>(v);
+    v += dpp_d<kDppMirror>(v);
+    v += dpp_d_masked(v, 0);
+    v += dpp_d_masked(v, 1);
+    return v;
+}
+// Best of 16 values replicated in every 16-lane row (lane & 15 indexes the value): result uniform across the wavefront.
+__device__ __forceinline__ Best row16_best(Best b) {
+    b = best_step<kDppXor1>(b);
+    b = best_step<kDppXor2>(b);
+    b = best_step<kDppHalfMirror>(b);
+    b = best_step<kDppMirror>(b);
+    return Best{readlane_f(b.v, 0), __builtin_amdgcn_readlane(b.key, 0)};
+}
 __device__ __forceinline__ int wave_sum(int v) {
     v += dpp_i<kDppXor1>(v);
     v += dpp_i<kDppXor2>(v);

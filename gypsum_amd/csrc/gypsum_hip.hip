@@ -1027,12 +1027,12 @@ int gyp_synth_iq_dev(gyp_ctx* ctx, float* out_dev, int32_t n_streams, int64_t st
 int gyp_debug_track_profile(gyp_ctx* ctx, int enable, long long* out8) {
     if (!ctx) return GYP_E_BAD_ARG;
     if (enable && !ctx->d_prof) {
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_prof, 8 * sizeof(long long)));
-        HIP_TRY(ctx, hipMemset(ctx->d_prof, 0, 8 * sizeof(long long)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_prof, 16 * sizeof(long long)));
+        HIP_TRY(ctx, hipMemset(ctx->d_prof, 0, 16 * sizeof(long long)));
     }
     if (out8 && ctx->d_prof) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipMemcpy(out8, ctx->d_prof, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(out8, ctx->d_prof, 16 * sizeof(long long), hipMemcpyDeviceToHost));
     }
     if (!enable && ctx->d_prof) { HIP_TRY(ctx, hipFree(ctx->d_prof)); ctx->d_prof = nullptr; }
     return GYP_OK;

@@ -84,6 +84,11 @@ struct RedScratch {
     int istate[4];      // new code phase, lost flag
     CarrierSteps steps; // rotation constants of the next millisecond's wipe-off
     LoopState loop;
+    gyp_track_rec rec;  // the millisecond's record, assembled by the loop updates, flushed to global memory by rec_flush
+    // speculative tracker: the Costas update for either loop bandwidth is formed by its own wavefront while a third works
+    // out the lock verdict; cand_sel says which one the next millisecond runs with (2: the watchdog's nudged values)
+    struct CostasCand { double nf, nphi; cf rot1; double pad; } cc[3];
+    int cand_sel, rec_sel, pad2[2];
 };
 static_assert(sizeof(RedScratch) <= kRedBytes, "reduction scratch too large");
 
@@ -1082,6 +1087,21 @@ __device__ __forceinline__ ElSample el_fetch(const cf* __restrict__ block, int s
     }
     return s;
 }
+// The same for a thread whose transition is fixed (sample offset K*m, or < 0: none).
+template <int K>
+__device__ __forceinline__ ElSample el_fetch_const(const cf* __restrict__ block, int sN, int off, float g) {
+    constexpr int N = K * kChips;
+    ElSample s;
+    s.nl = -1; s.g = g; s.xl = s.xe = make_float2(0.f, 0.f);
+    if (off >= 0) {
+        int nl = sN + off;
+        nl = nl >= N ? nl - N : nl;
+        s.nl = nl;
+        s.xl = block[nl];
+        s.xe = block[nl == 0 ? N - 1 : nl - 1];
+    }
+    return s;
+}
 template <int K>
 __device__ __forceinline__ void el_accumulate(const ElSample& s, double u0, double du, double (&acc)[4]) {
     constexpr int N = K * kChips;
@@ -1120,6 +1140,16 @@ __device__ __forceinline__ void sum_partials64(const double* part, double* fin, 
         a = wave_sum(a);
         if (lane == 0) fin[v] = a;
     }
+}
+// The speculative kernel's form (K == 8, 512 threads): all eight wavefronts take part -- wavefront w sums half
+// (w >> 2) of value (w & 3), four partials per lane requested together, and leaves the result in fin[2*(w & 3) + (w >> 2)].
+__device__ __forceinline__ void sum_partials64_spec(const double* part, double* fin, int tid) {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int v = wave & 3, half = wave >> 2;
+    const double* src = part + v * 512 + 256 * half + lane;
+    const double a0 = src[0], a1 = src[64], a2 = src[128], a3 = src[192];
+    const double a = wave_sum_last((a0 + a1) + (a2 + a3));
+    if (lane == 63) fin[2 * v + half] = a;
 }
 // tracker.py:297: ((E.re^2 + E.im^2) - (L.re^2 + L.im^2)) / 2 from the prompt value and the boundary sums.
 __device__ __forceinline__ double dll_discriminator(double p_re, double p_im, const double* d) {
@@ -1211,6 +1241,15 @@ __device__ __forceinline__ double pymod(double a, double b) {
     return r;
 }
 
+// pymod for a wave-uniform argument (the loop filters): the library fmod sits behind a SCALAR branch.
+__device__ __forceinline__ bool uniform_true(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
+__device__ __forceinline__ double pymod_uniform(double a, double b) {
+    double r = (a >= b && a < 2.0 * b) ? a - b : a;
+    if (!uniform_true(a > -b && a < 2.0 * b)) r = fmod(a, b);
+    r += (r != 0.0 && r < 0.0) ? b : 0.0;
+    return r;
+}
+
 struct LockVerdict {
     bool locked;
     bool marginal;   // some comparison was too close to its threshold to trust one-pass arithmetic
@@ -1218,12 +1257,14 @@ struct LockVerdict {
 
 __device__ __forceinline__ bool near(double v, double thr) { return fabs(v - thr) <= 1e-9 * thr; }
 
+// A wave-uniform condition held in a vector register, as a SCALAR branch condition.
+__device__ __forceinline__ bool uniform(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
+
 // is_locked() from the sliding sums (any lane; pure scalar math, no divisions: every comparison is multiplied through
-// by its positive denominators).  Anything within 1e-9 (relative) of a threshold is re-decided by the exact two-pass
-// evaluation.
+// by its positive denominators).
 __device__ __forceinline__ LockVerdict lock_from_sums(const LockSums& s, int64_t n_err) {
-    LockVerdict out{false, false};
-    if (n_err < kLockWindow) return out;                       // tracker.py:164-167
+    // straight-line: the values are wave-uniform but live in vector registers, where every `if` would become an
+    // exec-mask branch
     constexpr double W = (double)kLockWindow;
     // var(errors) = see/W - (se/W)^2 < 900   <=>   see*W - se^2 < 900*W^2
     const double xe = s.see * W - s.se * s.se, te = 900.0 * W * W;
@@ -1231,23 +1272,22 @@ __device__ __forceinline__ LockVerdict lock_from_sums(const LockSums& s, int64_t
     // mean of the two pole variances < 2, a pole with fewer than two members counting 0 (tracker.py:176-186):
     //   A/cn^2 + B/cp^2 < 4  with A = nrr*cn - nr^2, B = prr*cp - pr^2
     const double cn = (double)s.cn, cp = (double)s.cp;
-    const double a = s.cn >= 2 ? s.nrr * cn - s.nr * s.nr : 0.0, b = s.cp >= 2 ? s.prr * cp - s.pr * s.pr : 0.0;
-    const double cn2 = s.cn >= 2 ? cn * cn : 1.0, cp2 = s.cp >= 2 ? cp * cp : 1.0;
+    const bool n2 = s.cn >= 2, p2 = s.cp >= 2;
+    const double a = n2 ? s.nrr * cn - s.nr * s.nr : 0.0, b = p2 ? s.prr * cp - s.pr * s.pr : 0.0;
+    const double cn2 = n2 ? cn * cn : 1.0, cp2 = p2 ? cp * cp : 1.0;
     const double xi = a * cp2 + b * cn2, ti = 4.0 * cn2 * cp2;
     const bool i_ok = xi < ti;
-    out.marginal = fabs(xe - te) <= 1e-9 * te || fabs(xi - ti) <= 1e-9 * ti;
-    bool rot_ok = true;
-    if (var_ok && i_ok && s.cn >= 2) {
-        // tracker.py:190-197: the mean of the negative pole must lie within 6 degrees of the real axis (mod 180; the
-        // `abs(bool)` quirk makes it one-sided).  distance(angle, 180Z) < 6  <=>  |im| < tan(6 deg) * |re|: no atan2
-        // on the per-millisecond path; a decision within 1e-9 of the boundary goes to the exact evaluation like the
-        // variances do (with cn < 2 upstream's mean is 0+0j, angle 0: locked)
-        const double lhs = fabs(s.ni), rhs = 0.10510423526567646 * fabs(s.nr);   // tan(pi/30)
-        rot_ok = lhs < rhs;
-        out.marginal = out.marginal || fabs(lhs - rhs) <= 1e-9 * (lhs + rhs);
-    }
-    out.locked = var_ok && i_ok && rot_ok;
-    return out;
+    // tracker.py:190-197: the mean of the negative pole must lie within 6 degrees of the real axis (mod 180; the
+    // `abs(bool)` quirk makes it one-sided).  distance(angle, 180Z) < 6  <=>  |im| < tan(6 deg) * |re|: no atan2 on
+    // the per-millisecond path (with cn < 2 upstream's mean is 0+0j, angle 0: locked)
+    const double lhs = fabs(s.ni), rhs = 0.10510423526567646 * fabs(s.nr);   // tan(pi/30)
+    const bool rot_tested = var_ok && i_ok && n2;
+    const bool rot_ok = !rot_tested || lhs < rhs;
+    // anything within 1e-9 (relative) of a threshold is re-decided by the exact two-pass evaluation
+    const bool marginal = fabs(xe - te) <= 1e-9 * te || fabs(xi - ti) <= 1e-9 * ti ||
+                          (rot_tested && fabs(lhs - rhs) <= 1e-9 * (lhs + rhs));
+    const bool full = n_err >= kLockWindow;                    // tracker.py:164-167
+    return LockVerdict{full && var_ok && i_ok && rot_ok, full && marginal};
 }
 
 // Exact (two-pass) evaluation of tracker.py:157-203 by one whole wavefront; also returns the freshly summed
@@ -1368,6 +1408,11 @@ struct TrackBlockParams {
     float* dbg;                // optional [n_chan][n_ms][20]: |window|^2 x 16, sample energy, code phase mod N, 0, 0 (debug)
 };
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory queue (s_waitcnt
+// vmcnt(0)), which in the latency-bound tracking loop means waiting for prefetches and record stores nobody reads here.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 __device__ __forceinline__ void workgroup_mem_fence_wave() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -1403,38 +1448,53 @@ __device__ __forceinline__ void fetch_leaving(const ChanState* st, const RedScra
     }
 }
 
+// The loop updates of one millisecond of one channel, in two independent halves so that two wavefronts can run them
+// side by side (all lanes, uniform values).  Loop state lives in `red` (LDS), the history rings in `st`; the
+// millisecond's record is assembled in red->rec and written out by rec_flush.
+//
+// tracker.py:297-303 code loop.  Owns LoopState::dll_phase and istate[0].
+__device__ __forceinline__ void dll_update(RedScratch* red, double disc, int lane) {
+    double dll = red->loop.dll_phase + disc * 0.002;
+    const int new_code_phase = (int)dll;           // int() truncates toward zero, before the wrap
+    dll = pymod_uniform(dll, 2046.0);
+    dll += dll < 0.0 ? 2046.0 : 0.0;
+    if (lane == 0) {
+        red->loop.dll_phase = dll;
+        red->istate[0] = new_code_phase;
+        red->rec.discriminator = (float)disc;
+        red->rec.code_phase = new_code_phase;
+    }
+}
+// tracker.py:246-262 Costas loop with the is_locked() bandwidth switch, :346-389 histories and circularity watchdog.
+// Owns everything else in LoopState, dstate, istate[1], steps.
 template <int K>
-__device__ __forceinline__ void loop_filter_update(const TrackBlockParams& p, ChanState* st, RedScratch* red, double t0, int lane,
-                                                   const MsMeasure& r, const double (&leave)[3], gyp_track_rec* rec) {
+__device__ __forceinline__ void costas_update(const TrackBlockParams& p, ChanState* st, RedScratch* red, double t0, int lane,
+                                              const MsMeasure& r, const double (&leave)[3]) {
     constexpr int N = K * kChips;
     const double f = red->dstate[0], phi = red->dstate[1];
     int lost = 0;
-    LoopState ls = red->loop;                       // uniform: every lane reads the same words
-    const int64_t n = ls.n_steps;
-    double dll_phase = ls.dll_phase, last_watchdog = ls.last_watchdog;
-    LockSums sums = ls.sums;
-    int pos_e = ls.pos_e, pos_p = ls.pos_p, pos_refresh = ls.pos_refresh;
+    const int64_t n = red->loop.n_steps;            // uniform: every lane reads the same words
+    double last_watchdog = red->loop.last_watchdog;
+    LockSums sums = red->loop.sums;
+    int pos_e = red->loop.pos_e, pos_p = red->loop.pos_p, pos_refresh = red->loop.pos_refresh;
     const double leave_e = leave[0], leave_pr = leave[1], leave_pi = leave[2];
-    // ---- code loop, tracker.py:297-303
-    const double disc = r.disc;
-    double dll = dll_phase + disc * 0.002;
-    const int new_code_phase = (int)dll;           // int() truncates toward zero, before the wrap
-    dll = pymod(dll, 2046.0);
-    if (dll < 0.0) dll += 2046.0;
     // ---- histories, tracker.py:346-347 (the peak joins the window before is_locked() looks at it)
     const double pr = (double)r.peak.x, pim = (double)r.peak.y;
     if (lane == 0) { st->peak_re[pos_p] = pr; st->peak_im[pos_p] = pim; }
-    if (n >= kLockWindow) {
-        if (leave_pr < 0.0) { sums.nr -= leave_pr; sums.ni -= leave_pi; sums.nrr -= leave_pr * leave_pr; --sums.cn; }
-        else { sums.pr -= leave_pr; sums.prr -= leave_pr * leave_pr; --sums.cp; }
+    {   // straight-line (see lock_from_sums): the entry leaving the 250-ms window, then the new peak
+        const bool full = n >= kLockWindow;
+        const bool ln = full && leave_pr < 0.0, lp = full && !(leave_pr < 0.0);
+        sums.nr -= ln ? leave_pr : 0.0; sums.ni -= ln ? leave_pi : 0.0; sums.nrr -= ln ? leave_pr * leave_pr : 0.0; sums.cn -= ln ? 1 : 0;
+        sums.pr -= lp ? leave_pr : 0.0; sums.prr -= lp ? leave_pr * leave_pr : 0.0; sums.cp -= lp ? 1 : 0;
+        const bool nn = pr < 0.0;
+        sums.nr += nn ? pr : 0.0; sums.ni += nn ? pim : 0.0; sums.nrr += nn ? pr * pr : 0.0; sums.cn += nn ? 1 : 0;
+        sums.pr += nn ? 0.0 : pr; sums.prr += nn ? 0.0 : pr * pr; sums.cp += nn ? 0 : 1;
     }
-    if (pr < 0.0) { sums.nr += pr; sums.ni += pim; sums.nrr += pr * pr; ++sums.cn; }
-    else { sums.pr += pr; sums.prr += pr * pr; ++sums.cp; }
     // ---- Costas loop, tracker.py:246-262
     const double err = pr * pim;
     LockVerdict lv = lock_from_sums(sums, n);
     bool locked = lv.locked;
-    if (lv.marginal || pos_refresh == kLockRefresh - 1) {
+    if (uniform(lv.marginal || pos_refresh == kLockRefresh - 1)) {
         workgroup_mem_fence_wave();                 // lane 0's ring stores -> every lane of this wavefront
         LockSums fresh;
         locked = is_locked_exact_wave(st, n, n + 1, lane, fresh);
@@ -1444,10 +1504,10 @@ __device__ __forceinline__ void loop_filter_update(const TrackBlockParams& p, Ch
     const double tps = p.inv_fs;                // == 1.0 / samples_per_second, formed on the host
     const double alpha = 4.0 * (1.0 / sqrt(2.0)) * bw * tps;
     const double beta = 4.0 * (bw * bw) * tps;
-    double nphi = pymod(phi + err * alpha, 6.283185307179586);
+    double nphi = pymod_uniform(phi + err * alpha, 6.283185307179586);
     double nf = f + err * beta;
     // the error joins its window after is_locked() has been evaluated (tracker.py:251,261)
-    if (n >= kLockWindow) { sums.se -= leave_e; sums.see -= leave_e * leave_e; }
+    sums.se -= n >= kLockWindow ? leave_e : 0.0; sums.see -= n >= kLockWindow ? leave_e * leave_e : 0.0;
     sums.se += err; sums.see += err * err;
     if (lane == 0) st->err_ring[pos_e] = err;
     pos_e = pos_e + 1 == kLockWindow ? 0 : pos_e + 1;
@@ -1456,7 +1516,7 @@ __device__ __forceinline__ void loop_filter_update(const TrackBlockParams& p, Ch
     const double rec_f = nf, rec_phi = nphi;
     // ---- circularity watchdog, tracker.py:370-387
     int status = 0, nudged = 0;
-    if (t0 - last_watchdog >= 6.0) {
+    if (uniform(t0 - last_watchdog >= 6.0)) {
         workgroup_mem_fence_wave();
         double cs[3];
         constellation_stats_wave(st, n + 1, lane, cs);
@@ -1472,37 +1532,146 @@ __device__ __forceinline__ void loop_filter_update(const TrackBlockParams& p, Ch
         }
     }
     if (lane == 0) {
-        ls.dll_phase = dll; ls.last_watchdog = last_watchdog; ls.n_steps = n + 1; ls.sums = sums;
-        ls.pos_e = pos_e; ls.pos_p = pos_p; ls.pos_refresh = pos_refresh;
-        red->loop = ls;
+        red->loop.last_watchdog = last_watchdog; red->loop.n_steps = n + 1; red->loop.sums = sums;
+        red->loop.pos_e = pos_e; red->loop.pos_p = pos_p; red->loop.pos_refresh = pos_refresh;
         red->dstate[0] = nf; red->dstate[1] = nphi;
-        red->istate[0] = new_code_phase; red->istate[1] = lost;
+        red->istate[1] = lost;
         if (kOwnStaging<K>) {   // only the one-sample rotation is used by the halo-free staging
-            const double2 r1 = carrier64_small(nf * p.inv_fs);
+            const double2 rot = carrier64_small(nf * p.inv_fs);
             CarrierSteps cs;
-            cs.rot1 = make_float2((float)r1.x, (float)r1.y);
+            cs.rot1 = make_float2((float)rot.x, (float)rot.y);
             cs.rot_wrap = make_float2(1.f, 0.f);
             red->steps = cs;
         } else {
             red->steps = carrier_steps<K>(nf * p.inv_fs);
         }
-        if (rec) {
-            gyp_track_rec o;
-            o.peak_re = r.peak.x; o.peak_im = r.peak.y;
-            if (r.strength_pending) {
-                o.strength = 0.0f;                  // filled in by track_verify_kernel
-            } else {
-                const float mean_excl = (float)((r.sum - (double)r.n_max * (double)r.peak_mag) / (double)(N - r.n_max));
-                o.strength = r.peak_mag / mean_excl;
-            }
-            o.discriminator = (float)disc;
-            o.doppler_hz = rec_f; o.carrier_phase = rec_phi; o.error = err;
-            o.code_phase = new_code_phase; o.peak_offset = r.key;
-            o.pseudosymbol = (int8_t)(pr > 0.0 ? 1 : (pr < 0.0 ? -1 : 0));
-            o.locked = locked ? 1 : 0; o.status = (int8_t)status; o.nudged = (int8_t)nudged;
-            o.path_info = r.path_info;
-            *rec = o;
+        gyp_track_rec& o = red->rec;
+        o.peak_re = r.peak.x; o.peak_im = r.peak.y;
+        if (r.strength_pending) {
+            o.strength = 0.0f;                  // filled in by track_verify_kernel
+        } else {
+            const float mean_excl = (float)((r.sum - (double)r.n_max * (double)r.peak_mag) / (double)(N - r.n_max));
+            o.strength = r.peak_mag / mean_excl;
         }
+        o.doppler_hz = rec_f; o.carrier_phase = rec_phi; o.error = err;
+        o.peak_offset = r.key;
+        o.pseudosymbol = (int8_t)(pr > 0.0 ? 1 : (pr < 0.0 ? -1 : 0));
+        o.locked = locked ? 1 : 0; o.status = (int8_t)status; o.nudged = (int8_t)nudged;
+        o.path_info = r.path_info;
+    }
+}
+// red->rec -> global memory: 14 dwords, one per lane.  The caller has made the LDS record visible to this wavefront.
+__device__ __forceinline__ void rec_flush(const RedScratch* red, gyp_track_rec* rec, int lane) {
+    static_assert(sizeof(gyp_track_rec) == 56, "record layout");
+    if (rec && lane < 14) reinterpret_cast<uint32_t*>(rec)[lane] = reinterpret_cast<const uint32_t*>(&red->rec)[lane];
+}
+
+// ---- the Costas half again, split three ways for the speculative tracker (see RedScratch::cc) ----------------
+// One candidate: tracker.py:246-262 with the given loop bandwidth.
+__device__ __forceinline__ void costas_candidate(const TrackBlockParams& p, RedScratch* red, cf peak, double f, double phi,
+                                                 double bw, int slot, int lane) {
+    const double err = (double)peak.x * (double)peak.y;
+    const double tps = p.inv_fs;
+    const double alpha = 4.0 * (1.0 / sqrt(2.0)) * bw * tps;
+    const double beta = 4.0 * (bw * bw) * tps;
+    const double nphi = pymod_uniform(phi + err * alpha, 6.283185307179586);
+    const double nf = f + err * beta;
+    const double2 rot = carrier64_small(nf * p.inv_fs);
+    if (lane == 0) {
+        red->cc[slot].nf = nf; red->cc[slot].nphi = nphi;
+        red->cc[slot].rot1 = make_float2((float)rot.x, (float)rot.y);
+    }
+}
+// Everything else of costas_update: histories, lock verdict, watchdog, the record's fields.
+template <int K>
+__device__ __forceinline__ void costas_verdict(const TrackBlockParams& p, ChanState* st, RedScratch* red, double t0, int lane,
+                                               const MsMeasure& r, const double (&leave)[3], double f, double phi) {
+    constexpr int N = K * kChips;
+    int lost = 0;
+    const int64_t n = red->loop.n_steps;
+    double last_watchdog = red->loop.last_watchdog;
+    LockSums sums = red->loop.sums;
+    int pos_e = red->loop.pos_e, pos_p = red->loop.pos_p, pos_refresh = red->loop.pos_refresh;
+    const double leave_e = leave[0], leave_pr = leave[1], leave_pi = leave[2];
+    const double pr = (double)r.peak.x, pim = (double)r.peak.y;
+    if (lane == 0) { st->peak_re[pos_p] = pr; st->peak_im[pos_p] = pim; }
+    {
+        const bool full = n >= kLockWindow;
+        const bool ln = full && leave_pr < 0.0, lp = full && !(leave_pr < 0.0);
+        sums.nr -= ln ? leave_pr : 0.0; sums.ni -= ln ? leave_pi : 0.0; sums.nrr -= ln ? leave_pr * leave_pr : 0.0; sums.cn -= ln ? 1 : 0;
+        sums.pr -= lp ? leave_pr : 0.0; sums.prr -= lp ? leave_pr * leave_pr : 0.0; sums.cp -= lp ? 1 : 0;
+        const bool nn = pr < 0.0;
+        sums.nr += nn ? pr : 0.0; sums.ni += nn ? pim : 0.0; sums.nrr += nn ? pr * pr : 0.0; sums.cn += nn ? 1 : 0;
+        sums.pr += nn ? 0.0 : pr; sums.prr += nn ? 0.0 : pr * pr; sums.cp += nn ? 0 : 1;
+    }
+    const double err = pr * pim;
+    LockVerdict lv = lock_from_sums(sums, n);
+    bool locked = lv.locked;
+    if (uniform(lv.marginal || pos_refresh == kLockRefresh - 1)) {
+        workgroup_mem_fence_wave();
+        LockSums fresh;
+        locked = is_locked_exact_wave(st, n, n + 1, lane, fresh);
+        sums = fresh;
+    }
+    sums.se -= n >= kLockWindow ? leave_e : 0.0; sums.see -= n >= kLockWindow ? leave_e * leave_e : 0.0;
+    sums.se += err; sums.see += err * err;
+    if (lane == 0) st->err_ring[pos_e] = err;
+    pos_e = pos_e + 1 == kLockWindow ? 0 : pos_e + 1;
+    pos_p = pos_p + 1 == kPeakHistory ? 0 : pos_p + 1;
+    pos_refresh = pos_refresh + 1 == kLockRefresh ? 0 : pos_refresh + 1;
+    int status = 0, nudged = 0, sel = locked ? 0 : 1;
+    const int rec_sel = sel;                    // the record carries the values before any watchdog nudge
+    if (uniform(t0 - last_watchdog >= 6.0)) {
+        workgroup_mem_fence_wave();
+        double cs[3];
+        constellation_stats_wave(st, n + 1, lane, cs);
+        last_watchdog = t0;
+        if (cs[0] >= 0.0) {
+            if (cs[0] < 0.2) { status = 1; lost = 1; }
+            else if (cs[0] < 0.93 && cs[2] != 0.0) {
+                const double bw = locked ? 3.0 : 6.0, tps = p.inv_fs;
+                double nphi = pymod_uniform(phi + err * (4.0 * (1.0 / sqrt(2.0)) * bw * tps), 6.283185307179586);
+                double nf = f + err * (4.0 * (bw * bw) * tps);
+                const double sg = cs[1] > 0.0 ? 1.0 : (cs[1] < 0.0 ? -1.0 : 0.0);
+                nf += -sg * 5.0;
+                nphi += sg * (3.141592653589793 / 2.0);
+                nudged = 1;
+                sel = 2;
+                const double2 rot = carrier64_small(nf * p.inv_fs);
+                if (lane == 0) {
+                    red->cc[2].nf = nf; red->cc[2].nphi = nphi;
+                    red->cc[2].rot1 = make_float2((float)rot.x, (float)rot.y);
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        red->loop.last_watchdog = last_watchdog; red->loop.n_steps = n + 1; red->loop.sums = sums;
+        red->loop.pos_e = pos_e; red->loop.pos_p = pos_p; red->loop.pos_refresh = pos_refresh;
+        red->istate[1] = lost;
+        red->cand_sel = sel; red->rec_sel = rec_sel;
+        gyp_track_rec& o = red->rec;
+        o.peak_re = r.peak.x; o.peak_im = r.peak.y;
+        if (r.strength_pending) {
+            o.strength = 0.0f;
+        } else {
+            const float mean_excl = (float)((r.sum - (double)r.n_max * (double)r.peak_mag) / (double)(N - r.n_max));
+            o.strength = r.peak_mag / mean_excl;
+        }
+        o.error = err;
+        o.peak_offset = r.key;
+        o.pseudosymbol = (int8_t)(pr > 0.0 ? 1 : (pr < 0.0 ? -1 : 0));
+        o.locked = locked ? 1 : 0; o.status = (int8_t)status; o.nudged = (int8_t)nudged;
+        o.path_info = r.path_info;
+    }
+}
+// rec_flush for the split form: doppler_hz / carrier_phase (dwords 4..7 of the record) come from the chosen candidate.
+__device__ __forceinline__ void rec_flush_spec(const RedScratch* red, gyp_track_rec* rec, int lane) {
+    static_assert(offsetof(gyp_track_rec, doppler_hz) == 16 && offsetof(gyp_track_rec, carrier_phase) == 24, "record layout");
+    if (rec && lane < 14) {
+        const uint32_t* c = reinterpret_cast<const uint32_t*>(&red->cc[red->rec_sel]);
+        const uint32_t* r = reinterpret_cast<const uint32_t*>(&red->rec);
+        reinterpret_cast<uint32_t*>(rec)[lane] = (lane >= 4 && lane < 8) ? c[lane - 4] : r[lane];
     }
 }
 
@@ -1522,8 +1691,8 @@ struct SpecLds {
     uint16_t* trans;  // [kMaxTrans] this channel's chip transitions
     double* part;     // [4][512]
     float* ein_part;  // [512]
-    double* fin;      // [0..3] boundary sums, [6] (as float) sample energy
-    cf* win;          // [0..15] c0 at the window lags centre-8 .. centre+7, [16] c0 at the prompt lag s
+    double* fin;      // [0..7] boundary sums, two halves each; [8..9] (as 4 floats) sample-energy quarters
+    cf* win;          // [0..15] c0 at the window lags centre-8 .. centre+7, [16..19] four partial sums of c0 at the prompt lag s
 };
 constexpr int kSpecHalf = 8;   // window: 16 lags centre - 8 .. centre + 7 around the previous millisecond's peak lag
 
@@ -1564,28 +1733,52 @@ __device__ __forceinline__ void spec_window(const Smem& sm, const SpecLds& sl, i
         ar = fmaf(a, hv.x, ar); ai = fmaf(a, hv.y, ai);
         br = fmaf(b, hv.x, br); bi = fmaf(b, hv.y, bi);
     }
-    ar = wave_sum(ar); ai = wave_sum(ai); br = wave_sum(br); bi = wave_sum(bi);
-    if (lane == 0) {
+    ar = wave_sum_last(ar); ai = wave_sum_last(ai); br = wave_sum_last(br); bi = wave_sum_last(bi);
+    if (lane == 63) {
         sl.win[wave] = make_float2(ar, ai);
         sl.win[wave + kSpecHalf] = make_float2(br, bi);
     }
-    if (wave == 0) {
+    if (wave < 4) {   // a quarter of the prompt lag each: chips j = lane + 64*(4*wave + k); wavefront 0 adds the halo terms
         const int rs = sN % K, qs = sN / K;
-        const cf* rowp = sm.xch + rs * kXchWave + lane;
-        const float* cp = sl.chipf + (kChips - qs) + lane;
+        const cf* rowp = sm.xch + rs * kXchWave + lane + 256 * wave;
+        const float* cp = sl.chipf + (kChips - qs) + lane + 256 * wave;
         float pr = 0.f, pi = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < 4; ++k) {
             const cf y = rowp[64 * k];
             const float a = cp[64 * k];
             pr = fmaf(a, y.x, pr); pi = fmaf(a, y.y, pi);
         }
-        const cf hv = sm.halo[hrow + rs];
-        const float a = on ? sl.chipf[jf - qs + kChips] : 0.f;
-        pr = fmaf(a, hv.x, pr); pi = fmaf(a, hv.y, pi);
-        pr = wave_sum(pr); pi = wave_sum(pi);
-        if (lane == 0) sl.win[2 * kSpecHalf] = make_float2(pr, pi);
+        if (wave == 0) {
+            const cf hv = sm.halo[hrow + rs];
+            const float a = on ? sl.chipf[jf - qs + kChips] : 0.f;
+            pr = fmaf(a, hv.x, pr); pi = fmaf(a, hv.y, pi);
+        }
+        pr = wave_sum_last(pr); pi = wave_sum_last(pi);
+        if (lane == 63) sl.win[2 * kSpecHalf + wave] = make_float2(pr, pi);
     }
+}
+
+// The transform path of the speculative kernel, out of line: it runs once per few hundred milliseconds, and inlined
+// its 100+ live registers set the register pressure (and the spills) of the whole per-millisecond loop.
+template <int K>
+__device__ __attribute__((noinline)) EplResult spec_transform_path(const Smem& sm, const cf* __restrict__ rep, int sN) {
+    const int tid = launder(threadIdx.x);
+    const int wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
+    cf x[32];
+    const cf* yw = sm.xch + wave * kXchWave;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) x[j] = yw[32 * j + l];
+    halo_fixup<K>(x, sm.halo, wave, l);
+    wave_lds_fence();
+    float* tile_half = reinterpret_cast<float*>(sm.xch + wave * kXchWave) + h * kXchTile;
+    const LdsTables t{sm.tw1024, sm.tw2048};
+    cf c[16];
+    wave_fft_fwd(x, tile_half, t, l, h);
+    spectrum_mul_from(x, rep, lane);
+    wave_fft_inv(x, c, tile_half, t, l, h);
+    epl_round_wave<K>(c, sN, sN, sm.red, nullptr, tid);
+    return epl_finish_wave<K>(sm.red);
 }
 
 // MODE 0: throughput form (several workgroups per CU).  MODE 1: latency variant for at most one workgroup per CU
@@ -1652,10 +1845,16 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         sm.red->istate[0] = st->code_phase; sm.red->istate[1] = st->lost;
         sm.red->istate[2] = mod_n(st->code_phase, N);   // speculative window centre: no peak seen yet in this launch
         sm.red->steps = carrier_steps<K>(st->doppler * p.inv_fs);
+        sm.red->cc[0].nf = st->doppler; sm.red->cc[0].nphi = st->carrier_phase;
+        sm.red->cc[0].rot1 = sm.red->steps.rot1;
+        sm.red->cand_sel = 0; sm.red->rec_sel = 0;
     }
     __syncthreads();
     const bool prof = PROF && p.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
-    long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_last = 0;
+    // speculative mode: tp[6 + i] accumulates the cycles between stamp i-1 and stamp i of workgroup 0's thread 0
+#define GYP_STAMP(i) do { if (prof) { const long long now_ = (long long)__builtin_readcyclecounter(); tp[6 + (i)] += now_ - t_last; t_last = now_; } } while (0)
     OwnSamples<LAT ? K : 1> smp;          // LAT: the next millisecond's raw samples
     cf prn[MODE == 1 ? 32 : 1];           // MODE 1: this satellite's replica spectrum
     if constexpr (LAT) {
@@ -1666,13 +1865,23 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         }
         if (p.ms_begin < p.ms_end) stage_fetch_own<K>(stream + (int64_t)p.ms_begin * N, smp, launder(threadIdx.x));
     }
+    // speculative mode: this thread's chip transitions (sample offset K*m, coefficient +-2), fixed for the whole launch
+    int el_off0 = -1, el_off1 = -1;
+    float el_g0 = 0.f, el_g1 = 0.f;
+    if constexpr (SPEC) {
+        const int e0 = launder(threadIdx.x), e1 = e0 + Geom<K>::kThreads;
+        if (e0 < nt) { const unsigned t = trans[e0]; el_off0 = K * (int)(t & 0x3ffu); el_g0 = (t & 0x8000u) ? -2.0f : 2.0f; }
+        if (e1 < nt) { const unsigned t = trans[e1]; el_off1 = K * (int)(t & 0x3ffu); el_g1 = (t & 0x8000u) ? -2.0f : 2.0f; }
+    }
     for (int ms = p.ms_begin; ms < p.ms_end; ++ms) {
         gyp_track_rec* rec = p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + ms : nullptr;
         if (sm.red->istate[1]) {  // a dropped channel stays dropped until the host re-creates it (receiver.py:259-267)
             if (threadIdx.x == 0) {
                 if (rec) {
                     gyp_track_rec z = {};
-                    z.status = 2; z.doppler_hz = sm.red->dstate[0]; z.carrier_phase = sm.red->dstate[1]; z.code_phase = sm.red->istate[0];
+                    z.status = 2; z.code_phase = sm.red->istate[0];
+                    z.doppler_hz = SPEC ? sm.red->cc[sm.red->cand_sel].nf : sm.red->dstate[0];
+                    z.carrier_phase = SPEC ? sm.red->cc[sm.red->cand_sel].nphi : sm.red->dstate[1];
                     *rec = z;
                 }
                 if (SPEC) p.spec_out[(int64_t)ch * p.n_ms + ms].key = -1;
@@ -1681,12 +1890,19 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         }
         long long t_a = prof ? (long long)__builtin_readcyclecounter() : 0;
         long long t_b = t_a, t_c = t_a;
+        t_last = t_a;
         MsMeasure m;
         double leave[3] = {0.0, 0.0, 0.0};
         const double t0 = p.start_time[launder(ms)];
+        double f, phi;
+        CarrierSteps cs;
+        if constexpr (SPEC) {
+            const auto cc = sm.red->cc[sm.red->cand_sel];
+            f = cc.nf; phi = cc.nphi; cs.rot1 = cc.rot1; cs.rot_wrap = make_float2(1.f, 0.f);
+        } else {
+            f = sm.red->dstate[0]; phi = sm.red->dstate[1]; cs = sm.red->steps;
+        }
         {
-            const double f = sm.red->dstate[0], phi = sm.red->dstate[1];
-            const CarrierSteps cs = sm.red->steps;
             const int code_phase = sm.red->istate[0];
             const double u0 = f * t0 + phi * 0.15915494309189533577, du = f * p.inv_fs;
             const cf* block = stream + (int64_t)ms * N;
@@ -1694,10 +1910,13 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
                 const int tid = launder(threadIdx.x);
                 const int sN = mod_n(code_phase, N);
                 asm volatile("; MARK_STAGE_BEGIN");
+                GYP_STAMP(0);
                 // the boundary samples of the float64 early/late sums are requested first, consumed after the staging
-                if (wave == 0) fetch_leaving(st, sm.red, leave);
-                const ElSample el0 = el_fetch<K>(block, sN, sl.trans, nt, tid);
-                const ElSample el1 = el_fetch<K>(block, sN, sl.trans, nt, tid + Geom<K>::kThreads);
+                const ElSample el0 = el_fetch_const<K>(block, sN, el_off0, el_g0);
+                ElSample el1;
+                el1.nl = -1;
+                if (nt > Geom<K>::kThreads) el1 = el_fetch_const<K>(block, sN, el_off1, el_g1);   // uniform
+                GYP_STAMP(1);
                 const float e_in = (smp.w[0][0].x * smp.w[0][0].x + smp.w[0][0].y * smp.w[0][0].y) +
                                    (smp.w[0][4].x * smp.w[0][4].x + smp.w[0][4].y * smp.w[0][4].y) +
                                    (smp.w[1][0].x * smp.w[1][0].x + smp.w[1][0].y * smp.w[1][0].y) +
@@ -1706,27 +1925,33 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
 #pragma unroll
                 for (int r = 0; r < K; ++r) y_rows[r] = sm.xch + r * kXchWave;
                 stage_emit_own<K>(smp, u0, du, cs, y_rows, sm.halo, tid);
+                GYP_STAMP(2);
                 double acc[4] = {0.0, 0.0, 0.0, 0.0};
                 el_accumulate<K>(el0, u0, du, acc);
-                if (__any(el1.nl >= 0)) el_accumulate<K>(el1, u0, du, acc);
+                if (nt > Geom<K>::kThreads && __any(el1.nl >= 0)) el_accumulate<K>(el1, u0, du, acc);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) sl.part[v * Geom<K>::kThreads + tid] = acc[v];
                 sl.ein_part[tid] = e_in;
                 asm volatile("; MARK_STAGE_END");
-                __syncthreads();
+                GYP_STAMP(3);
+                lds_barrier();
+                GYP_STAMP(4);
+                if (wave == 0) fetch_leaving(st, sm.red, leave);
+                // the raw samples are consumed: request the next millisecond now, the loads fly under the window sums
+                if (ms + 1 < p.ms_end) stage_fetch_own<K>(stream + (int64_t)(ms + 1) * N, smp, launder(threadIdx.x));
                 if (prof) t_b = (long long)__builtin_readcyclecounter();
                 const int centre = sm.red->istate[2];
                 spec_window<K>(sm, sl, centre, sN, tid);
-                sum_partials64<K, 4>(sl.part, sl.fin, 4, tid);
-                if (wave == 3) {
-                    float a = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) a += sl.ein_part[lane + 64 * k];
-                    a = wave_sum(a);
-                    if (lane == 0) reinterpret_cast<float*>(sl.fin + 6)[0] = 4.0f * a;   // every 4th sample was summed
+                sum_partials64_spec(sl.part, sl.fin, tid);
+                if (wave >= 4) {   // the sample energy, a quarter per wavefront
+                    const float* src = sl.ein_part + 128 * (wave - 4) + lane;
+                    const float a = wave_sum_last(src[0] + src[64]);
+                    if (lane == 63) reinterpret_cast<float*>(sl.fin + 8)[wave - 4] = a;
                 }
                 asm volatile("; MARK_WINDOW_END");
-                __syncthreads();
+                GYP_STAMP(5);
+                lds_barrier();
+                GYP_STAMP(6);
                 // every wavefront takes the same decision from the same 16 values; ties resolve like np.argmax on the
                 // profile of the PRN rolled by s (lowest rolled index)
                 const int wi = lane & 15;
@@ -1735,12 +1960,13 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
                 int wkey = wlag - sN;
                 wkey = wkey < 0 ? wkey + N : wkey;
                 const cf wv = sl.win[wi];
-                const Best b = wave_best(Best{fmaf(wv.x, wv.x, wv.y * wv.y), wkey});
+                const Best b = row16_best(Best{fmaf(wv.x, wv.x, wv.y * wv.y), wkey});
                 int blag = b.key + sN;
                 blag = blag >= N ? blag - N : blag;
                 int wbest = blag - centre + kSpecHalf;
                 wbest = wbest < 0 ? wbest + N : (wbest >= N ? wbest - N : wbest);
-                const float energy = reinterpret_cast<const float*>(sl.fin + 6)[0];
+                const float4 eq = *reinterpret_cast<const float4*>(sl.fin + 8);
+                const float energy = 4.0f * ((eq.x + eq.y) + (eq.z + eq.w));   // every 4th sample was summed
                 const bool fast = wbest != 0 && wbest != 2 * kSpecHalf - 1 && b.v >= p.spec_kappa * energy;
                 if (prof) { t_c = (long long)__builtin_readcyclecounter(); tp[5] += fast ? 0 : 1; }
                 if (p.dbg && wave == 0 && lane < 20) {
@@ -1748,49 +1974,34 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
                     o[lane] = lane < 16 ? fmaf(wv.x, wv.x, wv.y * wv.y) : (lane == 16 ? energy : (lane == 17 ? (float)sN : (lane == 18 ? (float)centre : 0.f)));
                 }
                 m.disc = 0.0;
-                {
-                    const float ratio = energy > 0.f ? b.v / energy : 65535.f;
-                    m.path_info = (fast ? 1 : 0) | (wbest << 8) | ((int)fminf(ratio, 65535.f) << 16);
-                }
+                m.path_info = (fast ? 1 : 0) | (wbest << 8) | ((int)fminf(b.v * __builtin_amdgcn_rcpf(fmaxf(energy, 1e-30f)), 65535.f) << 16);
                 int next_centre = blag;
                 asm volatile("; MARK_DECIDE_END");
+                GYP_STAMP(7);
                 if (fast) {
                     m.peak = sl.win[wbest];
                     m.peak_mag = __builtin_amdgcn_sqrtf(b.v);
                     m.key = b.key; m.sum = 0.0; m.n_max = 0; m.strength_pending = true;
                 } else {
-                    // full profile from the rows already staged (track_ms_fetched from its barrier on)
-                    const int l = lane & 31, h = lane >> 5;
-                    cf x[32];
-                    const cf* yw = sm.xch + wave * kXchWave;
-#pragma unroll
-                    for (int j = 0; j < 32; ++j) x[j] = yw[32 * j + l];
-                    halo_fixup<K>(x, sm.halo, wave, l);
-                    wave_lds_fence();
-                    float* tile_half = reinterpret_cast<float*>(sm.xch + wave * kXchWave) + h * kXchTile;
-                    const LdsTables t{sm.tw1024, sm.tw2048};
-                    cf c[16];
-                    wave_fft_fwd(x, tile_half, t, l, h);
-                    spectrum_mul_from(x, rep, lane);
-                    wave_fft_inv(x, c, tile_half, t, l, h);
-                    epl_round_wave<K>(c, sN, sN, sm.red, nullptr, tid);
-                    const EplResult r = epl_finish_wave<K>(sm.red);
+                    // full profile from the rows already staged; the prefetched samples of the next millisecond stay
+                    // in their registers meanwhile
+                    const EplResult r = spec_transform_path<K>(sm, rep, sN);
                     m.peak = r.peak; m.peak_mag = r.best.v; m.key = r.best.key; m.sum = r.sum; m.n_max = r.n_max;
                     m.strength_pending = false;
                     next_centre = r.best.key + sN;
                     next_centre = next_centre >= N ? next_centre - N : next_centre;
                 }
-                if (wave == 0) {
-                    const cf pv = sl.win[2 * kSpecHalf];
-                    m.disc = dll_discriminator((double)pv.x, (double)pv.y, sl.fin);
-                    if (lane == 0) {
-                        sm.red->istate[2] = next_centre;
-                        SpecIn si;
-                        si.doppler = f; si.carrier_phase = phi; si.code_phase = code_phase; si.key = fast ? m.key : -1;
-                        p.spec_out[(int64_t)ch * p.n_ms + ms] = si;
-                    }
+                if (wave == 1) {   // the code loop runs beside the Costas loop (wavefront 0)
+                    const cf p0 = sl.win[2 * kSpecHalf], p1 = sl.win[2 * kSpecHalf + 1], p2 = sl.win[2 * kSpecHalf + 2], p3 = sl.win[2 * kSpecHalf + 3];
+                    const double d[4] = {sl.fin[0] + sl.fin[1], sl.fin[2] + sl.fin[3], sl.fin[4] + sl.fin[5], sl.fin[6] + sl.fin[7]};
+                    m.disc = dll_discriminator((double)((p0.x + p1.x) + (p2.x + p3.x)), (double)((p0.y + p1.y) + (p2.y + p3.y)), d);
                 }
-                if (ms + 1 < p.ms_end) stage_fetch_own<K>(stream + (int64_t)(ms + 1) * N, smp, launder(threadIdx.x));
+                if (wave == 3 && lane == 0) {
+                    SpecIn si;
+                    si.doppler = f; si.carrier_phase = phi; si.code_phase = code_phase; si.key = fast ? m.key : -1;
+                    p.spec_out[(int64_t)ch * p.n_ms + ms] = si;
+                    sm.red->istate[2] = next_centre;
+                }
             } else {
                 EplResult r;
                 if constexpr (MODE == 1) {
@@ -1809,26 +2020,39 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
                 if (prof) t_c = (long long)__builtin_readcyclecounter();
             }
         }
+        GYP_STAMP(8);
         asm volatile("; MARK_UPDATE_BEGIN");
-        if (wave == 0) {
-            if constexpr (!SPEC) fetch_leaving(st, sm.red, leave);
-            loop_filter_update<K>(p, st, sm.red, t0, lane, m, leave, rec);
+        if constexpr (SPEC) {
+            if (wave == 0) costas_verdict<K>(p, st, sm.red, t0, lane, m, leave, f, phi);
+            if (wave == 1) dll_update(sm.red, m.disc, lane);
+            if (wave == 2) costas_candidate(p, sm.red, m.peak, f, phi, 3.0, 0, lane);
+            if (wave == 3) costas_candidate(p, sm.red, m.peak, f, phi, 6.0, 1, lane);
+        } else if (wave == 0) {
+            fetch_leaving(st, sm.red, leave);
+            dll_update(sm.red, m.disc, lane);
+            costas_update<K>(p, st, sm.red, t0, lane, m, leave);
+            workgroup_mem_fence_wave();
+            rec_flush(sm.red, rec, lane);
         }
         asm volatile("; MARK_UPDATE_END");
         long long t_d = prof ? (long long)__builtin_readcyclecounter() : 0;
-        __syncthreads();
+        GYP_STAMP(9);
+        if constexpr (SPEC) lds_barrier(); else __syncthreads();
+        if (SPEC && wave == 2) rec_flush_spec(sm.red, rec, lane);   // assembled by wavefronts 0..3 before the barrier
         if (prof) {
             const long long t_e = (long long)__builtin_readcyclecounter();
             tp[0] += t_b - t_a; tp[1] += t_c - t_b; tp[2] += t_d - t_c; tp[3] += t_e - t_d; tp[4] += 1;
         }
+#undef GYP_STAMP
     }
     if (threadIdx.x == 0) {
-        st->doppler = sm.red->dstate[0]; st->carrier_phase = sm.red->dstate[1];
+        st->doppler = SPEC ? sm.red->cc[sm.red->cand_sel].nf : sm.red->dstate[0];
+        st->carrier_phase = SPEC ? sm.red->cc[sm.red->cand_sel].nphi : sm.red->dstate[1];
         st->code_phase = sm.red->istate[0]; st->lost = sm.red->istate[1];
         const LoopState ls = sm.red->loop;
         st->dll_phase = ls.dll_phase; st->n_steps = ls.n_steps; st->last_watchdog_time = ls.last_watchdog;
         st->sums = ls.sums;
-        if (prof) for (int i = 0; i < 8; ++i) p.prof[i] = tp[i];
+        if (prof) for (int i = 0; i < 16; ++i) p.prof[i] = tp[i];
     }
 }
 

@@ -371,8 +371,11 @@ int gyp_ingest_times(const gyp_ingest* ing, int64_t first_ms, int32_t n_ms, doub
 /* Debug: per-phase shader-cycle counters of workgroup 0 of gyp_track_block_dev (correlate, reduce, loop update,
  * barrier, ms count) or, for the pipelined 8.184 Msps non-coherent cells kernel behind gyp_correlate_cells_dev /
  * gyp_acquire_dev, (stage, row load + forward, spectrum + prefetch, inverse + accumulate, barrier, iterations).
- * enable != 0 arms it; out8 (may be NULL) receives the counters of the last launch. */
-int gyp_debug_track_profile(gyp_ctx* ctx, int enable, long long* out8);
+ * enable != 0 arms it; out16 (may be NULL, else room for 16 values) receives the counters of the last launch: [0..4] as
+ * above, [5] milliseconds that took the transform path in the speculative tracker, [6..15] the speculative tracker's
+ * stamp-to-stamp cycles (state read, sample requests, staging, boundary sums, barrier, window, barrier, decision,
+ * transform path if taken, loop update). */
+int gyp_debug_track_profile(gyp_ctx* ctx, int enable, long long* out16);
 /* Debug (speculative block tracker, 8.184 Msps banks of at most one channel per CU): with GYP_SPEC_DEBUG set in the
  * environment the last gyp_track_block(_dev) call leaves, per (channel, ms), 20 floats: |c0|^2 at the 16 window lags
  * code_phase-8 .. code_phase+7, the sample-energy estimate, code_phase mod N, 0, 0.  bad_out (may be NULL): per

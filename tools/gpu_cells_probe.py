@@ -43,7 +43,7 @@ def main():
     print(f"{len(cells)} cells x {T} ms: {ms:.3f} ms -> {ms * 1e3 / (len(cells) * T / 256):.2f} us per cell-ms per CU")
     if "--noprof" in sys.argv:
         return
-    out = np.zeros(8, dtype=np.int64)
+    out = np.zeros(16, dtype=np.int64)
     eng._check(eng.lib.gyp_debug_track_profile(eng.ctx, 1, C.c_void_p(out.ctypes.data)))
     steps = max(1, out[5])
     names = ["emit (wipe + rows of ms+1)", "row load + forward transform", "spectrum mul + fetch issue", "inverse + |.| accumulate", "barrier"]

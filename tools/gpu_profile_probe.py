@@ -40,7 +40,7 @@ def main():
         eng.timer_start()
         bank.track_block_dev(iq.ptr.value, T * n, T, t_dev.ptr.value, rec.ptr.value)
         ms = eng.timer_stop()
-    out = np.zeros(8, dtype=np.int64)
+    out = np.zeros(16, dtype=np.int64)
     eng._check(eng.lib.gyp_debug_track_profile(eng.ctx, 1, C.c_void_p(out.ctypes.data)))
     steps = max(1, out[4])
     names = ["stage+fft (correlate_ms)", "reduce (epl)", "loop update (wave 0)", "barrier + state broadcast"]
@@ -52,6 +52,10 @@ def main():
     print(f"  speculative mode: phases are stage | window + decision | transform path (if taken) + loop update | barrier; "
           f"{out[5]} of {steps} ms took the transform path in workgroup 0")
     r = rec.download(TRACK_REC, B * C_ * T).reshape(B * C_, T)
+    stamps = ["state read", "sample requests", "staging emit", "boundary sums + partial writes", "barrier A", "window + partial sums",
+              "barrier B", "decision", "(transform path)", "loop update"]
+    for i, nm in enumerate(stamps):
+        print(f"    stamp {i} {nm:32s} {out[6 + i] / steps:8.0f} cycles/ms")
     pi = r["path_info"]
     print("  fast-path fraction", float((pi & 3).mean()), "window index histogram", np.bincount(((pi >> 8) & 255).ravel(), minlength=16)[:16].tolist(),
           "ratio min/median", int((pi >> 16).min()), float(np.median(pi >> 16)), "per-channel fast", (pi & 3).mean(axis=1).round(2).tolist())
