@@ -87,7 +87,9 @@ struct RedScratch {
     gyp_track_rec rec;  // the millisecond's record, assembled by the loop updates, flushed to global memory by rec_flush
     // speculative tracker: the Costas update for either loop bandwidth is formed by its own wavefront while a third works
     // out the lock verdict; cand_sel says which one the next millisecond runs with (2: the watchdog's nudged values)
-    struct CostasCand { double nf, nphi; cf rot1; double pad; } cc[3];
+    // verdict_prepare -> verdict_finish hand-over (kept here rather than in registers across the window barrier)
+    struct VerdictPrepLds { LockSums sums; double leave_e; int32_t var_ok, var_marginal; } vprep;
+    struct CostasCand { double nf, nphi; cf rot1; cf step; } cc[3];   // step: the carrier over 4096 samples (second chip of a thread)
     int cand_sel, rec_sel, pad2[2];
 };
 static_assert(sizeof(RedScratch) <= kRedBytes, "reduction scratch too large");
@@ -1293,8 +1295,10 @@ __device__ __forceinline__ LockVerdict lock_from_sums(const LockSums& s, int64_t
 // Exact (two-pass) evaluation of tracker.py:157-203 by one whole wavefront; also returns the freshly summed
 // LockSums so the sliding sums can be re-based.  n_err: errors appended so far (window = the last 250 of them);
 // n_peaks: peaks appended so far, the current one included.
-__device__ __forceinline__ bool is_locked_exact_wave(const ChanState* st, int64_t n_err, int64_t n_peaks, int lane,
-                                                     LockSums& fresh) {
+// Out of line (it runs about once per thousand milliseconds): inlined, its dozens of live float64 values raise the
+// register pressure of every tracking loop that contains it.
+__device__ __attribute__((noinline)) bool is_locked_exact_wave(const ChanState* st, int64_t n_err, int64_t n_peaks, int lane,
+                                                               LockSums& fresh) {
     const int e_newest = (int)((n_err - 1 + kLockWindow) % kLockWindow), p_newest = (int)((n_peaks - 1) % kPeakHistory);
     const int ne = (int)(n_err < kLockWindow ? n_err : kLockWindow);
     const int np = (int)(n_peaks < kLockWindow ? n_peaks : kLockWindow);
@@ -1348,7 +1352,7 @@ __device__ __forceinline__ bool is_locked_exact_wave(const ChanState* st, int64_
 
 // utils.py:134-144 circularity and :119-131 rotation over the last min(n_peaks, 1000) peaks, by wavefront 0.
 // out[0] = circularity (or -1 if < 2 peaks), out[1] = rotation in degrees, out[2] = 1 if rotation valid.
-__device__ __forceinline__ void constellation_stats_wave(const ChanState* st, int64_t n_peaks, int lane, double (&out)[3]) {
+__device__ __attribute__((noinline)) void constellation_stats_wave(const ChanState* st, int64_t n_peaks, int lane, double (&out)[3]) {
     const int n = (int)(n_peaks < kPeakHistory ? n_peaks : kPeakHistory);
     double sr = 0.0, si = 0.0, lr = 0.0, li = 0.0;
     int cl = 0;
@@ -1577,43 +1581,71 @@ __device__ __forceinline__ void costas_candidate(const TrackBlockParams& p, RedS
     const double nphi = pymod_uniform(phi + err * alpha, 6.283185307179586);
     const double nf = f + err * beta;
     const double2 rot = carrier64_small(nf * p.inv_fs);
+    const cf step = carrier_from_cycles_fast(nf * p.inv_fs * 4096.0);
     if (lane == 0) {
         red->cc[slot].nf = nf; red->cc[slot].nphi = nphi;
         red->cc[slot].rot1 = make_float2((float)rot.x, (float)rot.y);
+        red->cc[slot].step = step;
     }
 }
-// Everything else of costas_update: histories, lock verdict, watchdog, the record's fields.
+// Everything else of costas_update -- histories, lock verdict, watchdog, the record's fields -- in two steps: what does
+// not depend on this millisecond's peak (state read, the entries leaving the windows, the error-variance test, which
+// is_locked() evaluates before the new error joins) is done while the window sums are still being formed.
+__device__ __forceinline__ void verdict_prepare(RedScratch* red, const double (&leave)[3], int lane) {
+    const int64_t n = red->loop.n_steps;
+    LockSums s = red->loop.sums;
+    const double leave_pr = leave[1], leave_pi = leave[2];
+    const bool full = n >= kLockWindow;
+    const bool ln = full && leave_pr < 0.0, lp = full && !(leave_pr < 0.0);
+    s.nr -= ln ? leave_pr : 0.0; s.ni -= ln ? leave_pi : 0.0; s.nrr -= ln ? leave_pr * leave_pr : 0.0; s.cn -= ln ? 1 : 0;
+    s.pr -= lp ? leave_pr : 0.0; s.prr -= lp ? leave_pr * leave_pr : 0.0; s.cp -= lp ? 1 : 0;
+    constexpr double W = (double)kLockWindow;
+    const double xe = s.see * W - s.se * s.se, te = 900.0 * W * W;     // see lock_from_sums
+    if (lane == 0) {
+        red->vprep.sums = s;                       // the leaving peak already removed
+        red->vprep.leave_e = leave[0];
+        red->vprep.var_ok = xe < te ? 1 : 0;
+        red->vprep.var_marginal = fabs(xe - te) <= 1e-9 * te ? 1 : 0;
+    }
+}
 template <int K>
-__device__ __forceinline__ void costas_verdict(const TrackBlockParams& p, ChanState* st, RedScratch* red, double t0, int lane,
-                                               const MsMeasure& r, const double (&leave)[3], double f, double phi) {
+__device__ __forceinline__ void verdict_finish(const TrackBlockParams& p, ChanState* st, RedScratch* red, double t0, int lane,
+                                               const MsMeasure& r, double f, double phi) {
     constexpr int N = K * kChips;
     int lost = 0;
     const int64_t n = red->loop.n_steps;
     double last_watchdog = red->loop.last_watchdog;
-    LockSums sums = red->loop.sums;
+    LockSums sums = red->vprep.sums;
+    struct { bool var_ok, var_marginal; double leave_e; } v{red->vprep.var_ok != 0, red->vprep.var_marginal != 0, red->vprep.leave_e};
     int pos_e = red->loop.pos_e, pos_p = red->loop.pos_p, pos_refresh = red->loop.pos_refresh;
-    const double leave_e = leave[0], leave_pr = leave[1], leave_pi = leave[2];
     const double pr = (double)r.peak.x, pim = (double)r.peak.y;
     if (lane == 0) { st->peak_re[pos_p] = pr; st->peak_im[pos_p] = pim; }
-    {
-        const bool full = n >= kLockWindow;
-        const bool ln = full && leave_pr < 0.0, lp = full && !(leave_pr < 0.0);
-        sums.nr -= ln ? leave_pr : 0.0; sums.ni -= ln ? leave_pi : 0.0; sums.nrr -= ln ? leave_pr * leave_pr : 0.0; sums.cn -= ln ? 1 : 0;
-        sums.pr -= lp ? leave_pr : 0.0; sums.prr -= lp ? leave_pr * leave_pr : 0.0; sums.cp -= lp ? 1 : 0;
-        const bool nn = pr < 0.0;
-        sums.nr += nn ? pr : 0.0; sums.ni += nn ? pim : 0.0; sums.nrr += nn ? pr * pr : 0.0; sums.cn += nn ? 1 : 0;
-        sums.pr += nn ? 0.0 : pr; sums.prr += nn ? 0.0 : pr * pr; sums.cp += nn ? 0 : 1;
-    }
+    const bool nn = pr < 0.0;
+    sums.nr += nn ? pr : 0.0; sums.ni += nn ? pim : 0.0; sums.nrr += nn ? pr * pr : 0.0; sums.cn += nn ? 1 : 0;
+    sums.pr += nn ? 0.0 : pr; sums.prr += nn ? 0.0 : pr * pr; sums.cp += nn ? 0 : 1;
     const double err = pr * pim;
-    LockVerdict lv = lock_from_sums(sums, n);
-    bool locked = lv.locked;
-    if (uniform(lv.marginal || pos_refresh == kLockRefresh - 1)) {
+    bool locked, marginal;
+    {   // the pole half of lock_from_sums
+        const double cn = (double)sums.cn, cp = (double)sums.cp;
+        const bool n2 = sums.cn >= 2, p2 = sums.cp >= 2;
+        const double a = n2 ? sums.nrr * cn - sums.nr * sums.nr : 0.0, b = p2 ? sums.prr * cp - sums.pr * sums.pr : 0.0;
+        const double cn2 = n2 ? cn * cn : 1.0, cp2 = p2 ? cp * cp : 1.0;
+        const double xi = a * cp2 + b * cn2, ti = 4.0 * cn2 * cp2;
+        const bool i_ok = xi < ti;
+        const double lhs = fabs(sums.ni), rhs = 0.10510423526567646 * fabs(sums.nr);
+        const bool rot_tested = v.var_ok && i_ok && n2;
+        const bool rot_ok = !rot_tested || lhs < rhs;
+        const bool full = n >= kLockWindow;
+        marginal = full && (v.var_marginal || fabs(xi - ti) <= 1e-9 * ti || (rot_tested && fabs(lhs - rhs) <= 1e-9 * (lhs + rhs)));
+        locked = full && v.var_ok && i_ok && rot_ok;
+    }
+    if (uniform(marginal || pos_refresh == kLockRefresh - 1)) {
         workgroup_mem_fence_wave();
         LockSums fresh;
         locked = is_locked_exact_wave(st, n, n + 1, lane, fresh);
         sums = fresh;
     }
-    sums.se -= n >= kLockWindow ? leave_e : 0.0; sums.see -= n >= kLockWindow ? leave_e * leave_e : 0.0;
+    sums.se -= n >= kLockWindow ? v.leave_e : 0.0; sums.see -= n >= kLockWindow ? v.leave_e * v.leave_e : 0.0;
     sums.se += err; sums.see += err * err;
     if (lane == 0) st->err_ring[pos_e] = err;
     pos_e = pos_e + 1 == kLockWindow ? 0 : pos_e + 1;
@@ -1638,9 +1670,11 @@ __device__ __forceinline__ void costas_verdict(const TrackBlockParams& p, ChanSt
                 nudged = 1;
                 sel = 2;
                 const double2 rot = carrier64_small(nf * p.inv_fs);
+                const cf step = carrier_from_cycles_fast(nf * p.inv_fs * 4096.0);
                 if (lane == 0) {
                     red->cc[2].nf = nf; red->cc[2].nphi = nphi;
                     red->cc[2].rot1 = make_float2((float)rot.x, (float)rot.y);
+                    red->cc[2].step = step;
                 }
             }
         }
@@ -1692,70 +1726,79 @@ struct SpecLds {
     double* part;     // [4][512]
     float* ein_part;  // [512]
     double* fin;      // [0..7] boundary sums, two halves each; [8..9] (as 4 floats) sample-energy quarters
-    cf* win;          // [0..15] c0 at the window lags centre-8 .. centre+7, [16..19] four partial sums of c0 at the prompt lag s
+    cf* win;          // [0..7] c0 at the window lags centre-4 .. centre+3, [8..11] four partial sums of c0 at the prompt lag s
 };
-constexpr int kSpecHalf = 8;   // window: 16 lags centre - 8 .. centre + 7 around the previous millisecond's peak lag
+constexpr int kSpecHalf = 4;   // window: 8 lags centre - 4 .. centre + 3 around the previous millisecond's peak lag
 
 // Window correlations of the speculative path, straight from the staged rows:
 //     c0[K*q + r] = sum_j chip[(j - q) mod 1023] * y_r[j].
 // The window follows the PEAK, not the code phase: the reference's code loop (tracker.py:297-303) is repelled by the peak
 // and parks the code phase ~9 samples to one side of it, so the arg-max of the rolled prompt profile sits at an offset of
-// about +-9 and wanders slowly.  Wavefront w forms the lags centre + w - 8 and centre + w (same polyphase row, code shifted
-// by one chip); wavefront 0 also forms the prompt lag s itself (win[16]), which the discriminator needs.
+// about +-9 and wanders slowly.  Wavefront w forms the lag centre + w - 4; wavefronts 0..3 also form a quarter each of
+// the prompt lag s itself, which the discriminator needs.  The +-1 code values a lane multiplies its sixteen (four) row
+// elements by depend only on the lag's chip offset q, which changes every few hundred milliseconds: they are kept in
+// registers (WinCache) and re-read from the LDS code table only then.
+struct WinCache {
+    float c[16], ch;   // window lag: chip[(lane + 64k - q) mod 1023], and the halo chip's
+    int q;
+    float p[4], ph;    // prompt-lag quarter
+    int qs;
+};
 template <int K>
-__device__ __forceinline__ void spec_window(const Smem& sm, const SpecLds& sl, int centre, int sN, int tid) {
-    static_assert(K == 8 && Geom<K>::W == 8, "one window lag pair per wavefront");
+__device__ __forceinline__ void spec_window(const Smem& sm, const SpecLds& sl, int centre, int sN, int tid, WinCache& wc) {
+    static_assert(K == 8 && Geom<K>::W == 8, "one window lag per wavefront");
     constexpr int N = K * kChips;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    int la = centre + wave - kSpecHalf;
-    la = la < 0 ? la + N : la;
+    int la = __builtin_amdgcn_readfirstlane(centre) + wave - kSpecHalf;
+    la = la < 0 ? la + N : (la >= N ? la - N : la);
     const int rw = la % K, qa = la / K;
-    const int qb = qa + 1 == kChips ? 0 : qa + 1;
-    const cf* row = sm.xch + rw * kXchWave + lane;
-    const float* ca = sl.chipf + (kChips - qa) + lane;    // chip[(j - q) mod 1023] = chipf[j - q + 1023]
-    const float* cb = sl.chipf + (kChips - qb) + lane;
-    float ar = 0.f, ai = 0.f, br = 0.f, bi = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const cf y = row[64 * k];
-        const float a = ca[64 * k], b = cb[64 * k];
-        ar = fmaf(a, y.x, ar); ai = fmaf(a, y.y, ai);
-        br = fmaf(b, y.x, br); bi = fmaf(b, y.y, bi);
-    }
-    // the sixteen chips whose neighbour prefix sums live in the halo table (see halo_fixup)
+    // the sixteen chips whose neighbour prefix sums live in the halo table (see halo_fixup): lane k < 16 takes one
     const int hk = lane & 15;
     const int jf = hk < 15 ? 63 + 64 * hk : kChips - 1;
     const int hrow = (hk < 15 ? hk + 1 : 0) * K;
     const bool on = lane < 16;
+    if (qa != wc.q) {   // wave-uniform
+        const float* ca = sl.chipf + (kChips - qa) + lane;    // chip[(j - q) mod 1023] = chipf[j - q + 1023]
+#pragma unroll
+        for (int k = 0; k < 16; ++k) wc.c[k] = ca[64 * k];
+        wc.ch = on ? sl.chipf[jf - qa + kChips] : 0.f;
+        wc.q = qa;
+    }
+    const cf* row = sm.xch + rw * kXchWave + lane;
+    float ar = 0.f, ai = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const cf y = row[64 * k];
+        ar = fmaf(wc.c[k], y.x, ar); ai = fmaf(wc.c[k], y.y, ai);
+    }
     {
         const cf hv = sm.halo[hrow + rw];
-        const float a = on ? sl.chipf[jf - qa + kChips] : 0.f, b = on ? sl.chipf[jf - qb + kChips] : 0.f;
-        ar = fmaf(a, hv.x, ar); ai = fmaf(a, hv.y, ai);
-        br = fmaf(b, hv.x, br); bi = fmaf(b, hv.y, bi);
+        ar = fmaf(wc.ch, hv.x, ar); ai = fmaf(wc.ch, hv.y, ai);
     }
-    ar = wave_sum_last(ar); ai = wave_sum_last(ai); br = wave_sum_last(br); bi = wave_sum_last(bi);
-    if (lane == 63) {
-        sl.win[wave] = make_float2(ar, ai);
-        sl.win[wave + kSpecHalf] = make_float2(br, bi);
-    }
-    if (wave < 4) {   // a quarter of the prompt lag each: chips j = lane + 64*(4*wave + k); wavefront 0 adds the halo terms
-        const int rs = sN % K, qs = sN / K;
-        const cf* rowp = sm.xch + rs * kXchWave + lane + 256 * wave;
-        const float* cp = sl.chipf + (kChips - qs) + lane + 256 * wave;
+    ar = wave_sum_last(ar); ai = wave_sum_last(ai);
+    if (lane == 63) sl.win[wave] = make_float2(ar, ai);
+    if (wave >= 2 && wave < 6) {   // a quarter of the prompt lag each: chips j = lane + 64*(4*pq + k); quarter 0 adds the halo terms
+        const int pq = wave - 2;     // (wavefronts 0 and 1 prepare the loop updates meanwhile, 6 and 7 sum the sample energy)
+        const int ss = __builtin_amdgcn_readfirstlane(sN);
+        const int rs = ss % K, qs = ss / K;
+        if (qs != wc.qs) {
+            const float* cp = sl.chipf + (kChips - qs) + lane + 256 * pq;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wc.p[k] = cp[64 * k];
+            wc.ph = (on && pq == 0) ? sl.chipf[jf - qs + kChips] : 0.f;
+            wc.qs = qs;
+        }
+        const cf* rowp = sm.xch + rs * kXchWave + lane + 256 * pq;
         float pr = 0.f, pi = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const cf y = rowp[64 * k];
-            const float a = cp[64 * k];
-            pr = fmaf(a, y.x, pr); pi = fmaf(a, y.y, pi);
+            pr = fmaf(wc.p[k], y.x, pr); pi = fmaf(wc.p[k], y.y, pi);
         }
-        if (wave == 0) {
-            const cf hv = sm.halo[hrow + rs];
-            const float a = on ? sl.chipf[jf - qs + kChips] : 0.f;
-            pr = fmaf(a, hv.x, pr); pi = fmaf(a, hv.y, pi);
-        }
+        const cf hv = sm.halo[hrow + rs];
+        pr = fmaf(wc.ph, hv.x, pr); pi = fmaf(wc.ph, hv.y, pi);
         pr = wave_sum_last(pr); pi = wave_sum_last(pi);
-        if (lane == 63) sl.win[2 * kSpecHalf + wave] = make_float2(pr, pi);
+        if (lane == 63) sl.win[2 * kSpecHalf + pq] = make_float2(pr, pi);
     }
 }
 
@@ -1783,7 +1826,7 @@ __device__ __attribute__((noinline)) EplResult spec_transform_path(const Smem& s
 
 // MODE 0: throughput form (several workgroups per CU).  MODE 1: latency variant for at most one workgroup per CU
 // (see track_ms_fetched); needs kTablesBytes more LDS.  MODE 2: latency variant + speculation: the millisecond's
-// prompt correlation is evaluated only at the 16 lags around the code phase, directly from the staged rows; if the
+// prompt correlation is evaluated only at the 8 lags around the previous peak lag, directly from the staged rows; if the
 // window maximum is interior and dominates the sample energy (so that no lag outside the window can plausibly exceed
 // it) the loop filters advance on it at once and the full profile -- needed for the strength record, and to PROVE that
 // the window held the global arg-max -- is left to track_verify_kernel, which runs the transforms of all (channel, ms)
@@ -1847,6 +1890,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         sm.red->steps = carrier_steps<K>(st->doppler * p.inv_fs);
         sm.red->cc[0].nf = st->doppler; sm.red->cc[0].nphi = st->carrier_phase;
         sm.red->cc[0].rot1 = sm.red->steps.rot1;
+        sm.red->cc[0].step = carrier_from_cycles_fast(st->doppler * p.inv_fs * 4096.0);
         sm.red->cand_sel = 0; sm.red->rec_sel = 0;
     }
     __syncthreads();
@@ -1866,6 +1910,8 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         if (p.ms_begin < p.ms_end) stage_fetch_own<K>(stream + (int64_t)p.ms_begin * N, smp, launder(threadIdx.x));
     }
     // speculative mode: this thread's chip transitions (sample offset K*m, coefficient +-2), fixed for the whole launch
+    WinCache wcache;
+    wcache.q = -1; wcache.qs = -1;
     int el_off0 = -1, el_off1 = -1;
     float el_g0 = 0.f, el_g1 = 0.f;
     if constexpr (SPEC) {
@@ -1896,9 +1942,11 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         const double t0 = p.start_time[launder(ms)];
         double f, phi;
         CarrierSteps cs;
+        cf half_step = make_float2(1.f, 0.f);
         if constexpr (SPEC) {
-            const auto cc = sm.red->cc[sm.red->cand_sel];
-            f = cc.nf; phi = cc.nphi; cs.rot1 = cc.rot1; cs.rot_wrap = make_float2(1.f, 0.f);
+            const auto cand = sm.red->cc[sm.red->cand_sel];
+            f = cand.nf; phi = cand.nphi; cs.rot1 = cand.rot1; cs.rot_wrap = make_float2(1.f, 0.f);
+            half_step = cand.step;
         } else {
             f = sm.red->dstate[0]; phi = sm.red->dstate[1]; cs = sm.red->steps;
         }
@@ -1912,6 +1960,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
                 asm volatile("; MARK_STAGE_BEGIN");
                 GYP_STAMP(0);
                 // the boundary samples of the float64 early/late sums are requested first, consumed after the staging
+                if (wave == 0) fetch_leaving(st, sm.red, leave);
                 const ElSample el0 = el_fetch_const<K>(block, sN, el_off0, el_g0);
                 ElSample el1;
                 el1.nl = -1;
@@ -1924,7 +1973,13 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
                 cf* y_rows[K];
 #pragma unroll
                 for (int r = 0; r < K; ++r) y_rows[r] = sm.xch + r * kXchWave;
-                stage_emit_own<K>(smp, u0, du, cs, y_rows, sm.halo, tid);
+                {
+                    static_assert(OwnSamples<K>::CH == 2 && OwnSamples<K>::T * K == 4096, "second chip = first + 4096 samples");
+                    cf anchor[2];
+                    anchor[0] = carrier_from_cycles_fast(u0 + du * (double)(K * tid));
+                    anchor[1] = cmul(anchor[0], half_step);
+                    stage_emit_own_anchored<K>(smp, anchor, cs, y_rows, sm.halo, tid);
+                }
                 GYP_STAMP(2);
                 double acc[4] = {0.0, 0.0, 0.0, 0.0};
                 el_accumulate<K>(el0, u0, du, acc);
@@ -1936,25 +1991,28 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
                 GYP_STAMP(3);
                 lds_barrier();
                 GYP_STAMP(4);
-                if (wave == 0) fetch_leaving(st, sm.red, leave);
+                // wavefront 0: the ring entries leaving the lock windows were requested at the top of the millisecond and are
+                // consumed here, BEFORE the next millisecond's samples are requested -- the vector-memory counter retires
+                // in order, so a later wait for those three loads would also wait for the eight sample loads behind them
+                if (wave == 0) verdict_prepare(sm.red, leave, lane);
                 // the raw samples are consumed: request the next millisecond now, the loads fly under the window sums
                 if (ms + 1 < p.ms_end) stage_fetch_own<K>(stream + (int64_t)(ms + 1) * N, smp, launder(threadIdx.x));
                 if (prof) t_b = (long long)__builtin_readcyclecounter();
                 const int centre = sm.red->istate[2];
-                spec_window<K>(sm, sl, centre, sN, tid);
+                spec_window<K>(sm, sl, centre, sN, tid, wcache);
                 sum_partials64_spec(sl.part, sl.fin, tid);
-                if (wave >= 4) {   // the sample energy, a quarter per wavefront
-                    const float* src = sl.ein_part + 128 * (wave - 4) + lane;
-                    const float a = wave_sum_last(src[0] + src[64]);
-                    if (lane == 63) reinterpret_cast<float*>(sl.fin + 8)[wave - 4] = a;
+                if (wave >= 6) {   // the sample energy, half per wavefront
+                    const float* src = sl.ein_part + 256 * (wave - 6) + lane;
+                    const float a = wave_sum_last((src[0] + src[64]) + (src[128] + src[192]));
+                    if (lane == 63) reinterpret_cast<float*>(sl.fin + 8)[wave - 6] = a;
                 }
                 asm volatile("; MARK_WINDOW_END");
                 GYP_STAMP(5);
                 lds_barrier();
                 GYP_STAMP(6);
-                // every wavefront takes the same decision from the same 16 values; ties resolve like np.argmax on the
+                // every wavefront takes the same decision from the same 8 values; ties resolve like np.argmax on the
                 // profile of the PRN rolled by s (lowest rolled index)
-                const int wi = lane & 15;
+                const int wi = lane & (2 * kSpecHalf - 1);
                 int wlag = centre + wi - kSpecHalf;
                 wlag = wlag < 0 ? wlag + N : (wlag >= N ? wlag - N : wlag);
                 int wkey = wlag - sN;
@@ -1965,13 +2023,13 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
                 blag = blag >= N ? blag - N : blag;
                 int wbest = blag - centre + kSpecHalf;
                 wbest = wbest < 0 ? wbest + N : (wbest >= N ? wbest - N : wbest);
-                const float4 eq = *reinterpret_cast<const float4*>(sl.fin + 8);
-                const float energy = 4.0f * ((eq.x + eq.y) + (eq.z + eq.w));   // every 4th sample was summed
+                const float2 eq = *reinterpret_cast<const float2*>(sl.fin + 8);
+                const float energy = 4.0f * (eq.x + eq.y);   // every 4th sample was summed
                 const bool fast = wbest != 0 && wbest != 2 * kSpecHalf - 1 && b.v >= p.spec_kappa * energy;
                 if (prof) { t_c = (long long)__builtin_readcyclecounter(); tp[5] += fast ? 0 : 1; }
                 if (p.dbg && wave == 0 && lane < 20) {
                     float* o = p.dbg + ((int64_t)ch * p.n_ms + ms) * 20;
-                    o[lane] = lane < 16 ? fmaf(wv.x, wv.x, wv.y * wv.y) : (lane == 16 ? energy : (lane == 17 ? (float)sN : (lane == 18 ? (float)centre : 0.f)));
+                    o[lane] = lane < 2 * kSpecHalf ? fmaf(wv.x, wv.x, wv.y * wv.y) : (lane < 16 ? 0.f : lane == 16 ? energy : (lane == 17 ? (float)sN : (lane == 18 ? (float)centre : 0.f)));
                 }
                 m.disc = 0.0;
                 m.path_info = (fast ? 1 : 0) | (wbest << 8) | ((int)fminf(b.v * __builtin_amdgcn_rcpf(fmaxf(energy, 1e-30f)), 65535.f) << 16);
@@ -2023,7 +2081,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         GYP_STAMP(8);
         asm volatile("; MARK_UPDATE_BEGIN");
         if constexpr (SPEC) {
-            if (wave == 0) costas_verdict<K>(p, st, sm.red, t0, lane, m, leave, f, phi);
+            if (wave == 0) verdict_finish<K>(p, st, sm.red, t0, lane, m, f, phi);
             if (wave == 1) dll_update(sm.red, m.disc, lane);
             if (wave == 2) costas_candidate(p, sm.red, m.peak, f, phi, 3.0, 0, lane);
             if (wave == 3) costas_candidate(p, sm.red, m.peak, f, phi, 6.0, 1, lane);

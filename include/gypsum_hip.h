@@ -222,7 +222,7 @@ typedef struct gyp_track_rec {
     int8_t nudged;                /* circularity watchdog adjusted doppler/phase after this ms */
     /* How the millisecond was evaluated (diagnostic; the record's other fields do not depend on it):
      *   bits 0..1  0 = full transform profile; 1 = window maximum (speculative tracker), confirmed by the verify pass;
-     *   bits 8..15 window index of the maximum (lag code_phase - 8 + index), speculative tracker only;
+     *   bits 8..15 window index of the maximum (the window is the 8 lags around the previous peak), speculative tracker only;
      *   bits 16..31 min(65535, peak^2 / sample energy) the confidence test saw, speculative tracker only. */
     int32_t path_info;
 } gyp_track_rec;
@@ -377,8 +377,8 @@ int gyp_ingest_times(const gyp_ingest* ing, int64_t first_ms, int32_t n_ms, doub
  * transform path if taken, loop update). */
 int gyp_debug_track_profile(gyp_ctx* ctx, int enable, long long* out16);
 /* Debug (speculative block tracker, 8.184 Msps banks of at most one channel per CU): with GYP_SPEC_DEBUG set in the
- * environment the last gyp_track_block(_dev) call leaves, per (channel, ms), 20 floats: |c0|^2 at the 16 window lags
- * code_phase-8 .. code_phase+7, the sample-energy estimate, code_phase mod N, 0, 0.  bad_out (may be NULL): per
+ * environment the last gyp_track_block(_dev) call leaves, per (channel, ms), 20 floats: |c0|^2 at the 8 window lags
+ * (previous peak lag - 4 .. + 3), 8 zeros, the sample-energy estimate, code_phase mod N, the window centre, 0.  bad_out (may be NULL): per
  * channel, 1 if the verify pass sent the channel back through the transform kernel.  Synchronises the stream. */
 int gyp_debug_spec_read(gyp_bank* bank, float* out, int32_t n_floats, int32_t* bad_out);
 /* Debug: time `iters` forward+inverse wavefront transform pairs per wavefront, `wgs` workgroups of `waves_per_wg`
