@@ -44,6 +44,7 @@ BITS_STATE = np.dtype([("determined_bit_phase", "<i4"), ("previous_bit_phase_dec
                        ("emitted_bit_count", "<i8"), ("processed_pseudosymbol_count", "<i8"),
                        ("last_emitted_bits_len", "<i4"), ("last_emitted_bits", "i1", (52,))], align=True)
 GYP_BIT_ZERO, GYP_BIT_ONE, GYP_BIT_UNKNOWN = 0, 1, 2
+GYP_COMM_ID_BYTES = 128
 RECORD_SIZES = {"gyp_bit_event": 24, "gyp_bits_state": 112, "gyp_synth_sat": 32, "gyp_cell_desc": 24, "gyp_cell": 32, "gyp_acq_result": 32, "gyp_chan_in": 32, "gyp_chan_out": 80,
                 "gyp_track_rec": 56}
 
@@ -54,6 +55,7 @@ EXPORTS = (
     "gyp_correlate_grid gyp_acquire_dev "
     "gyp_acquire gyp_track_step_dev gyp_track_step gyp_bank_create gyp_bank_destroy gyp_bank_size gyp_bank_set_channel gyp_bank_drop_channel "
     "gyp_track_block_dev gyp_track_block gyp_bank_get_state gyp_synth_iq_dev gyp_synth_nav_bit gyp_bank_reset_dev gyp_debug_track_profile gyp_debug_fft_bench gyp_debug_spec_read "
+    "gyp_comm_unique_id gyp_comm_init gyp_comm_destroy gyp_comm_info gyp_allgather_dev gyp_host_alloc gyp_host_free gyp_widen_iq_dev "
     "gyp_bits_create gyp_bits_destroy gyp_bits_reset gyp_bits_push gyp_bits_push_block gyp_bits_drain gyp_bits_get_state "
     "gyp_ingest_open gyp_ingest_close gyp_ingest_total_ms gyp_ingest_set_scale gyp_ingest_seek gyp_ingest_next_host gyp_ingest_next_dev gyp_ingest_times"
 ).split()
@@ -117,6 +119,14 @@ def load() -> C.CDLL:
         "gyp_debug_track_profile": (C.c_int, [vp, C.c_int, vp]),
         "gyp_debug_fft_bench": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
         "gyp_debug_spec_read": (C.c_int, [vp, vp, i32, vp]),
+        "gyp_comm_unique_id": (C.c_int, [vp]),
+        "gyp_comm_init": (C.c_int, [vp, i32, i32, vp]),
+        "gyp_comm_destroy": (C.c_int, [vp]),
+        "gyp_comm_info": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+        "gyp_allgather_dev": (C.c_int, [vp, vp, vp, u64]),
+        "gyp_host_alloc": (C.c_int, [vp, u64, C.POINTER(vp)]),
+        "gyp_host_free": (C.c_int, [vp, vp]),
+        "gyp_widen_iq_dev": (C.c_int, [vp, i32, vp, u64, C.c_float, vp]),
         "gyp_synth_iq_dev": (C.c_int, [vp, vp, i32, i64, i32, vp, i32, C.c_float, u64]),
         "gyp_synth_nav_bit": (C.c_int, [u64, i32, i32, i32, i64]),
         "gyp_bits_create": (C.c_int, [i32, C.POINTER(vp)]),

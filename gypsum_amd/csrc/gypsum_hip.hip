@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <new>
 #include <string>
 #include <vector>
@@ -128,6 +129,9 @@ struct gyp_ctx {
     uint16_t* d_trans = nullptr; // [32][kMaxTrans]: chip transitions (float64 early/late boundary sums)
     int32_t* d_ntrans = nullptr; // [32]
     float* d_chipf = nullptr;    // [32][2048]: +-1.0f codes, twice over (window correlations of the speculative tracker)
+    // RCCL communicator (gyp_comm_init); the library is dlopen'ed on first use, libgypsum_hip does not link against it
+    void* comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
     bool no_spec = false;        // GYP_NO_SPEC=1: A/B switch back to the non-speculative latency kernel
     float spec_kappa = 20.0f;    // GYP_SPEC_KAPPA: confidence threshold of the speculative tracker
     long long* d_prof = nullptr; // debug: per-phase cycle counters of track_block workgroup 0
@@ -150,6 +154,44 @@ struct gyp_bank {
     hipStream_t verify_stream = nullptr;
     hipEvent_t ev_spec = nullptr, ev_verify = nullptr;
 };
+
+// RCCL, resolved at run time (see the multi-GPU section of the C ABI below)
+namespace {
+struct RcclId { char b[128]; };   // ncclUniqueId, passed by value
+struct RcclApi {
+    typedef RcclId Id;
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+RcclApi g_rccl;
+bool rccl_load() {
+    if (g_rccl.lib) return true;
+    const char* names[] = {"librccl.so", "librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // the copy already in the process, if any
+    for (const char* n : {"librccl.so.1", "librccl.so"}) if (!h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { g_rccl.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return false; }
+    g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(h, "ncclAllGather"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
+        g_rccl.err = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy";
+        return false;
+    }
+    g_rccl.lib = h;
+    return true;
+}
+std::string rccl_msg(const char* what, int rc) {
+    return std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error") + " (" + std::to_string(rc) + ")";
+}
+}  // namespace
 
 static int fail(gyp_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg;
@@ -227,6 +269,7 @@ void gyp_destroy(gyp_ctx* ctx) {
     if (ctx->d_ntrans) (void)hipFree(ctx->d_ntrans);
     if (ctx->d_chipf) (void)hipFree(ctx->d_chipf);
     if (ctx->d_prof) (void)hipFree(ctx->d_prof);
+    if (ctx->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->comm);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -959,6 +1002,88 @@ int gyp_track_block(gyp_bank* bank, const float* iq_host, int32_t n_streams, int
     return GYP_OK;
 }
 
+// ---------------------------------------------------------------- multi-GPU: one all-gather over RCCL ------
+// the only exchange of the path is one all-gather of fixed-size result records per batch.  RCCL is
+// resolved at run time (dlopen of the librccl the process already has, e.g. torch's, else the system one), so the
+// library loads -- and every single-GPU entry point works -- on hosts without it.
+
+int gyp_comm_unique_id(void* out_128_bytes) {
+    if (!out_128_bytes) return GYP_E_BAD_ARG;
+    if (!rccl_load()) return fail(nullptr, GYP_E_COMM, g_rccl.err);
+    const int rc = g_rccl.GetUniqueId(out_128_bytes);
+    if (rc != 0) return fail(nullptr, GYP_E_COMM, rccl_msg("ncclGetUniqueId", rc));
+    return GYP_OK;
+}
+
+int gyp_comm_init(gyp_ctx* ctx, int32_t rank, int32_t world, const void* unique_id_128_bytes) {
+    if (!ctx || world < 1 || rank < 0 || rank >= world) return ctx ? fail(ctx, GYP_E_BAD_ARG, "gyp_comm_init: bad rank / world") : GYP_E_BAD_ARG;
+    if (ctx->comm) return fail(ctx, GYP_E_BAD_ARG, "gyp_comm_init: the context already has a communicator");
+    if (!unique_id_128_bytes) {
+        if (world != 1) return fail(ctx, GYP_E_BAD_ARG, "gyp_comm_init: a unique id is required for world > 1");
+        ctx->comm_rank = 0; ctx->comm_world = 1;      // single process, no RCCL: gyp_allgather_dev is a device copy
+        return GYP_OK;
+    }
+    if (!rccl_load()) return fail(ctx, GYP_E_COMM, g_rccl.err);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RcclApi::Id id;
+    std::memcpy(id.b, unique_id_128_bytes, sizeof(id.b));
+    void* comm = nullptr;
+    const int rc = g_rccl.CommInitRank(&comm, world, id, rank);
+    if (rc != 0) return fail(ctx, GYP_E_COMM, rccl_msg("ncclCommInitRank", rc));
+    ctx->comm = comm; ctx->comm_rank = rank; ctx->comm_world = world;
+    return GYP_OK;
+}
+
+int gyp_comm_destroy(gyp_ctx* ctx) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    if (ctx->comm) {
+        (void)hipStreamSynchronize(ctx->stream);
+        const int rc = g_rccl.CommDestroy(ctx->comm);
+        ctx->comm = nullptr;
+        if (rc != 0) return fail(ctx, GYP_E_COMM, rccl_msg("ncclCommDestroy", rc));
+    }
+    ctx->comm_rank = 0; ctx->comm_world = 1;
+    return GYP_OK;
+}
+
+int gyp_comm_info(gyp_ctx* ctx, int32_t* rank, int32_t* world, int32_t* uses_rccl) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    if (rank) *rank = ctx->comm_rank;
+    if (world) *world = ctx->comm_world;
+    if (uses_rccl) *uses_rccl = ctx->comm ? 1 : 0;
+    return GYP_OK;
+}
+
+int gyp_allgather_dev(gyp_ctx* ctx, const void* send_dev, void* recv_dev, uint64_t bytes_per_rank) {
+    if (!ctx || (!send_dev && bytes_per_rank) || (!recv_dev && bytes_per_rank)) return ctx ? fail(ctx, GYP_E_BAD_ARG, "gyp_allgather_dev: bad argument") : GYP_E_BAD_ARG;
+    if (bytes_per_rank == 0) return GYP_OK;
+    if (!ctx->comm) {
+        if (ctx->comm_world != 1) return fail(ctx, GYP_E_COMM, "gyp_allgather_dev: no communicator");
+        if (send_dev != recv_dev)
+            HIP_TRY(ctx, hipMemcpyAsync(recv_dev, send_dev, bytes_per_rank, hipMemcpyDeviceToDevice, ctx->stream));
+        return GYP_OK;
+    }
+    // enqueued on the context's stream, behind the kernels that produce the records: no host synchronisation
+    const int rc = g_rccl.AllGather(send_dev, recv_dev, (size_t)bytes_per_rank, /* ncclInt8 */ 0, ctx->comm, ctx->stream);
+    if (rc != 0) return fail(ctx, GYP_E_COMM, rccl_msg("ncclAllGather", rc));
+    return GYP_OK;
+}
+
+// ---------------------------------------------------------------- host staging helpers -----------------------
+int gyp_host_alloc(gyp_ctx* ctx, uint64_t bytes, void** out) {
+    if (!ctx || !out) return GYP_E_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ctx, GYP_E_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    return GYP_OK;
+}
+
+int gyp_host_free(gyp_ctx* ctx, void* p) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    if (p) HIP_TRY(ctx, hipHostFree(p));
+    return GYP_OK;
+}
+
 int gyp_debug_spec_read(gyp_bank* bank, float* out, int32_t n_floats, int32_t* bad_out) {
     if (!bank) return GYP_E_BAD_ARG;
     gyp_ctx* ctx = bank->ctx;
@@ -1416,6 +1541,20 @@ int gyp_ingest_next_dev(gyp_ingest* g, const float** iq_dev_out, int64_t* first_
     *iq_dev_out = g->dev_iq[d];
     *first_ms_out = cur.first_ms;
     *n_ms_out = cur.n_ms;
+    return GYP_OK;
+}
+
+int gyp_widen_iq_dev(gyp_ctx* ctx, int32_t fmt, const void* raw_dev, uint64_t n_words, float scale, float* out_dev) {
+    if (!ctx || !raw_dev || !out_dev) return ctx ? fail(ctx, GYP_E_BAD_ARG, "gyp_widen_iq_dev: bad argument") : GYP_E_BAD_ARG;
+    if (n_words == 0) return GYP_OK;
+    const int grid = (int)std::min<uint64_t>((n_words / 16 + 255) / 256 + 1, (uint64_t)ctx->n_cus * 8);
+    switch (fmt) {
+        case GYP_FMT_I8: hipLaunchKernelGGL(ingest_widen_kernel<int8_t>, dim3(grid), dim3(256), 0, ctx->stream, (const int8_t*)raw_dev, out_dev, (size_t)n_words, scale); break;
+        case GYP_FMT_U8: hipLaunchKernelGGL(ingest_widen_kernel<uint8_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint8_t*)raw_dev, out_dev, (size_t)n_words, scale); break;
+        case GYP_FMT_I16: hipLaunchKernelGGL(ingest_widen_kernel<int16_t>, dim3(grid), dim3(256), 0, ctx->stream, (const int16_t*)raw_dev, out_dev, (size_t)n_words, scale); break;
+        default: return fail(ctx, GYP_E_BAD_ARG, "gyp_widen_iq_dev: fmt must be GYP_FMT_I8, GYP_FMT_U8 or GYP_FMT_I16");
+    }
+    HIP_TRY(ctx, hipGetLastError());
     return GYP_OK;
 }
 

@@ -106,6 +106,54 @@ class GypsumEngine:
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
 
+    def host_alloc(self, nbytes: int, dtype=np.uint8) -> np.ndarray:
+        """Page-locked host memory as a numpy array (freed with host_free)."""
+        p = C.c_void_p()
+        self._check(self.lib.gyp_host_alloc(self.ctx, int(nbytes), C.byref(p)))
+        buf = (C.c_char * int(nbytes)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=np.uint8).view(dtype)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr: np.ndarray) -> None:
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None:
+            self._check(self.lib.gyp_host_free(self.ctx, p))
+
+    def memcpy_h2d_async(self, dst_ptr: int, host: np.ndarray) -> None:
+        """Enqueue a host-to-device copy on the engine's stream (asynchronous for page-locked `host`)."""
+        self._check(self.lib.gyp_memcpy_h2d(self.ctx, C.c_void_p(dst_ptr), ptr(host), host.nbytes))
+
+    def widen_iq_dev(self, fmt: int, raw_ptr: int, n_words: int, out_ptr: int, scale: float = 1.0) -> None:
+        self._check(self.lib.gyp_widen_iq_dev(self.ctx, int(fmt), C.c_void_p(raw_ptr), int(n_words), float(scale), C.c_void_p(out_ptr)))
+
+    # ------------------------------------------------------------------ multi-GPU (gyp_comm_*)
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(_lib.GYP_COMM_ID_BYTES)
+        rc = self.lib.gyp_comm_unique_id(buf)
+        if rc != 0:
+            raise GypsumHipError(rc, (self.lib.gyp_last_error(None) or b"").decode())
+        return buf.raw
+
+    def comm_init(self, rank: int, world: int, unique_id: Optional[bytes]) -> None:
+        """One RCCL communicator per context (`unique_id` from rank 0's comm_unique_id(), 128 bytes); None with
+        world == 1 declares a single-process world without RCCL."""
+        uid = C.create_string_buffer(unique_id, _lib.GYP_COMM_ID_BYTES) if unique_id is not None else None
+        self._check(self.lib.gyp_comm_init(self.ctx, int(rank), int(world), uid))
+
+    def comm_destroy(self) -> None:
+        self._check(self.lib.gyp_comm_destroy(self.ctx))
+
+    def comm_info(self) -> Dict[str, int]:
+        r, w, u = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self.lib.gyp_comm_info(self.ctx, C.byref(r), C.byref(w), C.byref(u)))
+        return {"rank": r.value, "world": w.value, "uses_rccl": u.value}
+
+    def allgather_dev(self, send_ptr: int, recv_ptr: int, bytes_per_rank: int) -> None:
+        """ncclAllGather of opaque record bytes on the engine's stream (device copy in a single-process world)."""
+        self._check(self.lib.gyp_allgather_dev(self.ctx, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), int(bytes_per_rank)))
+
     def set_stream_format(self, samples_per_second: int, samples_per_prn_transmission: int) -> None:
         self._check(self.lib.gyp_set_stream_format(self.ctx, int(samples_per_second), int(samples_per_prn_transmission)))
         self.fs, self.n = int(samples_per_second), int(samples_per_prn_transmission)

@@ -38,7 +38,8 @@ enum {
     GYP_E_HIP = -4,
     GYP_E_NO_FORMAT = -5,   /* gyp_set_stream_format has not been called */
     GYP_E_NOMEM = -6,
-    GYP_E_IO = -7           /* file could not be opened / read */
+    GYP_E_IO = -7,          /* file could not be opened / read */
+    GYP_E_COMM = -8         /* RCCL missing or a collective failed */
 };
 
 /* utils.py:23-25 IntegrationType */
@@ -249,6 +250,32 @@ int gyp_bank_reset_dev(gyp_bank* bank, const gyp_chan_init* inits_dev);
 /* Read back the live estimates (GpsSatelliteTrackingParameters.current_*): n_chan entries each. */
 int gyp_bank_get_state(gyp_bank* bank, double* doppler_hz, double* carrier_phase, int32_t* code_phase,
                        int32_t* lost);
+
+/* ---------------------------------------------------------------- multi-GPU ----------------------------- */
+/* The path shards by stream, satellite or (satellite x Doppler) cell with no data-path exchange except ONE all-gather
+ * of fixed-size result records per batch (SURVEY.md 8 e; the reference itself is single-process).  One process per
+ * GPU; the communicator is RCCL's (librccl is dlopen'ed on first use -- the copy the process already holds, e.g.
+ * torch's, else the system one -- so nothing here is needed, or loaded, on a single GPU).
+ *   rank 0: gyp_comm_unique_id(id); every rank receives the 128 bytes by any out-of-band means (MPI, a file, a gloo
+ *   broadcast ...) and calls gyp_comm_init(ctx, rank, world, id) with its own context.
+ * gyp_comm_init(ctx, 0, 1, NULL) declares a single-process "world" without touching RCCL: gyp_allgather_dev is then a
+ * device copy.  With an id and world == 1 a real one-rank RCCL communicator is created. */
+#define GYP_COMM_ID_BYTES 128
+int gyp_comm_unique_id(void* out_128_bytes);
+int gyp_comm_init(gyp_ctx* ctx, int32_t rank, int32_t world, const void* unique_id_128_bytes);
+int gyp_comm_destroy(gyp_ctx* ctx);
+int gyp_comm_info(gyp_ctx* ctx, int32_t* rank, int32_t* world, int32_t* uses_rccl);
+/* recv_dev[r * bytes_per_rank ...] = rank r's send_dev, on every rank.  Enqueued on the context's stream behind the
+ * kernels that wrote send_dev (ncclAllGather over xGMI); no host synchronisation.  Records are opaque bytes. */
+int gyp_allgather_dev(gyp_ctx* ctx, const void* send_dev, void* recv_dev, uint64_t bytes_per_rank);
+
+/* ---------------------------------------------------------------- host staging ------------------------- */
+/* Page-locked host memory for callers that feed IQ from the host (asynchronous gyp_memcpy_h2d needs it). */
+int gyp_host_alloc(gyp_ctx* ctx, uint64_t bytes, void** out);
+int gyp_host_free(gyp_ctx* ctx, void* p);
+/* Integer recordings that crossed PCIe in file width: out_dev[i] = (float)raw_dev[i] * scale for n_words interleaved
+ * I,Q words of format GYP_FMT_I8 / GYP_FMT_U8 / GYP_FMT_I16 (see the ingest section), on the context's stream. */
+int gyp_widen_iq_dev(gyp_ctx* ctx, int32_t fmt, const void* raw_dev, uint64_t n_words, float scale, float* out_dev);
 
 /* ---------------------------------------------------------------- synthetic IQ (bench / test support) ---- */
 /* No recording ships with the reference (vendored_signals/ is git-ignored), so benchmarks run on synthetic

@@ -125,12 +125,12 @@ def make_acquisition(tag: str, fs: int, seed: int, sat_ids) -> None:
 
 
 def make_tracking(tag: str, fs: int, seed: int, n_ms: int, n_track: int, n_sats: int = 6,
-                  noise_sigma=None, doppler_offsets=()) -> None:
+                  noise_sigma=None, doppler_offsets=(), amplitude=None) -> None:
     """Reference acquisition on the first 10 ms, then the reference tracker from ms 9 on.
     `doppler_offsets[i]` (Hz) deliberately mis-initialises channel i to exercise the lock-loss paths."""
     n = fs // 1000
     scene = synth.random_scene(fs, n_ms, n_sats, seed, max_code_phase=(2046 if n > 2046 else None),
-                               noise_sigma=noise_sigma)
+                               noise_sigma=noise_sigma, amplitude=amplitude)
     iq = synth.render(scene)
     attrs = SampleProviderAttributes(samples_per_second=fs, samples_per_prn_transmission=n)
     sats = satellites_for(n)
@@ -218,7 +218,7 @@ def make_bits() -> None:
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["prn", "grid", "acq", "track", "lock", "long", "bits"]
+    what = sys.argv[1:] or ["prn", "grid", "acq", "track", "lock", "long", "long8184", "bits"]
     if "prn" in what:
         make_prn()
     if "grid" in what:
@@ -234,5 +234,12 @@ if __name__ == "__main__":
     if "long" in what:
         make_tracking("2046_long", 2_046_000, 20260930, 6600, 4, n_sats=4, noise_sigma=0.02,
                       doppler_offsets=(0, 0, 250, 40))
+    if "long8184" in what:
+        # the headline rate through lock acquisition, the 6-second watchdog and a forced lock loss (channel 2 starts
+        # 250 Hz off).  is_locked() compares ABSOLUTE variances (var(I*Q) < 900, var(I) < 2, tracker.py:170-186), and at
+        # a*N = 41 the cross-correlation of the other satellites alone keeps var(I*Q) near 1e4: the scene uses a*N = 20,
+        # three satellites and sigma = 0.004
+        make_tracking("8184_long", 8_184_000, 20260932, 6700, 3, n_sats=3, noise_sigma=0.004, amplitude=0.0025,
+                      doppler_offsets=(0, 0, 250))
     if "bits" in what:
         make_bits()

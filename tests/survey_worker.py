@@ -1,0 +1,79 @@
+"""Worker of tests/test_gpu_track_survey.py: one random scene through the float64 oracle tracker (CPU), in its own process.
+
+The oracle (oracle/gypsum_oracle.py) is the checker; the GPU side of the comparison runs in the parent process.  The
+rendered IQ travels to the parent through a file under /dev/shm (or the temp dir), the trajectories through the
+return value.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parents[1]
+if str(REPO) not in sys.path:
+    sys.path.insert(0, str(REPO))
+
+
+def scene_inits(scene, rng):
+    """Tracker seeds as an acquisition would hand them over: integer Doppler within a couple of Hz of the truth,
+    the true carrier phase perturbed a little, the exact code phase."""
+    out = []
+    for s in scene.sats:
+        out.append((int(s.sat_id), float(int(round(s.doppler_hz)) + int(rng.integers(-2, 3))),
+                    float(np.angle(np.exp(1j * (s.carrier_phase + rng.uniform(-0.2, 0.2))))), int(s.code_phase)))
+    return out
+
+
+def run_scene(args):
+    """args = (fs, n_ms, n_sats, seed, keep_iq_dir).  Returns (seed, iq_path, inits, traj) with traj[ch] an int64/float64
+    array of per-ms rows (pseudosymbol, code_phase_after, peak_offset, locked, doppler_after, lost_flag)."""
+    fs, n_ms, n_sats, seed, iq_dir = args
+    from gypsum_amd import synth
+    from oracle import gypsum_oracle as orc
+
+    n = fs // 1000
+    scene = synth.random_scene(fs, n_ms, n_sats, seed, max_code_phase=(2046 if n > 2046 else None))
+    iq = synth.render(scene)
+    rng = np.random.default_rng(seed ^ 0x5EED)
+    inits = scene_inits(scene, rng)
+    chips = orc.generate_ca_codes()
+    times = [orc.chunk_times(ms * n, n, fs) for ms in range(9, n_ms)]
+    traj = []
+    for sv, dop, phi, cp in inits:
+        trk = orc.Tracker(orc.TrackingState(dop, phi, cp), orc.prn_as_complex(chips[sv - 1], n), fs, n)
+        rows = np.zeros((len(times), 6), dtype=np.float64)
+        for j, (st, en) in enumerate(times):
+            ms = 9 + j
+            try:
+                r = trk.process_samples(iq[ms * n:(ms + 1) * n], st, en)
+            except orc.LostSatelliteLock:
+                rows[j:, 5] = 1.0
+                break
+            rows[j] = (r.pseudosymbol, r.code_phase_after, r.peak_offset, float(r.locked), r.doppler_after, 0.0)
+        traj.append(rows)
+    base = iq_dir or ("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir())
+    path = os.path.join(base, f"gyp_survey_{os.getpid()}_{seed}.npy")
+    np.save(path, iq)
+    return seed, path, inits, traj
+
+
+def run_acq_scene(args):
+    """args = (fs, seed).  The oracle's full 10-level acquisition (acquisition.py:70-152) of the scene's visible
+    satellites: [(sat_id, doppler_shift, prn_phase_shift)]."""
+    fs, seed = args
+    from gypsum_amd import synth
+    from oracle import gypsum_oracle as orc
+
+    n = fs // 1000
+    scene = synth.random_scene(fs, 10, 6, seed, with_nav_bits=False, max_code_phase=(2046 if n > 2046 else None))
+    iq = synth.render(scene)
+    chips = orc.generate_ca_codes()
+    out = []
+    for s in scene.sats:
+        r = orc.acquire_satellite(s.sat_id, iq, fs, n, orc.prn_as_complex(chips[s.sat_id - 1], n))
+        out.append((int(s.sat_id), int(r.doppler_shift), int(r.prn_phase_shift)))
+    return seed, out

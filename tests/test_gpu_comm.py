@@ -1,0 +1,65 @@
+"""The collective behind the C ABI (gyp_comm_* / gyp_allgather_dev) and the host staging helpers, on one GPU."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from gypsum_amd import _lib
+from gypsum_amd.engine import GypsumEngine
+
+pytestmark = pytest.mark.gpu
+
+
+def test_allgather_through_a_real_rccl_communicator_world_1():
+    """librccl is dlopen'ed, ncclCommInitRank builds a one-rank communicator and ncclAllGather runs on the context's
+    stream behind a kernel of this library (no host synchronisation in between)."""
+    eng = GypsumEngine(0)
+    eng.set_stream_format(2_046_000, 2046)
+    uid = eng.comm_unique_id()
+    assert len(uid) == _lib.GYP_COMM_ID_BYTES and any(uid)
+    eng.comm_init(0, 1, uid)
+    assert eng.comm_info() == {"rank": 0, "world": 1, "uses_rccl": 1}
+    rec = np.arange(4096, dtype=np.uint8)
+    send = eng.alloc(rec.nbytes).upload(rec)
+    recv = eng.alloc(rec.nbytes)
+    eng.allgather_dev(send.ptr.value, recv.ptr.value, rec.nbytes)
+    assert np.array_equal(recv.download(np.uint8, rec.size), rec)
+    with pytest.raises(_lib.GypsumHipError):
+        eng.comm_init(0, 1, uid)           # one communicator per context
+    eng.comm_destroy()
+    assert eng.comm_info()["uses_rccl"] == 0
+    eng.close()
+
+
+def test_single_process_world_needs_no_rccl():
+    eng = GypsumEngine(0)
+    eng.comm_init(0, 1, None)
+    rec = np.arange(100, dtype=np.uint8)
+    send = eng.alloc(100).upload(rec)
+    recv = eng.alloc(100)
+    eng.allgather_dev(send.ptr.value, recv.ptr.value, 100)
+    assert np.array_equal(recv.download(np.uint8, 100), rec)
+    with pytest.raises(_lib.GypsumHipError):
+        GypsumEngine(0).comm_init(1, 2, None)   # world > 1 needs the unique id
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype,fmt", [(np.int8, _lib.GYP_FMT_I8), (np.uint8, _lib.GYP_FMT_U8), (np.int16, _lib.GYP_FMT_I16)])
+def test_pinned_upload_and_widen(dtype, fmt):
+    """Integer IQ words cross PCIe in file width from page-locked memory and are widened on the device: the float32
+    samples equal words.astype(float32) * scale exactly."""
+    eng = GypsumEngine(0)
+    rng = np.random.default_rng(3)
+    n_words = 2 * 8184 * 5 + 6                      # not a multiple of the kernel's 16-byte vectors
+    info = np.iinfo(dtype)
+    words = rng.integers(info.min, info.max + 1, n_words).astype(dtype)
+    pinned = eng.host_alloc(words.nbytes, dtype)
+    pinned[:] = words
+    raw = eng.alloc(words.nbytes)
+    out = eng.alloc(n_words * 4)
+    eng.memcpy_h2d_async(raw.ptr.value, pinned)
+    eng.widen_iq_dev(fmt, raw.ptr.value, n_words, out.ptr.value, 0.25)
+    got = out.download(np.float32, n_words)
+    assert np.array_equal(got, words.astype(np.float32) * np.float32(0.25))
+    eng.host_free(pinned)
+    eng.close()

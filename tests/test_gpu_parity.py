@@ -311,3 +311,57 @@ def test_cross_level_strength_near_ties_resolve_like_float64(engine_factory, see
     assert (int(got["doppler_hz"]), int(got["code_phase"])) == (ref.doppler_shift, ref.prn_phase_shift)
     assert float(got["strength"]) == pytest.approx(ref.correlation_strength, rel=1e-9)      # decided on float64 profiles
     assert float(got["carrier_phase"]) == pytest.approx(ref.carrier_wave_phase_shift, abs=2e-4)
+
+
+def test_track_block_8184_long_lock_watchdog_and_loss(engine_factory):
+    """6.7 s at the headline rate against the reference's own trajectory (tests/golden/track_8184_long.npz): the
+    is_locked() bandwidth switch (tracker.py:157-203), the 6-second circularity watchdog (:370-387) and the forced
+    lock loss of the channel that starts 250 Hz off, block after block so that state carries over between launches
+    (the speculative tracker, its sub-blocks and its verify pass included)."""
+    z = gu.load("track_8184_long.npz")
+    fs, n = int(z["fs"]), int(z["n"])
+    eng = engine_factory(fs, n)
+    iq = gu.tracking_iq(z)
+    C = gu.COL
+    tracked = [int(s) for s in z["tracked"]]
+    n_ms = int(z["n_ms"])
+    inits = np.zeros(len(tracked), dtype=CHAN_INIT)
+    for i, sv in enumerate(tracked):
+        acq = z[f"acq_{sv}"]
+        inits[i] = (0, sv, acq[0], acq[1], int(acq[2]), 0)
+    bank = eng.create_bank(inits)
+    parts = []
+    for b0 in range(9, n_ms, 1500):
+        b1 = min(n_ms, b0 + 1500)
+        t0 = [gu.chunk_times(ms, n, fs)[0] for ms in range(b0, b1)]
+        parts.append(bank.track_block(iq[b0 * n:b1 * n], 1, b1 - b0, t0))
+    recs = np.concatenate(parts, axis=1)
+    state = bank.state()
+    saw_lock = False
+    for i, sv in enumerate(tracked):
+        ref = z[f"rec_{sv}"]
+        lost_at = int(z[f"lost_{sv}"])
+        got = recs[i, :len(ref)]
+        mag_ref = np.hypot(ref[:, C["peak_re"]], ref[:, C["peak_im"]])
+        rel = np.abs(np.hypot(got["peak_re"], got["peak_im"]) - mag_ref) / mag_ref
+        srel = np.abs(got["strength"] - ref[:, C["strength"]]) / ref[:, C["strength"]]
+        dopp_err = np.abs(got["doppler_hz"] - ref[:, C["doppler_after"]]).max()
+        print(f"[8184_long] sv{sv}: {len(ref)} ms, prompt rel err max {rel.max():.2e}, strength rel err max {srel.max():.2e}, "
+              f"doppler max err {dopp_err:.3e} Hz, locked ref {ref[:, C['locked_after']].mean():.3f} got {np.mean(got['locked']):.3f}, "
+              f"fast path {np.mean((got['path_info'] & 3) == 1):.3f}, lost at {lost_at}")
+        assert np.array_equal(got["peak_offset"], ref[:, C["peak_offset"]].astype(np.int64))
+        assert np.array_equal(got["pseudosymbol"], ref[:, C["pseudosymbol"]].astype(np.int64))
+        assert np.array_equal(got["code_phase"], ref[:, C["code_phase_after"]].astype(np.int64))
+        assert rel.max() < RTOL_MAG and srel.max() < RTOL_MAG
+        assert dopp_err < 1e-3
+        # locked_after is is_locked() after the millisecond's appends; the record carries the flag the Costas loop used
+        # (evaluated one append earlier), so the two series agree except around transitions
+        assert np.mean(got["locked"][1:].astype(bool) == (ref[:-1, C["locked_after"]] != 0)) > 0.99
+        saw_lock = saw_lock or bool(ref[:, C["locked_after"]].any())
+        if lost_at >= 0:
+            assert recs[i, lost_at - 9]["status"] == 1 and state["lost"][i] == 1
+            assert np.all(recs[i, lost_at - 9 + 1:]["status"] == 2)
+        else:
+            assert state["lost"][i] == 0
+    assert saw_lock, "the fixture is meant to reach lock"
+    bank.close()
