@@ -29,6 +29,7 @@ CHAN_OUT = np.dtype([("early_re", "<f4"), ("early_im", "<f4"), ("late_re", "<f4"
                      ("peak_re", "<f4"), ("peak_im", "<f4"), ("peak_mag", "<f4"), ("peak_offset", "<i4"),
                      ("sum", "<f8"), ("n_max", "<i4"), ("reserved", "<i4"),
                      ("early64_re", "<f8"), ("early64_im", "<f8"), ("late64_re", "<f8"), ("late64_im", "<f8")], align=True)
+BEST_BIN = np.dtype([("bin", "<i4"), ("argmax", "<i4"), ("peak", "<f4"), ("reserved", "<i4"), ("strength", "<f8")], align=True)
 CHAN_INIT = CHAN_IN
 TRACK_REC = np.dtype([("peak_re", "<f4"), ("peak_im", "<f4"), ("strength", "<f4"), ("discriminator", "<f4"),
                       ("doppler_hz", "<f8"), ("carrier_phase", "<f8"), ("error", "<f8"), ("code_phase", "<i4"),
@@ -45,7 +46,7 @@ BITS_STATE = np.dtype([("determined_bit_phase", "<i4"), ("previous_bit_phase_dec
                        ("last_emitted_bits_len", "<i4"), ("last_emitted_bits", "i1", (52,))], align=True)
 GYP_BIT_ZERO, GYP_BIT_ONE, GYP_BIT_UNKNOWN = 0, 1, 2
 GYP_COMM_ID_BYTES = 128
-RECORD_SIZES = {"gyp_bit_event": 24, "gyp_bits_state": 112, "gyp_synth_sat": 32, "gyp_cell_desc": 24, "gyp_cell": 32, "gyp_acq_result": 32, "gyp_chan_in": 32, "gyp_chan_out": 80,
+RECORD_SIZES = {"gyp_bit_event": 24, "gyp_bits_state": 112, "gyp_synth_sat": 32, "gyp_cell_desc": 24, "gyp_cell": 32, "gyp_acq_result": 32, "gyp_chan_in": 32, "gyp_chan_out": 80, "gyp_best_bin": 24,
                 "gyp_track_rec": 56}
 
 EXPORTS = (
@@ -55,7 +56,7 @@ EXPORTS = (
     "gyp_correlate_grid gyp_acquire_dev "
     "gyp_acquire gyp_track_step_dev gyp_track_step gyp_bank_create gyp_bank_destroy gyp_bank_size gyp_bank_set_channel gyp_bank_drop_channel "
     "gyp_track_block_dev gyp_track_block gyp_bank_get_state gyp_synth_iq_dev gyp_synth_nav_bit gyp_bank_reset_dev gyp_debug_track_profile gyp_debug_fft_bench gyp_debug_spec_read "
-    "gyp_comm_unique_id gyp_comm_init gyp_comm_destroy gyp_comm_info gyp_allgather_dev gyp_host_alloc gyp_host_free gyp_widen_iq_dev "
+    "gyp_grid_best_bins_dev gyp_comm_unique_id gyp_comm_init gyp_comm_destroy gyp_comm_info gyp_allgather_dev gyp_host_alloc gyp_host_free gyp_widen_iq_dev "
     "gyp_bits_create gyp_bits_destroy gyp_bits_reset gyp_bits_push gyp_bits_push_block gyp_bits_drain gyp_bits_get_state "
     "gyp_ingest_open gyp_ingest_close gyp_ingest_total_ms gyp_ingest_set_scale gyp_ingest_seek gyp_ingest_next_host gyp_ingest_next_dev gyp_ingest_times"
 ).split()
@@ -119,6 +120,7 @@ def load() -> C.CDLL:
         "gyp_debug_track_profile": (C.c_int, [vp, C.c_int, vp]),
         "gyp_debug_fft_bench": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
         "gyp_debug_spec_read": (C.c_int, [vp, vp, i32, vp]),
+        "gyp_grid_best_bins_dev": (C.c_int, [vp, vp, i32, i32, vp]),
         "gyp_comm_unique_id": (C.c_int, [vp]),
         "gyp_comm_init": (C.c_int, [vp, i32, i32, vp]),
         "gyp_comm_destroy": (C.c_int, [vp]),

@@ -469,9 +469,10 @@ __device__ __forceinline__ cf next_lane(cf v) {   // lane i <- lane i+1, lane 63
                        __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v.y), 0x130, 0xF, 0xF, false)));
 }
 // `anchor[c]`: the carrier at the first sample of the thread's c-th chip.
-template <int K>
+// `wiped(c, w)` sees chip c's K wiped samples before they are summed (the tracking kernels take boundary samples there).
+template <int K, typename Wiped>
 __device__ __forceinline__ void stage_emit_own_anchored(OwnSamples<K>& s, const cf (&anchor)[OwnSamples<K>::CH], const CarrierSteps& cs,
-                                                        cf* (&y_rows)[K], cf* __restrict__ halo, int tid) {
+                                                        cf* (&y_rows)[K], cf* __restrict__ halo, int tid, Wiped&& wiped) {
     const cf rot1 = cs.rot1;
     const int lane = tid & 63;
 #pragma unroll
@@ -484,6 +485,7 @@ __device__ __forceinline__ void stage_emit_own_anchored(OwnSamples<K>& s, const 
             w[i] = cmul(w[i], car);
             car = cmul(car, rot1);
         }
+        wiped(c, w);
         cf pre[K];   // pre[r] = P_r, pre[0] = 0
         pre[0] = make_float2(0.f, 0.f);
 #pragma unroll
@@ -502,13 +504,23 @@ __device__ __forceinline__ void stage_emit_own_anchored(OwnSamples<K>& s, const 
     }
 }
 template <int K>
+__device__ __forceinline__ void stage_emit_own_anchored(OwnSamples<K>& s, const cf (&anchor)[OwnSamples<K>::CH], const CarrierSteps& cs,
+                                                        cf* (&y_rows)[K], cf* __restrict__ halo, int tid) {
+    stage_emit_own_anchored<K>(s, anchor, cs, y_rows, halo, tid, [](int, const cf (&)[K]) {});
+}
+template <int K, typename Wiped>
 __device__ __forceinline__ void stage_emit_own(OwnSamples<K>& s, double u0, double du, const CarrierSteps& cs,
-                                               cf* (&y_rows)[K], cf* __restrict__ halo, int tid) {
+                                               cf* (&y_rows)[K], cf* __restrict__ halo, int tid, Wiped&& wiped) {
     cf anchor[OwnSamples<K>::CH];
 #pragma unroll
     for (int c = 0; c < OwnSamples<K>::CH; ++c)
         anchor[c] = carrier_from_cycles_fast(u0 + du * (double)(K * (tid + c * OwnSamples<K>::T)));
-    stage_emit_own_anchored<K>(s, anchor, cs, y_rows, halo, tid);
+    stage_emit_own_anchored<K>(s, anchor, cs, y_rows, halo, tid, wiped);
+}
+template <int K>
+__device__ __forceinline__ void stage_emit_own(OwnSamples<K>& s, double u0, double du, const CarrierSteps& cs,
+                                               cf* (&y_rows)[K], cf* __restrict__ halo, int tid) {
+    stage_emit_own<K>(s, u0, du, cs, y_rows, halo, tid, [](int, const cf (&)[K]) {});
 }
 // Row loader side: x[j] holds y[32*j + l] of branch `r`; chips 63 + 64*k (k = 0..14) take P_r of chip 64*(k+1),
 // chip 1022 takes P_r of chip 0 (the block is circular; the wipe-off of a wrapped sample is the one of its index).

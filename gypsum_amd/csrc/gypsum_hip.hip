@@ -659,6 +659,16 @@ int gyp_correlate_grid(gyp_ctx* ctx, const float* iq_host, int32_t n_streams, in
     return GYP_OK;
 }
 
+int gyp_grid_best_bins_dev(gyp_ctx* ctx, const gyp_cell* cells_dev, int32_t n_rows, int32_t n_bins, gyp_best_bin* out_dev) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    if (!ctx->k) return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
+    if (!cells_dev || !out_dev || n_rows < 0 || n_bins <= 0) return fail(ctx, GYP_E_BAD_ARG, "gyp_grid_best_bins_dev: bad argument");
+    if (n_rows == 0) return GYP_OK;
+    hipLaunchKernelGGL(grid_best_bin_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, ctx->stream, cells_dev, n_rows, n_bins, ctx->n, out_dev);
+    HIP_TRY(ctx, hipGetLastError());
+    return GYP_OK;
+}
+
 // ---------------------------------------------------------------- acquisition ----------------------------
 int gyp_acquire_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_t stream_stride_samples,
                     int32_t n_ms, const int32_t* sat_ids_host, int32_t n_sats, gyp_acq_result* out_dev) {

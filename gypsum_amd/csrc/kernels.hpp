@@ -29,7 +29,7 @@ constexpr int kLockWindow = 250;    // config.py:23
 constexpr int kPeakHistory = 1000;  // tracker.py:146 (deque maxlen)
 constexpr int kLockRefresh = 1024;  // exact two-pass recomputation of the sliding sums every this many ms
 constexpr int kTablesBytes = 1024 * 8;  // tw1024 (tw2048 stays in global memory / L1)
-constexpr int kRedBytes = 1024;
+constexpr int kRedBytes = 1536;
 // K = samples per chip.  A workgroup has W wavefronts, W = the largest divisor of K that is <= 8; K > 8 is processed in
 // R = K / W rounds of W polyphase branches (branch r = rho*W + wavefront).
 constexpr int largest_divisor_up_to_8(int k) {
@@ -80,6 +80,7 @@ struct RedScratch {
     WaveCand cand[16];
     float taps[6];      // early re/im, late re/im, probe re/im (the value at one more lag of the caller's choice)
     double eldelta[4];  // float64 boundary sums c0[s] - c0[s-1] and c0[s+1] - c0[s] (re, im each), see el_delta_partial
+    double elpart[8][4];// the same per wavefront, summed by epl_finish* after its barrier
     double dstate[4];   // new doppler, new carrier phase
     int istate[4];      // new code phase, lost flag
     CarrierSteps steps; // rotation constants of the next millisecond's wipe-off
@@ -140,10 +141,12 @@ __device__ __forceinline__ void transform_staged(const Smem& sm, const cf* __res
 }
 
 // One millisecond block, round rho: stage (all wavefronts) -> barrier -> per-wavefront correlation.
-template <int K>
+// Halo-free staging only: `wiped(c, w)` sees each chip's K wiped samples, `staged(tid)` runs once the rows are written
+// (the tracking kernels take their early/late boundary sums there); neither is called on the other staging paths.
+template <int K, typename Wiped, typename Staged>
 __device__ __forceinline__ void correlate_round(const cf* __restrict__ block, int rho, double u0, double du,
                                                 const CarrierSteps& cs, const Smem& sm,
-                                                const cf* __restrict__ rep_table_sat, cf (&c)[16]) {
+                                                const cf* __restrict__ rep_table_sat, cf (&c)[16], Wiped&& wiped, Staged&& staged) {
     constexpr int W = Geom<K>::W;
     const int tid = launder(threadIdx.x);
     cf* y_rows[W];
@@ -152,13 +155,20 @@ __device__ __forceinline__ void correlate_round(const cf* __restrict__ block, in
     if constexpr (kOwnStaging<K>) {
         OwnSamples<K> smp;
         stage_fetch_own<K>(block, smp, tid);
-        stage_emit_own<K>(smp, u0, du, cs, y_rows, sm.halo, tid);
+        stage_emit_own<K>(smp, u0, du, cs, y_rows, sm.halo, tid, wiped);
+        staged(tid);
         transform_staged<K, true>(sm, rep_table_sat, c, tid);
     } else {
         if (Geom<K>::R == 1) stage_ms<W>(block, u0, du, cs, y_rows, tid);
         else stage_general<K, W>(block, 1, rho, u0, 0.0, du, cs, y_rows, tid);
         transform_staged<K>(sm, rep_table_sat, c, tid);
     }
+}
+template <int K>
+__device__ __forceinline__ void correlate_round(const cf* __restrict__ block, int rho, double u0, double du,
+                                                const CarrierSteps& cs, const Smem& sm,
+                                                const cf* __restrict__ rep_table_sat, cf (&c)[16]) {
+    correlate_round<K>(block, rho, u0, du, cs, sm, rep_table_sat, c, [](int, const cf (&)[K]) {}, [](int) {});
 }
 
 // Coherent integration of n_blocks millisecond blocks, round rho, with ONE transform (pre-folded inputs).
@@ -861,189 +871,6 @@ __device__ __forceinline__ int mod_n(int v, int n) {
     return r < 0 ? r + n : r;
 }
 
-// E/P/L of one millisecond given the un-rolled correlation c0 (SURVEY F3):
-//   early = c0[(s-1) mod N], late = c0[(s+1) mod N], prompt profile[k] = c0[(s+k) mod N].
-struct EplResult {
-    cf early, late, peak, probe;
-    Best best;   // best.key = peak offset in the rolled profile, best.v = |peak|
-    double sum;
-    int n_max;
-};
-
-// One round's 16 lags per lane: publish the early / late taps if this lane owns them, feed the running profile
-// statistics (keys = index in the profile of the PRN rolled by s, so ties resolve like np.argmax on that profile).
-template <int K>
-__device__ __forceinline__ void epl_round(const cf (&c)[16], int rho, int s, int probe, LaneStats& ls, RedScratch* red,
-                                          float* profile_row, int tid) {
-    constexpr int N = K * kChips;
-    constexpr int W = Geom<K>::W;
-    const int ie = mod_n(s - 1, N), il = mod_n(s + 1, N);
-    float pw[16];   // squared magnitudes
-#pragma unroll
-    for (int j = 0; j < 16; ++j) pw[j] = fmaf(c[j].x, c[j].x, c[j].y * c[j].y);
-    // Lag index idx lives in round (idx % K) / W, wavefront (idx % K) % W, lane (q & 31) + 32*(q >> 9),
-    // slot (q >> 5) & 15 with q = idx / K: all wave-uniform.
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int idx = t == 0 ? ie : (t == 1 ? il : probe), q = idx / K, r = idx % K;
-        if (r / W == rho && (tid >> 6) == r % W && (tid & 63) == (q & 31) + 32 * (q >> 9)) {
-            const int slot = (q >> 5) & 15;
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (j == slot) { red->taps[2 * t] = c[j].x; red->taps[2 * t + 1] = c[j].y; }
-        }
-    }
-    if (profile_row) {
-        const int base = lag_base<K>(tid, rho);
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            if (slot_valid(j, tid)) { int k = base + 32 * K * j - s; profile_row[k < 0 ? k + N : k] = __builtin_amdgcn_sqrtf(pw[j]); }
-    }
-    lane_stats_update<K, true>(ls, pw, c, rho, tid, [s](int idx) { int k = idx - s; return k < 0 ? k + N : k; });
-}
-
-// Single-round (K <= 8) form of epl_round + epl_finish with the profile statistics taken per WAVEFRONT instead of per
-// lane: one vector pass for the lane maxima of |c|^2 and the lane sums of |c|, one DPP max, then a scalar walk
-// (v_readlane + SALU compares) over the lanes that hold the wavefront maximum -- normally exactly one -- for the
-// first-index key, the complex value there and the count of equal maxima.  Same results as the per-lane running
-// statistics (same float summation order, ties by lowest key), ~200 fewer VALU instructions per millisecond.
-template <int K>
-__device__ __forceinline__ void epl_round_wave(const cf (&c)[16], int s, int probe, RedScratch* red, float* profile_row, int tid) {
-    static_assert(Geom<K>::R == 1, "single round only");
-    constexpr int N = K * kChips;
-    constexpr int W = Geom<K>::W;
-    const int ie = mod_n(s - 1, N), il = mod_n(s + 1, N);
-    float pw[16];   // squared magnitudes
-#pragma unroll
-    for (int j = 0; j < 16; ++j) pw[j] = fmaf(c[j].x, c[j].x, c[j].y * c[j].y);
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int idx = t == 0 ? ie : (t == 1 ? il : probe), q = idx / K, r = idx % K;
-        if ((tid >> 6) == r % W && (tid & 63) == (q & 31) + 32 * (q >> 9)) {
-            const int slot = (q >> 5) & 15;
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (j == slot) { red->taps[2 * t] = c[j].x; red->taps[2 * t + 1] = c[j].y; }
-        }
-    }
-    if (profile_row) {
-        const int base = lag_base<K>(tid, 0);
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            if (slot_valid(j, tid)) { int k = base + 32 * K * j - s; profile_row[k < 0 ? k + N : k] = __builtin_amdgcn_sqrtf(pw[j]); }
-    }
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const WaveProfile wp = wave_profile(
-        pw, c, tid, [&](int j) { return __builtin_amdgcn_sqrtf(pw[j]); },
-        [&](int L, int j) {
-            int k = K * ((L & 31) + 512 * (L >> 5)) + wave + 32 * K * j - s;   // lag_base of lane L, round 0
-            return k < 0 ? k + N : k;
-        });
-    if ((tid & 63) == 0) {
-        WaveCand wc;
-        wc.v = wp.vmax; wc.key = wp.key; wc.re = wp.re; wc.im = wp.im; wc.sum = wp.sum; wc.cnt = wp.cnt; wc.pad = 0;
-        red->cand[wave] = wc;
-    }
-}
-template <int K>
-__device__ __forceinline__ EplResult epl_finish_wave(RedScratch* red) {
-    constexpr int W = Geom<K>::W;
-    __syncthreads();   // candidates and taps published
-    WaveCand g = red->cand[0];
-    double sum = g.sum;
-#pragma unroll
-    for (int w = 1; w < W; ++w) {
-        const WaveCand o = red->cand[w];
-        sum += o.sum;
-        if (o.v > g.v || (o.v == g.v && o.key < g.key)) g = o;
-    }
-    int n_max = 0;
-#pragma unroll
-    for (int w = 0; w < W; ++w) n_max += (red->cand[w].v == g.v) ? red->cand[w].cnt : 0;
-    EplResult r;
-    r.early = make_float2(red->taps[0], red->taps[1]);
-    r.late = make_float2(red->taps[2], red->taps[3]);
-    r.probe = make_float2(red->taps[4], red->taps[5]);
-    r.peak = make_float2(g.re, g.im);
-    r.best = Best{__builtin_amdgcn_sqrtf(g.v), g.key};
-    r.sum = sum;
-    r.n_max = n_max;
-    return r;
-}
-
-template <int K>
-__device__ __forceinline__ EplResult epl_finish(const LaneStats& ls, RedScratch* red, int tid) {
-    const ProfileStats st = lane_stats_finish<K, true>(ls, red, tid);   // its barrier also publishes the taps
-    EplResult r;
-    r.early = make_float2(red->taps[0], red->taps[1]);
-    r.late = make_float2(red->taps[2], red->taps[3]);
-    r.probe = make_float2(red->taps[4], red->taps[5]);
-    r.peak = st.peak;
-    r.best = st.best;
-    r.sum = st.sum;
-    r.n_max = st.n_max;
-    return r;
-}
-
-// One tracking millisecond of one channel: all rounds, then the reductions.
-// `probe`: one more lag (0 <= probe < N) whose complex value is returned in EplResult::probe.
-template <int K>
-__device__ __forceinline__ EplResult track_ms(const cf* __restrict__ block, double u0, double du, const CarrierSteps& cs,
-                                              int code_phase, int probe, const Smem& sm, const cf* __restrict__ rep, float* profile_row) {
-    constexpr int N = K * kChips;
-    const int s = mod_n(code_phase, N);
-    if constexpr (Geom<K>::R == 1) {
-        cf c[16];
-        correlate_round<K>(block, 0, u0, du, cs, sm, rep, c);
-        epl_round_wave<K>(c, s, probe, sm.red, profile_row, launder(threadIdx.x));
-        return epl_finish_wave<K>(sm.red);
-    }
-    LaneStats ls = lane_stats_init();
-#pragma unroll 1
-    for (int rho = 0; rho < Geom<K>::R; ++rho) {
-        cf c[16];
-        correlate_round<K>(block, rho, u0, du, cs, sm, rep, c);
-        epl_round<K>(c, rho, s, probe, ls, sm.red, profile_row, launder(threadIdx.x));
-        if (Geom<K>::R > 1) __syncthreads();   // tiles are re-staged by the next round
-    }
-    return epl_finish<K>(ls, sm.red, launder(threadIdx.x));
-}
-
-// Latency form of one tracking millisecond for lightly loaded chips (one workgroup per CU, 256 VGPRs): the samples
-// were requested one loop-filter update earlier (stage_fetch_own), the replica spectrum is resident in registers,
-// and sm.tw2048 points into LDS -- no global-load latency is left on the millisecond's critical path.
-template <int K>
-__device__ __forceinline__ EplResult track_ms_fetched(OwnSamples<K>& smp, double u0, double du, const CarrierSteps& cs,
-                                                      int code_phase, const Smem& sm, const cf (&prn)[32]) {
-    static_assert(kOwnStaging<K>, "halo-free staging only");
-    constexpr int N = K * kChips;
-    constexpr int W = Geom<K>::W;
-    const int s = mod_n(code_phase, N);
-    const int tid = launder(threadIdx.x);
-    const int wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
-    cf* y_rows[W];
-#pragma unroll
-    for (int r = 0; r < W; ++r) y_rows[r] = sm.xch + r * kXchWave;
-    stage_emit_own<K>(smp, u0, du, cs, y_rows, sm.halo, tid);
-    __syncthreads();
-    cf x[32];
-    const cf* yw = sm.xch + wave * kXchWave;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) x[j] = yw[32 * j + l];
-    halo_fixup<K>(x, sm.halo, wave, l);
-    wave_lds_fence();
-    float* tile_half = reinterpret_cast<float*>(sm.xch + wave * kXchWave) + h * kXchTile;
-    const LdsTables t{sm.tw1024, sm.tw2048};
-    cf c[16];
-    wave_fft_fwd(x, tile_half, t, l, h);
-#pragma unroll
-    for (int i = 0; i < 32; ++i) x[i] = cmul(x[i], prn[i]);
-    __builtin_amdgcn_sched_barrier(0);
-    wave_fft_inv(x, c, tile_half, t, l, h);
-    epl_round_wave<K>(c, s, s, sm.red, nullptr, tid);
-    return epl_finish_wave<K>(sm.red);
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // float64 early / late taps.  The reference's DLL (tracker.py:293-301) integrates (|E|^2 - |L|^2)/2 * 0.002 and
 // takes int() of the accumulator, so an error of ~1e-6 in the taps lands int(self.phase) on the other side of an
@@ -1158,22 +985,285 @@ __device__ __forceinline__ double dll_discriminator(double p_re, double p_im, co
     const double er = p_re - d[0], ei = p_im - d[1], lr = p_re + d[2], li = p_im + d[3];
     return ((er * er + ei * ei) - (lr * lr + li * li)) / 2.0;
 }
-// After a track_ms(): every wavefront is past the transforms, so the tile region is free to hold the partials.
-// Two workgroup barriers; red->eldelta[0..3] valid in every thread afterwards.
+// One wavefront's share of the boundary sums, left in red->elpart[wave] for epl_finish* to add up after its barrier
+// (no barrier of its own).  `job.trans == nullptr`: nothing to do (callers that only want the profile).
+struct ElJob {
+    const cf* block;
+    double u0, du;
+    int sN;
+    const uint16_t* trans;
+    int nt;
+    const float* chipf;   // this satellite's +-1 code, twice over (own-sample form)
+};
 template <int K>
-__device__ __forceinline__ void el_delta_workgroup(const cf* __restrict__ block, double u0, double du, int code_phase,
-                                                   const CodeTables& ct, int sat_index, const Smem& sm) {
-    constexpr int N = K * kChips;
-    constexpr int T = Geom<K>::kThreads;
-    const int tid = launder(threadIdx.x);
+__device__ __forceinline__ void el_wave_partials(const ElJob& job, RedScratch* red, int tid) {
+    if (!job.trans) return;
     double acc[4];
-    el_delta_partial<K>(block, u0, du, mod_n(code_phase, N), ct.trans + sat_index * kMaxTrans, ct.n_trans[sat_index], tid, acc);
-    double* part = reinterpret_cast<double*>(sm.xch);
+    el_delta_partial<K>(job.block, job.u0, job.du, job.sN, job.trans, job.nt, tid, acc);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) part[v * T + tid] = acc[v];
+    for (int v = 0; v < 4; ++v) acc[v] = wave_sum_last(acc[v]);
+    if ((tid & 63) == 63) {
+        double* o = red->elpart[tid >> 6];
+        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+    }
+}
+// The throughput kernel's form, from the WIPED float32 samples the halo-free staging forms anyway (chips j = tid + c*T,
+// K samples each): sample (s + K*m) of transition m is offset r = s mod K of chip j = (s / K + m) mod 1023, so the
+// thread that owns chip j applies the coefficient chip[j-q-1] - chip[j-q] (0 where the code does not change sign) to its
+// own sample r, and to its sample r-1 for the early side (r == 0: its sample K-1 with the next transition's
+// coefficient).  No gather from memory (two 8-byte loads per transition at a 64-byte stride cost the throughput kernel
+// as much as its transforms) and no second carrier: the ~512 float32 products carry ~1e-8 each, the sums are
+// accumulated in float64 -- the same accuracy class as the float32 prompt value they are combined with.
+template <int K>
+struct ElOwn {
+    int q, r, re;
+    const float* chipf;
+    double acc[4];
+    __device__ __forceinline__ void init(const ElJob& job) {
+        q = __builtin_amdgcn_readfirstlane(job.sN / K); r = __builtin_amdgcn_readfirstlane(job.sN % K);
+        re = r ? r - 1 : K - 1;
+        chipf = job.chipf;
+        acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
+    }
+    __device__ __forceinline__ void chip(int c, const cf (&w)[K], int tid) {
+        const int j = tid + c * OwnSamples<K>::T;
+        cf xl = w[0], xe = w[0];
+#pragma unroll
+        for (int o = 1; o < K; ++o) {        // r, re are wave-uniform: scalar selects
+            xl = o == r ? w[o] : xl;
+            xe = o == re ? w[o] : xe;
+        }
+        int m = j - q;
+        m = m < 0 ? m + kChips : m;          // (j - q) mod 1023, j < 1023 (the padding chip j == 1023 carries zeros)
+        const float* cp = chipf + m + kChips;
+        const float c0 = cp[-1], c1 = cp[0], c2 = cp[1];
+        const float gl = c0 - c1;                             // chip[m-1] - chip[m]
+        const float ge = r ? gl : c1 - c2;                    // r == 0: transition m + 1
+        acc[0] += (double)(ge * xe.x); acc[1] += (double)(ge * xe.y);     // +-2 * x: exact
+        acc[2] += (double)(gl * xl.x); acc[3] += (double)(gl * xl.y);
+    }
+    __device__ __forceinline__ void finish(RedScratch* red, int tid) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] = wave_sum_last(acc[v]);
+        if ((tid & 63) == 63) {
+            double* o = red->elpart[tid >> 6];
+            o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+        }
+    }
+};
+template <int K>
+__device__ __forceinline__ void el_collect(const RedScratch* red, double (&eld)[4]) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        double a = red->elpart[0][v];
+#pragma unroll
+        for (int w = 1; w < Geom<K>::W; ++w) a += red->elpart[w][v];
+        eld[v] = a;
+    }
+}
+
+// E/P/L of one millisecond given the un-rolled correlation c0 (SURVEY F3):
+//   early = c0[(s-1) mod N], late = c0[(s+1) mod N], prompt profile[k] = c0[(s+k) mod N].
+struct EplResult {
+    double eld[4];   // float64 boundary sums c0[s] - c0[s-1], c0[s+1] - c0[s] (el_wave_partials), if requested
+    cf early, late, peak, probe;
+    Best best;   // best.key = peak offset in the rolled profile, best.v = |peak|
+    double sum;
+    int n_max;
+};
+
+// One round's 16 lags per lane: publish the early / late taps if this lane owns them, feed the running profile
+// statistics (keys = index in the profile of the PRN rolled by s, so ties resolve like np.argmax on that profile).
+template <int K>
+__device__ __forceinline__ void epl_round(const cf (&c)[16], int rho, int s, int probe, LaneStats& ls, RedScratch* red,
+                                          float* profile_row, int tid) {
+    constexpr int N = K * kChips;
+    constexpr int W = Geom<K>::W;
+    const int ie = mod_n(s - 1, N), il = mod_n(s + 1, N);
+    float pw[16];   // squared magnitudes
+#pragma unroll
+    for (int j = 0; j < 16; ++j) pw[j] = fmaf(c[j].x, c[j].x, c[j].y * c[j].y);
+    // Lag index idx lives in round (idx % K) / W, wavefront (idx % K) % W, lane (q & 31) + 32*(q >> 9),
+    // slot (q >> 5) & 15 with q = idx / K: all wave-uniform.
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int idx = t == 0 ? ie : (t == 1 ? il : probe), q = idx / K, r = idx % K;
+        if (r / W == rho && (tid >> 6) == r % W && (tid & 63) == (q & 31) + 32 * (q >> 9)) {
+            const int slot = (q >> 5) & 15;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j == slot) { red->taps[2 * t] = c[j].x; red->taps[2 * t + 1] = c[j].y; }
+        }
+    }
+    if (profile_row) {
+        const int base = lag_base<K>(tid, rho);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (slot_valid(j, tid)) { int k = base + 32 * K * j - s; profile_row[k < 0 ? k + N : k] = __builtin_amdgcn_sqrtf(pw[j]); }
+    }
+    lane_stats_update<K, true>(ls, pw, c, rho, tid, [s](int idx) { int k = idx - s; return k < 0 ? k + N : k; });
+}
+
+// Single-round (K <= 8) form of epl_round + epl_finish with the profile statistics taken per WAVEFRONT instead of per
+// lane: one vector pass for the lane maxima of |c|^2 and the lane sums of |c|, one DPP max, then a scalar walk
+// (v_readlane + SALU compares) over the lanes that hold the wavefront maximum -- normally exactly one -- for the
+// first-index key, the complex value there and the count of equal maxima.  Same results as the per-lane running
+// statistics (same float summation order, ties by lowest key), ~200 fewer VALU instructions per millisecond.
+template <int K>
+__device__ __forceinline__ void epl_round_wave(const cf (&c)[16], int s, int probe, RedScratch* red, float* profile_row, int tid) {
+    static_assert(Geom<K>::R == 1, "single round only");
+    constexpr int N = K * kChips;
+    constexpr int W = Geom<K>::W;
+    const int ie = mod_n(s - 1, N), il = mod_n(s + 1, N);
+    float pw[16];   // squared magnitudes
+#pragma unroll
+    for (int j = 0; j < 16; ++j) pw[j] = fmaf(c[j].x, c[j].x, c[j].y * c[j].y);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int idx = t == 0 ? ie : (t == 1 ? il : probe), q = idx / K, r = idx % K;
+        if ((tid >> 6) == r % W && (tid & 63) == (q & 31) + 32 * (q >> 9)) {
+            const int slot = (q >> 5) & 15;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j == slot) { red->taps[2 * t] = c[j].x; red->taps[2 * t + 1] = c[j].y; }
+        }
+    }
+    if (profile_row) {
+        const int base = lag_base<K>(tid, 0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (slot_valid(j, tid)) { int k = base + 32 * K * j - s; profile_row[k < 0 ? k + N : k] = __builtin_amdgcn_sqrtf(pw[j]); }
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const WaveProfile wp = wave_profile(
+        pw, c, tid, [&](int j) { return __builtin_amdgcn_sqrtf(pw[j]); },
+        [&](int L, int j) {
+            int k = K * ((L & 31) + 512 * (L >> 5)) + wave + 32 * K * j - s;   // lag_base of lane L, round 0
+            return k < 0 ? k + N : k;
+        });
+    if ((tid & 63) == 0) {
+        WaveCand wc;
+        wc.v = wp.vmax; wc.key = wp.key; wc.re = wp.re; wc.im = wp.im; wc.sum = wp.sum; wc.cnt = wp.cnt; wc.pad = 0;
+        red->cand[wave] = wc;
+    }
+}
+template <int K>
+__device__ __forceinline__ EplResult epl_finish_wave(RedScratch* red) {
+    constexpr int W = Geom<K>::W;
+    __syncthreads();   // candidates and taps published
+    WaveCand g = red->cand[0];
+    double sum = g.sum;
+#pragma unroll
+    for (int w = 1; w < W; ++w) {
+        const WaveCand o = red->cand[w];
+        sum += o.sum;
+        if (o.v > g.v || (o.v == g.v && o.key < g.key)) g = o;
+    }
+    int n_max = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) n_max += (red->cand[w].v == g.v) ? red->cand[w].cnt : 0;
+    EplResult r;
+    r.early = make_float2(red->taps[0], red->taps[1]);
+    r.late = make_float2(red->taps[2], red->taps[3]);
+    r.probe = make_float2(red->taps[4], red->taps[5]);
+    el_collect<K>(red, r.eld);
+    r.peak = make_float2(g.re, g.im);
+    r.best = Best{__builtin_amdgcn_sqrtf(g.v), g.key};
+    r.sum = sum;
+    r.n_max = n_max;
+    return r;
+}
+
+template <int K>
+__device__ __forceinline__ EplResult epl_finish(const LaneStats& ls, RedScratch* red, int tid) {
+    const ProfileStats st = lane_stats_finish<K, true>(ls, red, tid);   // its barrier also publishes the taps
+    EplResult r;
+    r.early = make_float2(red->taps[0], red->taps[1]);
+    r.late = make_float2(red->taps[2], red->taps[3]);
+    r.probe = make_float2(red->taps[4], red->taps[5]);
+    el_collect<K>(red, r.eld);
+    r.peak = st.peak;
+    r.best = st.best;
+    r.sum = st.sum;
+    r.n_max = st.n_max;
+    return r;
+}
+
+// One tracking millisecond of one channel: all rounds, then the reductions.
+// `probe`: one more lag (0 <= probe < N) whose complex value is returned in EplResult::probe.
+// WANT_EL: also form the float64 early/late boundary sums (EplResult::eld) -- from the staging's own wiped samples
+// where the halo-free staging is used (chipf), by gathering the transition samples otherwise (trans / nt).
+template <int K, bool WANT_EL = false>
+__device__ __forceinline__ EplResult track_ms(const cf* __restrict__ block, double u0, double du, const CarrierSteps& cs,
+                                              int code_phase, int probe, const Smem& sm, const cf* __restrict__ rep, float* profile_row,
+                                              const uint16_t* trans = nullptr, int nt = 0, const float* chipf = nullptr) {
+    constexpr int N = K * kChips;
+    const int s = mod_n(code_phase, N);
+    const ElJob job{block, u0, du, s, trans, nt, chipf};
+    if constexpr (Geom<K>::R == 1) {
+        cf c[16];
+        if constexpr (kOwnStaging<K> && WANT_EL) {
+            // the boundary sums come from the samples the staging holds anyway (reduced per wavefront at once: nothing
+            // stays live across the transforms)
+            ElOwn<K> el;
+            el.init(job);
+            const int tid0 = launder(threadIdx.x);
+            correlate_round<K>(block, 0, u0, du, cs, sm, rep, c, [&](int ci, const cf (&w)[K]) { el.chip(ci, w, tid0); },
+                               [&](int tid) { el.finish(sm.red, tid); });
+            epl_round_wave<K>(c, s, probe, sm.red, profile_row, launder(threadIdx.x));
+        } else {
+            correlate_round<K>(block, 0, u0, du, cs, sm, rep, c);
+            epl_round_wave<K>(c, s, probe, sm.red, profile_row, launder(threadIdx.x));
+            if constexpr (WANT_EL) el_wave_partials<K>(job, sm.red, launder(threadIdx.x));
+        }
+        return epl_finish_wave<K>(sm.red);
+    }
+    LaneStats ls = lane_stats_init();
+#pragma unroll 1
+    for (int rho = 0; rho < Geom<K>::R; ++rho) {
+        cf c[16];
+        correlate_round<K>(block, rho, u0, du, cs, sm, rep, c);
+        epl_round<K>(c, rho, s, probe, ls, sm.red, profile_row, launder(threadIdx.x));
+        if (Geom<K>::R > 1) __syncthreads();   // tiles are re-staged by the next round
+    }
+    if constexpr (WANT_EL) el_wave_partials<K>(job, sm.red, launder(threadIdx.x));
+    return epl_finish<K>(ls, sm.red, launder(threadIdx.x));
+}
+
+// Latency form of one tracking millisecond for lightly loaded chips (one workgroup per CU, 256 VGPRs): the samples
+// were requested one loop-filter update earlier (stage_fetch_own), the replica spectrum is resident in registers,
+// and sm.tw2048 points into LDS -- no global-load latency is left on the millisecond's critical path.
+template <int K>
+__device__ __forceinline__ EplResult track_ms_fetched(OwnSamples<K>& smp, double u0, double du, const CarrierSteps& cs,
+                                                      int code_phase, const Smem& sm, const cf (&prn)[32], const ElJob& job) {
+    static_assert(kOwnStaging<K>, "halo-free staging only");
+    constexpr int N = K * kChips;
+    constexpr int W = Geom<K>::W;
+    const int s = mod_n(code_phase, N);
+    const int tid = launder(threadIdx.x);
+    const int wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
+    cf* y_rows[W];
+#pragma unroll
+    for (int r = 0; r < W; ++r) y_rows[r] = sm.xch + r * kXchWave;
+    stage_emit_own<K>(smp, u0, du, cs, y_rows, sm.halo, tid);
     __syncthreads();
-    sum_partials64<K, 4>(part, sm.red->eldelta, 0, tid);
-    __syncthreads();
+    cf x[32];
+    const cf* yw = sm.xch + wave * kXchWave;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) x[j] = yw[32 * j + l];
+    halo_fixup<K>(x, sm.halo, wave, l);
+    wave_lds_fence();
+    float* tile_half = reinterpret_cast<float*>(sm.xch + wave * kXchWave) + h * kXchTile;
+    const LdsTables t{sm.tw1024, sm.tw2048};
+    cf c[16];
+    wave_fft_fwd(x, tile_half, t, l, h);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) x[i] = cmul(x[i], prn[i]);
+    __builtin_amdgcn_sched_barrier(0);
+    wave_fft_inv(x, c, tile_half, t, l, h);
+    epl_round_wave<K>(c, s, s, sm.red, nullptr, tid);
+    el_wave_partials<K>(job, sm.red, tid);
+    return epl_finish_wave<K>(sm.red);
 }
 
 template <int K>
@@ -1190,14 +1280,14 @@ __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void 
         const double du = in.doppler_hz * p.inv_fs;
         const double u0 = in.doppler_hz * p.start_time[in.stream] + in.carrier_phase * 0.15915494309189533577;
         const cf* block = p.iq + (int64_t)in.stream * p.stream_stride;
-        const EplResult r = track_ms<K>(block, u0, du, carrier_steps<K>(du), in.code_phase, mod_n(in.code_phase, N),
-                                        sm, rep, p.profile_out ? p.profile_out + (int64_t)ch * N : nullptr);
-        el_delta_workgroup<K>(block, u0, du, in.code_phase, CodeTables{p.trans, p.n_trans, p.chipf}, in.sat_id - 1, sm);
+        const EplResult r = track_ms<K, true>(block, u0, du, carrier_steps<K>(du), in.code_phase, mod_n(in.code_phase, N),
+                                        sm, rep, p.profile_out ? p.profile_out + (int64_t)ch * N : nullptr,
+                                        p.trans + (in.sat_id - 1) * kMaxTrans, p.n_trans[in.sat_id - 1], p.chipf + (in.sat_id - 1) * 2048);
         if (threadIdx.x == 0) {
             gyp_chan_out o;
             o.early_re = r.early.x; o.early_im = r.early.y;
             o.late_re = r.late.x; o.late_im = r.late.y;
-            const double* d = sm.red->eldelta;
+            const double* d = r.eld;
             o.early64_re = (double)r.probe.x - d[0]; o.early64_im = (double)r.probe.y - d[1];
             o.late64_re = (double)r.probe.x + d[2]; o.late64_im = (double)r.probe.y + d[3];
             o.peak_re = r.peak.x; o.peak_im = r.peak.y;
@@ -2063,18 +2153,18 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
             } else {
                 EplResult r;
                 if constexpr (MODE == 1) {
-                    r = track_ms_fetched<K>(smp, u0, du, cs, code_phase, sm, prn);
+                    r = track_ms_fetched<K>(smp, u0, du, cs, code_phase, sm, prn, ElJob{block, u0, du, mod_n(code_phase, N), trans, nt, nullptr});
                     // request the next millisecond now: the loads fly while the boundary sums and the loop filters run
                     if (ms + 1 < p.ms_end) stage_fetch_own<K>(stream + (int64_t)(ms + 1) * N, smp, launder(threadIdx.x));
                 } else {
-                    r = track_ms<K>(block, u0, du, cs, code_phase, mod_n(code_phase, N), sm, rep, nullptr);
+                    r = track_ms<K, true>(block, u0, du, cs, code_phase, mod_n(code_phase, N), sm, rep, nullptr, trans, nt,
+                                          p.codes.chipf + sat_index * 2048);
                 }
                 if (prof) t_b = (long long)__builtin_readcyclecounter();
-                el_delta_workgroup<K>(block, u0, du, code_phase, p.codes, sat_index, sm);
                 m.peak = r.peak; m.peak_mag = r.best.v; m.key = r.best.key; m.sum = r.sum; m.n_max = r.n_max;
                 m.strength_pending = false;
                 m.path_info = 0;
-                m.disc = dll_discriminator((double)r.probe.x, (double)r.probe.y, sm.red->eldelta);
+                m.disc = dll_discriminator((double)r.probe.x, (double)r.probe.y, r.eld);
                 if (prof) t_c = (long long)__builtin_readcyclecounter();
             }
         }
@@ -2184,6 +2274,24 @@ __global__ void bank_reset_kernel(ChanState* states, const gyp_chan_init* inits,
     s->code_phase = in.code_phase;
     s->lost = 0;
     s->sums = LockSums{};
+}
+
+// acquisition.py:180-189 on a flat grid's records: per (stream, satellite) the FIRST bin holding the largest profile
+// maximum, with that profile's arg-max and strength (utils.py:111-116, float64 from the reduced record).
+__global__ void grid_best_bin_kernel(const gyp_cell* __restrict__ cells, int n_rows, int n_bins, int n_per_ms, gyp_best_bin* out) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    const gyp_cell* c = cells + (int64_t)row * n_bins;
+    int best = 0;
+    float pk = c[0].peak;
+    for (int b = 1; b < n_bins; ++b)
+        if (c[b].peak > pk) { pk = c[b].peak; best = b; }
+    const gyp_cell w = c[best];
+    gyp_best_bin o;
+    o.bin = best; o.argmax = w.argmax; o.peak = w.peak; o.reserved = 0;
+    const double p = (double)w.peak;
+    o.strength = p / ((w.sum - (double)w.n_max * p) / (double)(n_per_ms - w.n_max));
+    out[row] = o;
 }
 
 // ---------------------------------------------------------------------------------------------------------

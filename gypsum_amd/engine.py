@@ -194,6 +194,10 @@ class GypsumEngine:
         self._check(self.lib.gyp_correlate_grid_dev(self.ctx, C.c_void_p(iq_ptr), n_streams, stream_stride, n_ms, ptr(ids),
                                                      len(ids), ptr(bins), len(bins), integration, C.c_void_p(out_ptr)))
 
+    def grid_best_bins_dev(self, cells_ptr: int, n_rows: int, n_bins: int, out_ptr: int) -> None:
+        """acquisition.py:180-189 per (stream, satellite) row of a flat grid's records, on the device (BEST_BIN records)."""
+        self._check(self.lib.gyp_grid_best_bins_dev(self.ctx, C.c_void_p(cells_ptr), int(n_rows), int(n_bins), C.c_void_p(out_ptr)))
+
     def cell_strength(self, cells: np.ndarray) -> np.ndarray:
         """utils.py:111-116 on the reduced record, float64."""
         pk = cells["peak"].astype(np.float64)

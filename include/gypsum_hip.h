@@ -132,6 +132,18 @@ int gyp_correlate_grid(gyp_ctx* ctx, const float* iq_host, int32_t n_streams, in
                        const int32_t* sat_ids_host, int32_t n_sats, const double* doppler_hz_host, int32_t n_bins,
                        int32_t integration, gyp_cell* out_host);
 
+/* acquisition.py:180-189 get_best_doppler_shift_estimation's selection over the records of a flat grid: for each of
+ * the n_rows = n_streams x n_sats rows of n_bins records (the layout gyp_correlate_grid writes) the first bin holding
+ * the largest profile maximum.  This 24-byte record per (stream, satellite) is what a multi-GPU search exchanges. */
+typedef struct gyp_best_bin {
+    int32_t bin;         /* index into the grid's Doppler bins */
+    int32_t argmax;      /* sample_offset_of_correlation_peak */
+    float peak;
+    int32_t reserved;
+    double strength;     /* correlation_strength of that bin's profile */
+} gyp_best_bin;
+int gyp_grid_best_bins_dev(gyp_ctx* ctx, const gyp_cell* cells_dev, int32_t n_rows, int32_t n_bins, gyp_best_bin* out_dev);
+
 /* ---------------------------------------------------------------- acquisition ------------------------- */
 /* acquisition.py:35-41 SatelliteAcquisitionAttemptResult */
 typedef struct gyp_acq_result {

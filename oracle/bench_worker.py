@@ -1,7 +1,8 @@
 """One worker of bench.py's all-cores CPU baseline (TEST/BENCH INFRASTRUCTURE ONLY, like the rest of oracle/).
 
 Each process renders the same bounded synthetic scene, runs the reference algorithm (numpy oracle) for ONE satellite:
-a full 10-level acquisition and a run of tracker milliseconds, and returns its own timings.  The reference is
+a full 10-level acquisition and a run of tracker milliseconds, and returns its own timings and the fraction of its last
+pseudosymbols that match the scene's data bits.  The reference is
 single-threaded; sharding by satellite over processes is how its path would use a whole host.
 """
 from __future__ import annotations
@@ -29,14 +30,20 @@ def run(args):
     a = orc.acquire_satellite(s.sat_id, iq[:10 * n], fs, n, prn)
     t_acq = time.perf_counter() - t0
     trk = orc.Tracker(orc.TrackingState(a.doppler_shift, a.carrier_wave_phase_shift, a.prn_phase_shift), prn, fs, n)
+    symbols = []
     t0 = time.perf_counter()
     for ms in range(9, 9 + n_track_ms):
         st, en = orc.chunk_times(ms * n, n, fs)
-        trk.process_samples(iq[ms * n:(ms + 1) * n], st, en)
+        symbols.append(trk.process_samples(iq[ms * n:(ms + 1) * n], st, en).pseudosymbol)
     t_trk = (time.perf_counter() - t0) / n_track_ms
-    return t_acq, t_trk
+    # how the float64 algorithm itself demodulates this channel: its last (up to) 200 pseudosymbols against the data
+    # bits the scene carries, up to the Costas loop's sign ambiguity
+    tail = min(200, n_track_ms)
+    truth = [synth.nav_symbol_at(s, ms) for ms in range(9 + n_track_ms - tail, 9 + n_track_ms)]
+    same = sum(int(a_ == b_) for a_, b_ in zip(symbols[-tail:], truth)) / tail
+    return t_acq, t_trk, max(same, 1.0 - same)
 
 
-if __name__ == "__main__":   # python oracle/bench_worker.py fs n sat_index n_track_ms  ->  "t_acq t_trk"
-    t_acq, t_trk = run(tuple(int(v) for v in sys.argv[1:5]))
-    print(f"{t_acq!r} {t_trk!r}")
+if __name__ == "__main__":   # python oracle/bench_worker.py fs n sat_index n_track_ms  ->  "t_acq t_trk demodulated_fraction"
+    t_acq, t_trk, ok = run(tuple(int(v) for v in sys.argv[1:5]))
+    print(f"{t_acq!r} {t_trk!r} {ok!r}")
