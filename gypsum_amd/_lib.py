@@ -31,6 +31,11 @@ CHAN_OUT = np.dtype([("early_re", "<f4"), ("early_im", "<f4"), ("late_re", "<f4"
                      ("early64_re", "<f8"), ("early64_im", "<f8"), ("late64_re", "<f8"), ("late64_im", "<f8")], align=True)
 BEST_BIN = np.dtype([("bin", "<i4"), ("argmax", "<i4"), ("peak", "<f4"), ("reserved", "<i4"), ("strength", "<f8")], align=True)
 CHAN_INIT = CHAN_IN
+PARAMS = np.dtype([(k, "<f8") for k in (
+    "acq_initial_spread_hz", "acq_min_spread_hz", "acq_bins_per_spread", "dll_gain", "dll_phase_modulus",
+    "pll_bandwidth_locked_hz", "pll_bandwidth_unlocked_hz", "lock_error_variance_max", "lock_i_variance_max",
+    "lock_rotation_max_deg", "watchdog_period_s", "watchdog_drop_below", "watchdog_nudge_below", "watchdog_nudge_hz",
+    "spec_confidence_kappa")], align=True)
 TRACK_REC = np.dtype([("peak_re", "<f4"), ("peak_im", "<f4"), ("strength", "<f4"), ("discriminator", "<f4"),
                       ("doppler_hz", "<f8"), ("carrier_phase", "<f8"), ("error", "<f8"), ("code_phase", "<i4"),
                       ("peak_offset", "<i4"), ("pseudosymbol", "i1"), ("locked", "i1"), ("status", "i1"),
@@ -46,14 +51,14 @@ BITS_STATE = np.dtype([("determined_bit_phase", "<i4"), ("previous_bit_phase_dec
                        ("last_emitted_bits_len", "<i4"), ("last_emitted_bits", "i1", (52,))], align=True)
 GYP_BIT_ZERO, GYP_BIT_ONE, GYP_BIT_UNKNOWN = 0, 1, 2
 GYP_COMM_ID_BYTES = 128
-RECORD_SIZES = {"gyp_bit_event": 24, "gyp_bits_state": 112, "gyp_synth_sat": 32, "gyp_cell_desc": 24, "gyp_cell": 32, "gyp_acq_result": 32, "gyp_chan_in": 32, "gyp_chan_out": 80, "gyp_best_bin": 24,
+RECORD_SIZES = {"gyp_bit_event": 24, "gyp_bits_state": 112, "gyp_synth_sat": 32, "gyp_cell_desc": 24, "gyp_cell": 32, "gyp_acq_result": 32, "gyp_chan_in": 32, "gyp_chan_out": 80, "gyp_best_bin": 24, "gyp_params": 120,
                 "gyp_track_rec": 56}
 
 EXPORTS = (
     "gyp_version gyp_create gyp_destroy gyp_last_error gyp_device_name gyp_set_stream gyp_sync gyp_timer_start "
     "gyp_timer_stop gyp_set_stream_format gyp_prn_chips gyp_prn_spectrum_lane_layout gyp_malloc gyp_free "
     "gyp_memcpy_h2d gyp_memcpy_d2h gyp_cell_strength gyp_correlate_cells_dev gyp_correlate_cells gyp_correlate_grid_dev "
-    "gyp_correlate_grid gyp_acquire_dev "
+    "gyp_correlate_grid gyp_acquire_dev gyp_params_default gyp_set_params gyp_get_params gyp_search_level_dev gyp_search_level "
     "gyp_acquire gyp_track_step_dev gyp_track_step gyp_bank_create gyp_bank_destroy gyp_bank_size gyp_bank_set_channel gyp_bank_drop_channel "
     "gyp_track_block_dev gyp_track_block gyp_bank_get_state gyp_synth_iq_dev gyp_synth_nav_bit gyp_bank_reset_dev gyp_debug_track_profile gyp_debug_fft_bench gyp_debug_spec_read "
     "gyp_grid_best_bins_dev gyp_comm_unique_id gyp_comm_init gyp_comm_destroy gyp_comm_info gyp_allgather_dev gyp_host_alloc gyp_host_free gyp_widen_iq_dev "
@@ -106,6 +111,11 @@ def load() -> C.CDLL:
         "gyp_correlate_grid": (C.c_int, [vp, vp, i32, i32, vp, i32, vp, i32, i32, vp]),
         "gyp_acquire_dev": (C.c_int, [vp, vp, i32, i64, i32, vp, i32, vp]),
         "gyp_acquire": (C.c_int, [vp, vp, i32, i32, vp, i32, vp]),
+        "gyp_search_level_dev": (C.c_int, [vp, vp, i32, i64, i32, vp, i32, dbl, dbl, vp]),
+        "gyp_search_level": (C.c_int, [vp, vp, i32, i32, vp, i32, dbl, dbl, vp]),
+        "gyp_params_default": (None, [vp]),
+        "gyp_set_params": (C.c_int, [vp, vp]),
+        "gyp_get_params": (C.c_int, [vp, vp]),
         "gyp_track_step_dev": (C.c_int, [vp, vp, i64, vp, vp, i32, vp, vp]),
         "gyp_track_step": (C.c_int, [vp, vp, i32, vp, vp, i32, vp, vp]),
         "gyp_bank_create": (C.c_int, [vp, vp, i32, C.POINTER(vp)]),

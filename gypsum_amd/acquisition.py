@@ -89,22 +89,21 @@ class GpsSatelliteDetector:
     def get_best_doppler_shift_estimation(self, center_doppler_shift: float, doppler_shift_spread: float,
                                           antenna_data: np.ndarray, stream_attributes: SampleProviderAttributes,
                                           satellite_id: Any) -> BestNonCoherentCorrelationProfile:
-        """acquisition.py:154-190: one level of the search: bins range(int(c-s), int(c+s), int(s/10))."""
+        """acquisition.py:154-190: one level of the search, bins range(int(c-s), int(c+s), int(s/10)).
+
+        The choice between bins goes through gyp_search_level: bins whose float32 maxima are within rounding of each
+        other are re-evaluated in float64 on the device, as in the full search, so that the winner is the reference's."""
         n = stream_attributes.samples_per_prn_transmission
         n_ms = len(antenna_data) // n
-        bins = list(range(int(center_doppler_shift - doppler_shift_spread), int(center_doppler_shift + doppler_shift_spread),
-                          int(doppler_shift_spread / 10)))
-        cells = np.zeros(len(bins), dtype=CELL_DESC)
-        cells["sat_id"] = _sv(satellite_id)
-        cells["doppler_hz"] = bins
-        cells["tap_index"] = -1
         eng = self._engine(stream_attributes)
-        out, prof = eng.correlate_cells(np.asarray(antenna_data)[:n_ms * n], 1, n_ms, cells, GYP_NON_COHERENT, want_profiles=True)
-        best = int(np.argmax(out["peak"]))          # first (lowest-Doppler) bin holding the largest maximum
+        iq = np.asarray(antenna_data)[:n_ms * n]
+        level = eng.search_level(iq, 1, n_ms, [_sv(satellite_id)], center_doppler_shift, doppler_shift_spread)[0]
+        cell = np.zeros(1, dtype=CELL_DESC)
+        cell[0] = (0, _sv(satellite_id), float(level["doppler_hz"]), -1, 0)
+        _, prof = eng.correlate_cells(iq, 1, n_ms, cell, GYP_NON_COHERENT, want_profiles=True)
         return BestNonCoherentCorrelationProfile(
-            doppler_shift=bins[best], non_coherent_correlation_profile=prof[best].astype(np.float64),
-            sample_offset_of_correlation_peak=int(out["argmax"][best]),
-            correlation_strength=float(eng.cell_strength(out[best:best + 1])[0]))
+            doppler_shift=int(level["doppler_hz"]), non_coherent_correlation_profile=prof[0].astype(np.float64),
+            sample_offset_of_correlation_peak=int(level["code_phase"]), correlation_strength=float(level["strength"]))
 
     def get_integrated_correlation_with_doppler_shifted_prn(self, integration_type: IntegrationType, antenna_data: np.ndarray,
                                                             stream_attributes: SampleProviderAttributes, doppler_shift: float,

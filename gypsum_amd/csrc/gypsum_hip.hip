@@ -132,8 +132,8 @@ struct gyp_ctx {
     // RCCL communicator (gyp_comm_init); the library is dlopen'ed on first use, libgypsum_hip does not link against it
     void* comm = nullptr;
     int comm_rank = 0, comm_world = 1;
+    gyp_params params;
     bool no_spec = false;        // GYP_NO_SPEC=1: A/B switch back to the non-speculative latency kernel
-    float spec_kappa = 20.0f;    // GYP_SPEC_KAPPA: confidence threshold of the speculative tracker
     long long* d_prof = nullptr; // debug: per-phase cycle counters of track_block workgroup 0
     // growable scratch for the host-buffer entry points and the acquisition driver
     void* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -143,6 +143,9 @@ struct gyp_ctx {
 struct gyp_bank {
     gyp_ctx* ctx = nullptr;
     int n_chan = 0;
+    int64_t fs = 0;              // the stream format the bank was created under
+    int n = 0;
+    std::vector<int32_t> stream_of;   // host copy of each channel's stream index
     ChanState* d_states = nullptr;
     // speculative block tracking: state checkpoint, per-(channel, ms) hand-over records, failed-verification flags
     ChanState* d_ckpt = nullptr;
@@ -223,6 +226,40 @@ extern "C" {
 
 int gyp_version(void) { return GYP_VERSION; }
 
+void gyp_params_default(gyp_params* p) {
+    if (!p) return;
+    p->acq_initial_spread_hz = 7000.0; p->acq_min_spread_hz = 10.0; p->acq_bins_per_spread = 10.0;
+    p->dll_gain = 0.002; p->dll_phase_modulus = 2046.0;
+    p->pll_bandwidth_locked_hz = 3.0; p->pll_bandwidth_unlocked_hz = 6.0;
+    p->lock_error_variance_max = 900.0; p->lock_i_variance_max = 2.0; p->lock_rotation_max_deg = 6.0;
+    p->watchdog_period_s = 6.0; p->watchdog_drop_below = 0.2; p->watchdog_nudge_below = 0.93; p->watchdog_nudge_hz = 5.0;
+    p->spec_confidence_kappa = 20.0;
+}
+
+int gyp_set_params(gyp_ctx* ctx, const gyp_params* p) {
+    if (!ctx || !p) return GYP_E_BAD_ARG;
+    if (!(p->acq_initial_spread_hz > 0) || !(p->acq_min_spread_hz > 0) || !(p->acq_bins_per_spread >= 1) || !(p->dll_phase_modulus > 0) ||
+        !(p->pll_bandwidth_locked_hz > 0) || !(p->pll_bandwidth_unlocked_hz > 0) || !(p->lock_error_variance_max > 0) ||
+        !(p->lock_i_variance_max > 0) || !(p->lock_rotation_max_deg > 0 && p->lock_rotation_max_deg < 90) || !(p->watchdog_period_s > 0) ||
+        !(p->spec_confidence_kappa >= 0) || !std::isfinite(p->dll_gain))
+        return fail(ctx, GYP_E_BAD_ARG, "gyp_set_params: value out of range");
+    for (double s = p->acq_initial_spread_hz; s >= p->acq_min_spread_hz; s /= 2.0) {   // every level must fit the cell table
+        const int step = (int)(s / p->acq_bins_per_spread);
+        if (step < 1) return fail(ctx, GYP_E_BAD_ARG, "gyp_set_params: a search level would have a zero Doppler step");
+        // centres are integers (0, then a bin of the level above): int(c + s) - int(c - s) <= floor(2 s) + 1
+        const int span = (int)std::floor(2.0 * s) + 1;
+        if ((span + step - 1) / step > kMaxBins) return fail(ctx, GYP_E_BAD_ARG, "gyp_set_params: a search level would exceed 28 Doppler bins");
+    }
+    ctx->params = *p;
+    return GYP_OK;
+}
+
+int gyp_get_params(gyp_ctx* ctx, gyp_params* out) {
+    if (!ctx || !out) return GYP_E_BAD_ARG;
+    *out = ctx->params;
+    return GYP_OK;
+}
+
 const char* gyp_last_error(const gyp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 int gyp_create(int device_ordinal, gyp_ctx** out) {
@@ -244,7 +281,8 @@ int gyp_create(int device_ordinal, gyp_ctx** out) {
     ctx->n_cus = prop.multiProcessorCount;
     ctx->no_pipe = std::getenv("GYP_NO_PIPE") != nullptr;
     ctx->no_spec = std::getenv("GYP_NO_SPEC") != nullptr;
-    if (const char* kv = std::getenv("GYP_SPEC_KAPPA")) ctx->spec_kappa = (float)std::atof(kv);
+    gyp_params_default(&ctx->params);
+    if (const char* kv = std::getenv("GYP_SPEC_KAPPA")) ctx->params.spec_confidence_kappa = std::atof(kv);
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         delete ctx;
@@ -670,12 +708,14 @@ int gyp_grid_best_bins_dev(gyp_ctx* ctx, const gyp_cell* cells_dev, int32_t n_ro
 }
 
 // ---------------------------------------------------------------- acquisition ----------------------------
-int gyp_acquire_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_t stream_stride_samples,
-                    int32_t n_ms, const int32_t* sat_ids_host, int32_t n_sats, gyp_acq_result* out_dev) {
+// acquisition.py:70-152 from (center, spread) down to min_spread -- or exactly one level -- for every (stream, satellite).
+static int acquire_search(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_t stream_stride_samples, int32_t n_ms,
+                          const int32_t* sat_ids_host, int32_t n_sats, double center0, double spread0, bool single_level,
+                          gyp_acq_result* out_dev) {
     if (!ctx) return GYP_E_BAD_ARG;
     if (!ctx->k) return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
     if (!iq_dev || !sat_ids_host || !out_dev || n_streams <= 0 || n_sats <= 0 || n_ms <= 0)
-        return fail(ctx, GYP_E_BAD_ARG, "gyp_acquire_dev: bad argument");
+        return fail(ctx, GYP_E_BAD_ARG, "gyp_acquire_dev / gyp_search_level_dev: bad argument");
     for (int i = 0; i < n_sats; ++i)
         if (sat_ids_host[i] < 1 || sat_ids_host[i] > 32) return fail(ctx, GYP_E_BAD_ARG, "satellite id out of range");
     const int n_states = n_streams * n_sats;
@@ -686,8 +726,8 @@ int gyp_acquire_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_
             std::memset(&a, 0, sizeof(a));
             a.stream = s;
             a.sat_id = sat_ids_host[i];
-            a.center = 0.0;       // acquisition.py:78
-            a.spread = 7000.0;    // acquisition.py:79
+            a.center = center0;   // acquisition.py:78
+            a.spread = spread0;   // acquisition.py:79
         }
     int rc;
     const size_t n_cells = (size_t)n_states * kMaxBins;
@@ -706,8 +746,8 @@ int gyp_acquire_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_
     HIP_TRY(ctx, hipMemcpyAsync(d_states, init.data(), init.size() * sizeof(AcqSearchState), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `init` is a local
     const int tpb = 64, nblk = (n_states + tpb - 1) / tpb;
-    for (double spread = 7000.0; spread >= 10.0; spread /= 2.0) {  // acquisition.py:81,89
-        hipLaunchKernelGGL(acq_plan_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_cells);
+    for (double spread = spread0; single_level ? spread == spread0 : spread >= ctx->params.acq_min_spread_hz; spread /= 2.0) {  // acquisition.py:81,89
+        hipLaunchKernelGGL(acq_plan_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_cells, ctx->params.acq_bins_per_spread);
         rc = gyp_correlate_cells_dev(ctx, iq_dev, stream_stride_samples, n_ms, d_cells, (int32_t)n_cells, GYP_NON_COHERENT, d_out, nullptr);
         if (rc) return rc;
         RefineParams rp;
@@ -732,11 +772,52 @@ int gyp_acquire_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_
         hipLaunchKernelGGL(acq_exact_profile_kernel, dim3((unsigned)(ctx->k * n_ms), 2, (unsigned)std::min(n_states, 32)), dim3(1024), 0, ctx->stream, ep);
         hipLaunchKernelGGL(acq_exact_decide_kernel, dim3((unsigned)n_states), dim3(256), 0, ctx->stream, ep);
     }
+    if (single_level) {
+        hipLaunchKernelGGL(acq_finish_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, (const gyp_cell*)nullptr, out_dev);
+        HIP_TRY(ctx, hipGetLastError());
+        return GYP_OK;
+    }
     hipLaunchKernelGGL(acq_plan_coherent_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_cells);
     rc = gyp_correlate_cells_dev(ctx, iq_dev, stream_stride_samples, n_ms, d_cells, n_states, GYP_COHERENT, d_out, nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(acq_finish_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_out, out_dev);
     HIP_TRY(ctx, hipGetLastError());
+    return GYP_OK;
+}
+
+
+int gyp_acquire_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_t stream_stride_samples,
+                    int32_t n_ms, const int32_t* sat_ids_host, int32_t n_sats, gyp_acq_result* out_dev) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    return acquire_search(ctx, iq_dev, n_streams, stream_stride_samples, n_ms, sat_ids_host, n_sats, 0.0, ctx->params.acq_initial_spread_hz,
+                          false, out_dev);
+}
+
+int gyp_search_level_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_t stream_stride_samples, int32_t n_ms,
+                         const int32_t* sat_ids_host, int32_t n_sats, double center_hz, double spread_hz, gyp_acq_result* out_dev) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    const int step = (int)(spread_hz / ctx->params.acq_bins_per_spread);
+    if (!(spread_hz > 0) || step < 1 || ((int)(center_hz + spread_hz) - (int)(center_hz - spread_hz) + step - 1) / step > kMaxBins)
+        return fail(ctx, GYP_E_BAD_ARG, "gyp_search_level_dev: the level must have between 1 and 28 Doppler bins");
+    return acquire_search(ctx, iq_dev, n_streams, stream_stride_samples, n_ms, sat_ids_host, n_sats, center_hz, spread_hz, true, out_dev);
+}
+
+int gyp_search_level(gyp_ctx* ctx, const float* iq_host, int32_t n_streams, int32_t n_ms, const int32_t* sat_ids_host,
+                     int32_t n_sats, double center_hz, double spread_hz, gyp_acq_result* out_host) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    if (!ctx->k) return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
+    if (!iq_host || !out_host || n_streams <= 0 || n_ms <= 0 || n_sats <= 0) return fail(ctx, GYP_E_BAD_ARG, "gyp_search_level: bad argument");
+    const size_t iq_bytes = (size_t)n_streams * n_ms * ctx->n * 8;
+    const size_t out_bytes = (size_t)n_streams * n_sats * sizeof(gyp_acq_result);
+    int rc;
+    if ((rc = ensure_scratch(ctx, 0, iq_bytes))) return rc;
+    if ((rc = ensure_scratch(ctx, 5, out_bytes))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[0], iq_host, iq_bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = gyp_search_level_dev(ctx, (const float*)ctx->scratch[0], n_streams, (int64_t)n_ms * ctx->n, n_ms, sat_ids_host, n_sats,
+                              center_hz, spread_hz, (gyp_acq_result*)ctx->scratch[5]);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out_host, ctx->scratch[5], out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return GYP_OK;
 }
 
@@ -835,6 +916,9 @@ int gyp_bank_create(gyp_ctx* ctx, const gyp_chan_init* chans_host, int32_t n_cha
     gyp_bank* b = new gyp_bank();
     b->ctx = ctx;
     b->n_chan = n_chan;
+    b->fs = ctx->fs;
+    b->n = ctx->n;
+    for (int i = 0; i < n_chan; ++i) b->stream_of.push_back(chans_host[i].stream);
     hipError_t e = hipMalloc((void**)&b->d_states, init.size() * sizeof(ChanState));
     if (e == hipSuccess) e = hipMemcpy(b->d_states, init.data(), init.size() * sizeof(ChanState), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -878,6 +962,7 @@ int gyp_bank_set_channel(gyp_bank* bank, int32_t index, const gyp_chan_init* in)
     s.dll_phase = (double)in->code_phase;  // tracker.py:224
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(bank->d_states + index, &s, sizeof(ChanState), hipMemcpyHostToDevice));
+    bank->stream_of[index] = in->stream;
     return GYP_OK;
 }
 
@@ -920,7 +1005,7 @@ static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
     HIP_TRY(ctx, hipMemcpyAsync(bank->d_ckpt, bank->d_states, (size_t)bank->n_chan * sizeof(ChanState), hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(bank->d_bad, 0, (size_t)bank->n_chan * sizeof(int32_t), ctx->stream));
     p.spec_out = bank->d_spec;
-    p.spec_kappa = ctx->spec_kappa;
+    p.spec_kappa = (float)ctx->params.spec_confidence_kappa;
     if (std::getenv("GYP_SPEC_DEBUG")) {
         if (bank->dbg_cap < n_rec * 20) {
             if (bank->d_dbg) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(bank->d_dbg)); }
@@ -963,6 +1048,9 @@ int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stri
     if (!bank) return GYP_E_BAD_ARG;
     gyp_ctx* ctx = bank->ctx;
     if (!iq_dev || !start_time_dev || n_ms < 0) return fail(ctx, GYP_E_BAD_ARG, "gyp_track_block_dev: bad argument");
+    if (bank->fs != ctx->fs || bank->n != ctx->n)
+        return fail(ctx, GYP_E_BAD_ARG, "gyp_track_block: the bank was created for " + std::to_string(bank->fs) + " Hz / " + std::to_string(bank->n) +
+                                            " samples per ms, the context is now set to " + std::to_string(ctx->fs) + " / " + std::to_string(ctx->n));
     if (n_ms == 0) return GYP_OK;
     TrackBlockParams p;
     p.iq = reinterpret_cast<const cf*>(iq_dev);
@@ -980,8 +1068,15 @@ int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stri
     p.fs = (double)ctx->fs;
     p.prof = ctx->d_prof;
     p.codes = CodeTables{ctx->d_trans, ctx->d_ntrans, ctx->d_chipf};
+    {
+        const gyp_params& g = ctx->params;
+        p.lp = LoopParams{g.dll_gain, g.dll_phase_modulus, g.pll_bandwidth_locked_hz, g.pll_bandwidth_unlocked_hz,
+                          g.lock_error_variance_max, g.lock_i_variance_max, g.lock_rotation_max_deg,
+                          std::tan(g.lock_rotation_max_deg * M_PI / 180.0),
+                          g.watchdog_period_s, g.watchdog_drop_below, g.watchdog_nudge_below, g.watchdog_nudge_hz, (double)ctx->n};
+    }
     p.spec_out = nullptr;
-    p.spec_kappa = ctx->spec_kappa;
+    p.spec_kappa = (float)ctx->params.spec_confidence_kappa;
     p.only_if = nullptr;
     p.restore_from = nullptr;
     p.dbg = nullptr;
@@ -995,6 +1090,10 @@ int gyp_track_block(gyp_bank* bank, const float* iq_host, int32_t n_streams, int
     if (!bank) return GYP_E_BAD_ARG;
     gyp_ctx* ctx = bank->ctx;
     if (!iq_host || !start_time_host || n_streams <= 0 || n_ms < 0) return fail(ctx, GYP_E_BAD_ARG, "gyp_track_block: bad argument");
+    for (int c = 0; c < bank->n_chan; ++c)
+        if (bank->stream_of[c] >= n_streams)
+            return fail(ctx, GYP_E_BAD_ARG, "gyp_track_block: channel " + std::to_string(c) + " reads stream " +
+                                                std::to_string(bank->stream_of[c]) + " but only " + std::to_string(n_streams) + " were passed");
     if (n_ms == 0) return GYP_OK;
     const size_t iq_bytes = (size_t)n_streams * n_ms * ctx->n * 8;
     const size_t rec_bytes = (size_t)bank->n_chan * n_ms * sizeof(gyp_track_rec);

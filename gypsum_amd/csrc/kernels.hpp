@@ -1333,6 +1333,15 @@ __device__ __forceinline__ double pymod(double a, double b) {
     return r;
 }
 
+// The tunables of the reference's loops (gyp_params; tracker.py:157-203, 227-262, 297-303, 370-387, config.py:23-25).
+struct LoopParams {
+    double dll_gain, dll_modulus;
+    double bw_locked, bw_unlocked;
+    double err_var_max, i_var_max, rot_deg, rot_tan;     // rot_tan = tan(rot_deg)
+    double wd_period, wd_drop, wd_nudge, wd_nudge_hz;
+    double n_samples;                                      // samples per millisecond
+};
+
 // pymod for a wave-uniform argument (the loop filters): the library fmod sits behind a SCALAR branch.
 __device__ __forceinline__ bool uniform_true(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 __device__ __forceinline__ double pymod_uniform(double a, double b) {
@@ -1354,12 +1363,12 @@ __device__ __forceinline__ bool uniform(bool c) { return __builtin_amdgcn_readfi
 
 // is_locked() from the sliding sums (any lane; pure scalar math, no divisions: every comparison is multiplied through
 // by its positive denominators).
-__device__ __forceinline__ LockVerdict lock_from_sums(const LockSums& s, int64_t n_err) {
+__device__ __forceinline__ LockVerdict lock_from_sums(const LockSums& s, int64_t n_err, const LoopParams& lp) {
     // straight-line: the values are wave-uniform but live in vector registers, where every `if` would become an
     // exec-mask branch
     constexpr double W = (double)kLockWindow;
     // var(errors) = see/W - (se/W)^2 < 900   <=>   see*W - se^2 < 900*W^2
-    const double xe = s.see * W - s.se * s.se, te = 900.0 * W * W;
+    const double xe = s.see * W - s.se * s.se, te = lp.err_var_max * W * W;
     const bool var_ok = xe < te;
     // mean of the two pole variances < 2, a pole with fewer than two members counting 0 (tracker.py:176-186):
     //   A/cn^2 + B/cp^2 < 4  with A = nrr*cn - nr^2, B = prr*cp - pr^2
@@ -1367,12 +1376,12 @@ __device__ __forceinline__ LockVerdict lock_from_sums(const LockSums& s, int64_t
     const bool n2 = s.cn >= 2, p2 = s.cp >= 2;
     const double a = n2 ? s.nrr * cn - s.nr * s.nr : 0.0, b = p2 ? s.prr * cp - s.pr * s.pr : 0.0;
     const double cn2 = n2 ? cn * cn : 1.0, cp2 = p2 ? cp * cp : 1.0;
-    const double xi = a * cp2 + b * cn2, ti = 4.0 * cn2 * cp2;
+    const double xi = a * cp2 + b * cn2, ti = 2.0 * lp.i_var_max * cn2 * cp2;
     const bool i_ok = xi < ti;
     // tracker.py:190-197: the mean of the negative pole must lie within 6 degrees of the real axis (mod 180; the
     // `abs(bool)` quirk makes it one-sided).  distance(angle, 180Z) < 6  <=>  |im| < tan(6 deg) * |re|: no atan2 on
     // the per-millisecond path (with cn < 2 upstream's mean is 0+0j, angle 0: locked)
-    const double lhs = fabs(s.ni), rhs = 0.10510423526567646 * fabs(s.nr);   // tan(pi/30)
+    const double lhs = fabs(s.ni), rhs = lp.rot_tan * fabs(s.nr);   // tan(6 degrees)
     const bool rot_tested = var_ok && i_ok && n2;
     const bool rot_ok = !rot_tested || lhs < rhs;
     // anything within 1e-9 (relative) of a threshold is re-decided by the exact two-pass evaluation
@@ -1388,7 +1397,7 @@ __device__ __forceinline__ LockVerdict lock_from_sums(const LockSums& s, int64_t
 // Out of line (it runs about once per thousand milliseconds): inlined, its dozens of live float64 values raise the
 // register pressure of every tracking loop that contains it.
 __device__ __attribute__((noinline)) bool is_locked_exact_wave(const ChanState* st, int64_t n_err, int64_t n_peaks, int lane,
-                                                               LockSums& fresh) {
+                                                               LockSums& fresh, const LoopParams& lp) {
     const int e_newest = (int)((n_err - 1 + kLockWindow) % kLockWindow), p_newest = (int)((n_peaks - 1) % kPeakHistory);
     const int ne = (int)(n_err < kLockWindow ? n_err : kLockWindow);
     const int np = (int)(n_peaks < kLockWindow ? n_peaks : kLockWindow);
@@ -1437,7 +1446,7 @@ __device__ __attribute__((noinline)) bool is_locked_exact_wave(const ChanState* 
     const double mr = fresh.cn >= 2 ? fresh.nr / fresh.cn : 0.0, mi = fresh.cn >= 2 ? fresh.ni / fresh.cn : 0.0;
     const double ang = 180.0 - pymod((atan2(mi, mr) / 6.283185307179586) * 360.0, 180.0);
     const double centered = ang < 90.0 ? ang : 180.0 - ang;
-    return ve < 900.0 && (vneg + vpos) / 2.0 < 2.0 && centered < 6.0;
+    return ve < lp.err_var_max && (vneg + vpos) / 2.0 < lp.i_var_max && centered < lp.rot_deg;
 }
 
 // utils.py:134-144 circularity and :119-131 rotation over the last min(n_peaks, 1000) peaks, by wavefront 0.
@@ -1493,6 +1502,7 @@ struct TrackBlockParams {
     double fs;
     long long* prof;           // optional: per-phase cycle counters of workgroup 0 (debug)
     CodeTables codes;
+    LoopParams lp;
     // speculative mode (MODE 2)
     SpecIn* spec_out;          // [n_chan][n_ms]
     float spec_kappa;          // window peak^2 must reach spec_kappa * (energy of the millisecond's samples)
@@ -1547,11 +1557,16 @@ __device__ __forceinline__ void fetch_leaving(const ChanState* st, const RedScra
 // millisecond's record is assembled in red->rec and written out by rec_flush.
 //
 // tracker.py:297-303 code loop.  Owns LoopState::dll_phase and istate[0].
-__device__ __forceinline__ void dll_update(RedScratch* red, double disc, int lane) {
-    double dll = red->loop.dll_phase + disc * 0.002;
-    const int new_code_phase = (int)dll;           // int() truncates toward zero, before the wrap
-    dll = pymod_uniform(dll, 2046.0);
-    dll += dll < 0.0 ? 2046.0 : 0.0;
+// int(self.phase) of an accumulator beyond the int32 range (un-normalised integer recordings: the discriminator is
+// |E|^2 - |L|^2): Python's integer is unbounded and only ever used as an np.roll shift, so the record carries the
+// equivalent roll, the value modulo N with the sign kept.
+__device__ __attribute__((noinline)) int code_phase_beyond_int32(double t, double n) { return (int)fmod(t, n); }
+__device__ __forceinline__ void dll_update(RedScratch* red, double disc, int lane, const LoopParams& lp) {
+    double dll = red->loop.dll_phase + disc * lp.dll_gain;
+    const double whole = trunc(dll);               // int() truncates toward zero, before the wrap
+    const int new_code_phase = uniform(fabs(whole) < 2147483648.0) ? (int)whole : code_phase_beyond_int32(whole, lp.n_samples);
+    dll = pymod_uniform(dll, lp.dll_modulus);
+    dll += dll < 0.0 ? lp.dll_modulus : 0.0;
     if (lane == 0) {
         red->loop.dll_phase = dll;
         red->istate[0] = new_code_phase;
@@ -1586,15 +1601,16 @@ __device__ __forceinline__ void costas_update(const TrackBlockParams& p, ChanSta
     }
     // ---- Costas loop, tracker.py:246-262
     const double err = pr * pim;
-    LockVerdict lv = lock_from_sums(sums, n);
+    const LoopParams& lp = p.lp;
+    LockVerdict lv = lock_from_sums(sums, n, lp);
     bool locked = lv.locked;
     if (uniform(lv.marginal || pos_refresh == kLockRefresh - 1)) {
         workgroup_mem_fence_wave();                 // lane 0's ring stores -> every lane of this wavefront
         LockSums fresh;
-        locked = is_locked_exact_wave(st, n, n + 1, lane, fresh);
+        locked = is_locked_exact_wave(st, n, n + 1, lane, fresh, lp);
         sums = fresh;
     }
-    const double bw = locked ? 3.0 : 6.0;
+    const double bw = locked ? lp.bw_locked : lp.bw_unlocked;
     const double tps = p.inv_fs;                // == 1.0 / samples_per_second, formed on the host
     const double alpha = 4.0 * (1.0 / sqrt(2.0)) * bw * tps;
     const double beta = 4.0 * (bw * bw) * tps;
@@ -1610,16 +1626,16 @@ __device__ __forceinline__ void costas_update(const TrackBlockParams& p, ChanSta
     const double rec_f = nf, rec_phi = nphi;
     // ---- circularity watchdog, tracker.py:370-387
     int status = 0, nudged = 0;
-    if (uniform(t0 - last_watchdog >= 6.0)) {
+    if (uniform(t0 - last_watchdog >= p.lp.wd_period)) {
         workgroup_mem_fence_wave();
         double cs[3];
         constellation_stats_wave(st, n + 1, lane, cs);
         last_watchdog = t0;
         if (cs[0] >= 0.0) {
-            if (cs[0] < 0.2) { status = 1; lost = 1; }
-            else if (cs[0] < 0.93 && cs[2] != 0.0) {
+            if (cs[0] < p.lp.wd_drop) { status = 1; lost = 1; }
+            else if (cs[0] < p.lp.wd_nudge && cs[2] != 0.0) {
                 const double sg = cs[1] > 0.0 ? 1.0 : (cs[1] < 0.0 ? -1.0 : 0.0);
-                nf += -sg * 5.0;
+                nf += -sg * p.lp.wd_nudge_hz;
                 nphi += sg * (3.141592653589793 / 2.0);
                 nudged = 1;
             }
@@ -1681,16 +1697,16 @@ __device__ __forceinline__ void costas_candidate(const TrackBlockParams& p, RedS
 // Everything else of costas_update -- histories, lock verdict, watchdog, the record's fields -- in two steps: what does
 // not depend on this millisecond's peak (state read, the entries leaving the windows, the error-variance test, which
 // is_locked() evaluates before the new error joins) is done while the window sums are still being formed.
-__device__ __forceinline__ void verdict_prepare(RedScratch* red, const double (&leave)[3], int lane) {
+__device__ __forceinline__ void verdict_prepare(RedScratch* red, const double (&leave)[3], int lane, const LoopParams& lp) {
     const int64_t n = red->loop.n_steps;
     LockSums s = red->loop.sums;
     const double leave_pr = leave[1], leave_pi = leave[2];
     const bool full = n >= kLockWindow;
-    const bool ln = full && leave_pr < 0.0, lp = full && !(leave_pr < 0.0);
+    const bool ln = full && leave_pr < 0.0, lpos = full && !(leave_pr < 0.0);
     s.nr -= ln ? leave_pr : 0.0; s.ni -= ln ? leave_pi : 0.0; s.nrr -= ln ? leave_pr * leave_pr : 0.0; s.cn -= ln ? 1 : 0;
-    s.pr -= lp ? leave_pr : 0.0; s.prr -= lp ? leave_pr * leave_pr : 0.0; s.cp -= lp ? 1 : 0;
+    s.pr -= lpos ? leave_pr : 0.0; s.prr -= lpos ? leave_pr * leave_pr : 0.0; s.cp -= lpos ? 1 : 0;
     constexpr double W = (double)kLockWindow;
-    const double xe = s.see * W - s.se * s.se, te = 900.0 * W * W;     // see lock_from_sums
+    const double xe = s.see * W - s.se * s.se, te = lp.err_var_max * W * W;     // see lock_from_sums
     if (lane == 0) {
         red->vprep.sums = s;                       // the leaving peak already removed
         red->vprep.leave_e = leave[0];
@@ -1720,9 +1736,9 @@ __device__ __forceinline__ void verdict_finish(const TrackBlockParams& p, ChanSt
         const bool n2 = sums.cn >= 2, p2 = sums.cp >= 2;
         const double a = n2 ? sums.nrr * cn - sums.nr * sums.nr : 0.0, b = p2 ? sums.prr * cp - sums.pr * sums.pr : 0.0;
         const double cn2 = n2 ? cn * cn : 1.0, cp2 = p2 ? cp * cp : 1.0;
-        const double xi = a * cp2 + b * cn2, ti = 4.0 * cn2 * cp2;
+        const double xi = a * cp2 + b * cn2, ti = 2.0 * p.lp.i_var_max * cn2 * cp2;
         const bool i_ok = xi < ti;
-        const double lhs = fabs(sums.ni), rhs = 0.10510423526567646 * fabs(sums.nr);
+        const double lhs = fabs(sums.ni), rhs = p.lp.rot_tan * fabs(sums.nr);
         const bool rot_tested = v.var_ok && i_ok && n2;
         const bool rot_ok = !rot_tested || lhs < rhs;
         const bool full = n >= kLockWindow;
@@ -1732,7 +1748,7 @@ __device__ __forceinline__ void verdict_finish(const TrackBlockParams& p, ChanSt
     if (uniform(marginal || pos_refresh == kLockRefresh - 1)) {
         workgroup_mem_fence_wave();
         LockSums fresh;
-        locked = is_locked_exact_wave(st, n, n + 1, lane, fresh);
+        locked = is_locked_exact_wave(st, n, n + 1, lane, fresh, p.lp);
         sums = fresh;
     }
     sums.se -= n >= kLockWindow ? v.leave_e : 0.0; sums.see -= n >= kLockWindow ? v.leave_e * v.leave_e : 0.0;
@@ -1743,19 +1759,19 @@ __device__ __forceinline__ void verdict_finish(const TrackBlockParams& p, ChanSt
     pos_refresh = pos_refresh + 1 == kLockRefresh ? 0 : pos_refresh + 1;
     int status = 0, nudged = 0, sel = locked ? 0 : 1;
     const int rec_sel = sel;                    // the record carries the values before any watchdog nudge
-    if (uniform(t0 - last_watchdog >= 6.0)) {
+    if (uniform(t0 - last_watchdog >= p.lp.wd_period)) {
         workgroup_mem_fence_wave();
         double cs[3];
         constellation_stats_wave(st, n + 1, lane, cs);
         last_watchdog = t0;
         if (cs[0] >= 0.0) {
-            if (cs[0] < 0.2) { status = 1; lost = 1; }
-            else if (cs[0] < 0.93 && cs[2] != 0.0) {
-                const double bw = locked ? 3.0 : 6.0, tps = p.inv_fs;
+            if (cs[0] < p.lp.wd_drop) { status = 1; lost = 1; }
+            else if (cs[0] < p.lp.wd_nudge && cs[2] != 0.0) {
+                const double bw = locked ? p.lp.bw_locked : p.lp.bw_unlocked, tps = p.inv_fs;
                 double nphi = pymod_uniform(phi + err * (4.0 * (1.0 / sqrt(2.0)) * bw * tps), 6.283185307179586);
                 double nf = f + err * (4.0 * (bw * bw) * tps);
                 const double sg = cs[1] > 0.0 ? 1.0 : (cs[1] < 0.0 ? -1.0 : 0.0);
-                nf += -sg * 5.0;
+                nf += -sg * p.lp.wd_nudge_hz;
                 nphi += sg * (3.141592653589793 / 2.0);
                 nudged = 1;
                 sel = 2;
@@ -2084,7 +2100,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
                 // wavefront 0: the ring entries leaving the lock windows were requested at the top of the millisecond and are
                 // consumed here, BEFORE the next millisecond's samples are requested -- the vector-memory counter retires
                 // in order, so a later wait for those three loads would also wait for the eight sample loads behind them
-                if (wave == 0) verdict_prepare(sm.red, leave, lane);
+                if (wave == 0) verdict_prepare(sm.red, leave, lane, p.lp);
                 // the raw samples are consumed: request the next millisecond now, the loads fly under the window sums
                 if (ms + 1 < p.ms_end) stage_fetch_own<K>(stream + (int64_t)(ms + 1) * N, smp, launder(threadIdx.x));
                 if (prof) t_b = (long long)__builtin_readcyclecounter();
@@ -2172,12 +2188,12 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         asm volatile("; MARK_UPDATE_BEGIN");
         if constexpr (SPEC) {
             if (wave == 0) verdict_finish<K>(p, st, sm.red, t0, lane, m, f, phi);
-            if (wave == 1) dll_update(sm.red, m.disc, lane);
-            if (wave == 2) costas_candidate(p, sm.red, m.peak, f, phi, 3.0, 0, lane);
-            if (wave == 3) costas_candidate(p, sm.red, m.peak, f, phi, 6.0, 1, lane);
+            if (wave == 1) dll_update(sm.red, m.disc, lane, p.lp);
+            if (wave == 2) costas_candidate(p, sm.red, m.peak, f, phi, p.lp.bw_locked, 0, lane);
+            if (wave == 3) costas_candidate(p, sm.red, m.peak, f, phi, p.lp.bw_unlocked, 1, lane);
         } else if (wave == 0) {
             fetch_leaving(st, sm.red, leave);
-            dll_update(sm.red, m.disc, lane);
+            dll_update(sm.red, m.disc, lane, p.lp);
             costas_update<K>(p, st, sm.red, t0, lane, m, leave);
             workgroup_mem_fence_wave();
             rec_flush(sm.red, rec, lane);
@@ -2312,12 +2328,12 @@ struct AcqSearchState {
 };
 
 // Fill the descriptors of the current level: range(int(c-s), int(c+s), int(s/10)), padded to kMaxBins.
-__global__ void acq_plan_kernel(AcqSearchState* states, int n_states, gyp_cell_desc* cells) {
+__global__ void acq_plan_kernel(AcqSearchState* states, int n_states, gyp_cell_desc* cells, double bins_per_spread) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_states) return;
     AcqSearchState s = states[i];
-    const int lo = (int)(s.center - s.spread), hi = (int)(s.center + s.spread), step = (int)(s.spread / 10.0);
-    const int nb = hi > lo ? (hi - lo + step - 1) / step : 0;
+    const int lo = (int)(s.center - s.spread), hi = (int)(s.center + s.spread), step = (int)(s.spread / bins_per_spread);
+    const int nb = hi > lo ? min((hi - lo + step - 1) / step, kMaxBins) : 0;     // gyp_set_params keeps every level within kMaxBins
     states[i].bins_lo = lo; states[i].bins_step = step; states[i].n_bins = nb;
     for (int b = 0; b < kMaxBins; ++b) {
         gyp_cell_desc d;
@@ -2596,7 +2612,7 @@ __global__ void acq_finish_kernel(const AcqSearchState* states, int n_states, co
     gyp_acq_result r;
     r.stream = states[i].stream; r.sat_id = states[i].sat_id;
     r.doppler_hz = states[i].best_doppler; r.code_phase = states[i].best_index;
-    r.carrier_phase = atan2((double)cells[i].tap_im, (double)cells[i].tap_re);
+    r.carrier_phase = cells ? atan2((double)cells[i].tap_im, (double)cells[i].tap_re) : 0.0;   // no coherent pass after a single level
     r.strength = states[i].best_strength;
     out[i] = r;
 }

@@ -12,7 +12,7 @@ from typing import Dict, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import (ACQ_RESULT, CELL, CELL_DESC, CHAN_IN, CHAN_INIT, CHAN_OUT, GYP_COHERENT, GYP_NON_COHERENT,
+from ._lib import (ACQ_RESULT, CELL, CELL_DESC, CHAN_IN, CHAN_INIT, CHAN_OUT, GYP_COHERENT, GYP_NON_COHERENT, PARAMS,
                    SYNTH_SAT, TRACK_REC, GypsumHipError, ptr)
 
 
@@ -213,6 +213,35 @@ class GypsumEngine:
         self._check(self.lib.gyp_acquire(self.ctx, ptr(iq), n_streams, n_ms, ptr(ids), len(ids), ptr(out)))
         return out
 
+    def search_level(self, iq: np.ndarray, n_streams: int, n_ms: int, sat_ids: Sequence[int], center_hz: float,
+                     spread_hz: float) -> np.ndarray:
+        """One level of the search (acquisition.py:154-190): best bin, its arg-max and strength per (stream, satellite)."""
+        iq = _as_iq(iq).reshape(-1)
+        if iq.size != n_streams * n_ms * self.n:
+            raise ValueError(f"expected {n_streams}*{n_ms}*{self.n} samples, got {iq.size}")
+        ids = np.ascontiguousarray(sat_ids, dtype=np.int32)
+        out = np.zeros(n_streams * len(ids), dtype=ACQ_RESULT)
+        self._check(self.lib.gyp_search_level(self.ctx, ptr(iq), n_streams, n_ms, ptr(ids), len(ids), float(center_hz),
+                                               float(spread_hz), ptr(out)))
+        return out
+
+    # ------------------------------------------------------------------ tunables (gyp_params)
+    def get_params(self) -> dict:
+        rec = np.zeros(1, dtype=PARAMS)
+        self._check(self.lib.gyp_get_params(self.ctx, ptr(rec)))
+        return {k: float(rec[0][k]) for k in PARAMS.names}
+
+    def set_params(self, **changes: float) -> dict:
+        """Change some of the reference's tunables (names as in gyp_params); returns the full set now in force."""
+        rec = np.zeros(1, dtype=PARAMS)
+        self._check(self.lib.gyp_get_params(self.ctx, ptr(rec)))
+        for k, v in changes.items():
+            if k not in PARAMS.names:
+                raise KeyError(k)
+            rec[0][k] = float(v)
+        self._check(self.lib.gyp_set_params(self.ctx, ptr(rec)))
+        return {k: float(rec[0][k]) for k in PARAMS.names}
+
     def acquire_dev(self, iq_ptr: int, n_streams: int, stream_stride: int, n_ms: int, sat_ids: Sequence[int],
                     out_ptr: int) -> None:
         """Device-pointer form (asynchronous on the engine's stream): out_ptr receives n_streams*len(sat_ids) records."""
@@ -309,14 +338,16 @@ class ChannelBank:
             pass
 
 
-_default_engines: Dict[int, GypsumEngine] = {}
+_default_engines: Dict[Tuple[int, int, int], GypsumEngine] = {}
 
 
 def default_engine(samples_per_second: int, samples_per_prn_transmission: int, device: int = 0) -> GypsumEngine:
-    """Process-wide engine for the drop-in classes (the reference is single-threaded, one stream format)."""
-    eng = _default_engines.get(device)
+    """Process-wide engine of one (device, stream format) for the drop-in classes.  One engine per format: a bank or
+    tracker created under one sample rate keeps its context when another rate is used next to it."""
+    key = (int(device), int(samples_per_second), int(samples_per_prn_transmission))
+    eng = _default_engines.get(key)
     if eng is None:
-        eng = _default_engines[device] = GypsumEngine(device)
-    if eng.fs != samples_per_second or eng.n != samples_per_prn_transmission:
+        eng = GypsumEngine(device)
         eng.set_stream_format(samples_per_second, samples_per_prn_transmission)
+        _default_engines[key] = eng
     return eng

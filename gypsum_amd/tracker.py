@@ -165,6 +165,9 @@ class GpsSatelliteTracker:
                          - (math.pow(late.real, 2) + math.pow(late.imag, 2))) / 2
         self.phase += discriminator * _DLL_GAIN
         p.current_prn_code_phase_shift = int(self.phase)      # taken before the wrap, tracker.py:299
+        if abs(p.current_prn_code_phase_shift) >= 2 ** 31:    # beyond gyp_chan_in::code_phase: the same np.roll shift, mod N
+            p.current_prn_code_phase_shift = int(math.fmod(p.current_prn_code_phase_shift,
+                                                           self.stream_attributes.samples_per_prn_transmission))
         p.discriminators.append(float(discriminator))
         self.phase %= _DLL_MODULUS
         if self.phase < 0:

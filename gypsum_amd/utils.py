@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import math
 from enum import Enum, auto
-from typing import Iterator, Optional
+from typing import Iterator, Optional, Tuple
 
 import numpy as np
 
@@ -37,38 +37,52 @@ def chunks(li, chunk_size: int, step: Optional[int] = None) -> Iterator:
         yield li[i:i + chunk_size]
 
 
-def identify_satellite(prn_replica: np.ndarray) -> int:
-    """Which SV's un-rolled +-1 replica is this?  (The library keeps its own PRN spectra, keyed by satellite id.)"""
+def identify_satellite_and_roll(prn_replica: np.ndarray) -> Tuple[int, int]:
+    """Which SV's +-1 replica is this, and rolled by how many samples?  (The library keeps its own PRN spectra, keyed by
+    satellite id; a replica np.roll()ed by s -- what tracker.py:289-309 passes -- is the same code read s samples later.)"""
     n = len(prn_replica)
     if n % 1023:
         raise ValueError("PRN replica length must be a multiple of 1023 samples")
-    chips = (np.real(prn_replica[:: n // 1023]) > 0).astype(np.uint8)
-    hits = np.flatnonzero((generate_ca_code_table() == chips[None, :]).all(axis=1))
-    if len(hits) != 1:
-        raise NotImplementedError("replica is not the un-rolled C/A code of SV 1..32; rolled replicas are handled by "
-                                  "gypsum_amd.tracker (code phase is an argument of gyp_track_step), not here")
-    return int(hits[0]) + 1
+    k = n // 1023
+    got = np.where(np.real(prn_replica) > 0, 1.0, -1.0)
+    table = np.repeat(generate_ca_code_table().astype(np.float64) * 2.0 - 1.0, k, axis=1)          # [32, n] un-rolled
+    # circular cross-correlation with every SV's code: an exact match at roll s has the value n there (C/A cross- and
+    # off-peak auto-correlations stay far below it)
+    xc = np.fft.irfft(np.fft.rfft(got)[None, :] * np.conj(np.fft.rfft(table, axis=1)), n=n, axis=1)
+    sv, s = np.unravel_index(int(np.argmax(xc)), xc.shape)
+    if not np.array_equal(np.roll(table[sv], s), got) or not np.all(np.abs(np.real(prn_replica)) == 1.0) or np.any(np.imag(prn_replica)):
+        raise NotImplementedError("replica is not a (rolled) +-1 C/A code of SV 1..32")
+    return int(sv) + 1, int(s)
+
+
+def identify_satellite(prn_replica: np.ndarray) -> int:
+    return identify_satellite_and_roll(prn_replica)[0]
 
 
 def integrate_correlation_with_doppler_shifted_prn(integration_type: IntegrationType, antenna_data: np.ndarray,
                                                    stream_attributes: SampleProviderAttributes, doppler_shift: float,
                                                    prn_as_complex: np.ndarray) -> np.ndarray:
-    """utils.py:77-108.  NonCoherent -> float64[N] (sum |c|), Coherent -> complex128[N] (sum c)."""
+    """utils.py:77-108.  NonCoherent -> float64[N] (sum |c|), Coherent -> complex128[N] (sum c).
+
+    With a replica rolled by s samples the profile is the un-rolled one read s lags later:
+    corr(x, roll(p, s))[k] = sum_n x[n + k] conj(p[n - s]) = c0[(k + s) mod N]."""
     fs, n = stream_attributes.samples_per_second, stream_attributes.samples_per_prn_transmission
     eng = default_engine(fs, n)
     n_ms = len(antenna_data) // n
+    sv, roll = identify_satellite_and_roll(prn_as_complex)
     cell = np.zeros(1, dtype=CELL_DESC)
-    cell[0] = (0, identify_satellite(prn_as_complex), float(doppler_shift), -1, 0)
+    cell[0] = (0, sv, float(doppler_shift), -1, 0)
     coherent = integration_type == IntegrationType.Coherent
     if not coherent and integration_type != IntegrationType.NonCoherent:
         raise ValueError("Unexpected integration type")
     _, prof = eng.correlate_cells(np.asarray(antenna_data)[:n_ms * n], 1, n_ms, cell,
                                   GYP_COHERENT if coherent else GYP_NON_COHERENT, want_profiles=True)
-    return prof[0].astype(complex if coherent else np.float64)
+    out = prof[0].astype(complex if coherent else np.float64)
+    return np.roll(out, -roll) if roll else out
 
 
 def frequency_domain_correlation(antenna_samples: np.ndarray, prn_replica: np.ndarray) -> np.ndarray:
-    """utils.py:59-73 for one millisecond and an un-rolled replica: ifft(fft(x) * conj(fft(p)))."""
+    """utils.py:59-73 for one millisecond: ifft(fft(x) * conj(fft(p))), p un-rolled or np.roll()ed (tracker.py:289-309)."""
     n = len(prn_replica)
     if len(antenna_samples) != n:
         raise ValueError("operands could not be broadcast together")   # what numpy raises in the reference (SURVEY F1)

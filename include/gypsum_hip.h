@@ -61,6 +61,39 @@ int gyp_sync(gyp_ctx* ctx);
 int gyp_timer_start(gyp_ctx* ctx);
 int gyp_timer_stop(gyp_ctx* ctx, float* elapsed_ms);
 
+/* The reference's tunables on this path, with its values as defaults.  What is NOT here: the acquisition integration
+ * period (config.py:4: the caller passes n_ms = 10 blocks), the detection threshold (config.py:7: left to the caller of
+ * gyp_acquire) and the 250-ms lock window (config.py:23: sizes device-resident rings, compile-time). */
+typedef struct gyp_params {
+    /* acquisition.py:78-89, 163-167: coarse-to-fine Doppler search */
+    double acq_initial_spread_hz;      /* 7000 */
+    double acq_min_spread_hz;          /* 10: levels run while spread >= this, spread halves per level */
+    double acq_bins_per_spread;        /* 10: bins of a level are range(int(c-s), int(c+s), int(s / this)) */
+    /* tracker.py:297-303 code loop */
+    double dll_gain;                   /* 0.002 */
+    double dll_phase_modulus;          /* 2046 (hard-coded upstream whatever the sample rate) */
+    /* tracker.py:227-262 Costas loop */
+    double pll_bandwidth_locked_hz;    /* 3 */
+    double pll_bandwidth_unlocked_hz;  /* 6 */
+    /* tracker.py:157-203 is_locked(), config.py:25 */
+    double lock_error_variance_max;    /* 900 */
+    double lock_i_variance_max;        /* 2 */
+    double lock_rotation_max_deg;      /* 6 */
+    /* tracker.py:370-387 circularity watchdog */
+    double watchdog_period_s;          /* 6 */
+    double watchdog_drop_below;        /* 0.2 */
+    double watchdog_nudge_below;       /* 0.93 */
+    double watchdog_nudge_hz;          /* 5 (the phase nudge is pi/2 as upstream) */
+    /* this library's speculative tracker: a millisecond advances on its window maximum if peak^2 >= kappa * (energy of the
+     * millisecond's samples); results do not depend on it (every such millisecond is verified), only speed does */
+    double spec_confidence_kappa;      /* 20 */
+} gyp_params;
+void gyp_params_default(gyp_params* out);
+/* Takes effect for calls made afterwards (banks included).  GYP_E_BAD_ARG for values the kernels cannot represent
+ * (non-positive spreads / gains / bandwidths, a level with more than 28 Doppler bins). */
+int gyp_set_params(gyp_ctx* ctx, const gyp_params* params);
+int gyp_get_params(gyp_ctx* ctx, gyp_params* out);
+
 /* Stream descriptor -- replaces SampleProviderAttributes (antenna_sample_provider.py:24-28) and the PRN
  * replica construction of receiver.py:45-53 / satellite.py:20-31.  Requires samples_per_ms == fs_hz/1000 and
  * samples_per_ms == K*1023 with K in {1,2,3,4,5,6,8,10,12,16,20,48} (the reference needs an integer
@@ -163,6 +196,13 @@ int gyp_acquire_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_
                     int32_t n_ms, const int32_t* sat_ids_host, int32_t n_sats, gyp_acq_result* out_dev);
 int gyp_acquire(gyp_ctx* ctx, const float* iq_host, int32_t n_streams, int32_t n_ms,
                 const int32_t* sat_ids_host, int32_t n_sats, gyp_acq_result* out_host);
+/* ONE level of that search -- acquisition.py:154-190 get_best_doppler_shift_estimation(center, spread, ...) -- with the
+ * float64 tie-break between near-equal bins the full search applies: doppler_hz / code_phase / strength of the best
+ * bin per (stream, satellite); carrier_phase is 0. */
+int gyp_search_level_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_t stream_stride_samples, int32_t n_ms,
+                         const int32_t* sat_ids_host, int32_t n_sats, double center_hz, double spread_hz, gyp_acq_result* out_dev);
+int gyp_search_level(gyp_ctx* ctx, const float* iq_host, int32_t n_streams, int32_t n_ms, const int32_t* sat_ids_host,
+                     int32_t n_sats, double center_hz, double spread_hz, gyp_acq_result* out_host);
 
 /* ---------------------------------------------------------------- tracking: one explicit millisecond -- */
 /* Numeric core of tracker.py:264-329 _run_prn_code_tracking_loop_iteration for a batch of channels:
@@ -251,7 +291,13 @@ int gyp_bank_set_channel(gyp_bank* bank, int32_t index, const gyp_chan_init* ini
 int gyp_bank_drop_channel(gyp_bank* bank, int32_t index);
 /* Advance every channel n_ms milliseconds.  iq_dev: n_streams x n_ms x N (stream stride given);
  * start_time_dev/end_time_dev: n_ms doubles (shared by all streams): chunk.start_time / chunk.end_time;
- * rec_out_dev: n_chan x n_ms records (channel-major), may be NULL. */
+ * rec_out_dev: n_chan x n_ms records (channel-major), may be NULL.
+ * The host form returns GYP_E_BAD_ARG when a channel's stream index is >= n_streams; for the _dev form the caller
+ * guarantees that iq_dev holds (largest stream index + 1) streams.  Both return GYP_E_BAD_ARG when the context's stream
+ * format is no longer the one the bank was created under.
+ * gyp_track_rec::code_phase is int(self.phase) (tracker.py:299); should the accumulator leave the int32 range
+ * (un-normalised integer recordings: the discriminator is |E|^2 - |L|^2) the record carries that integer modulo N, sign
+ * kept -- the same np.roll shift. */
 int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stride_samples, int32_t n_ms,
                         const double* start_time_dev, gyp_track_rec* rec_out_dev);
 int gyp_track_block(gyp_bank* bank, const float* iq_host, int32_t n_streams, int32_t n_ms,

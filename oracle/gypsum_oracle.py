@@ -46,6 +46,8 @@ ACQUISITION_INTEGRATION_PERIOD_MS = 10     # config.py:4
 ACQUISITION_STRENGTH_THRESHOLD = 3         # config.py:7
 LOCK_WINDOW_MS = 250                       # config.py:23
 LOCK_MAX_PHASE_ERROR_VARIANCE = 900        # config.py:25
+LOCK_MAX_I_VARIANCE = 2                    # tracker.py:192 (literal upstream)
+LOCK_MAX_ROTATION_DEG = 6                  # tracker.py:197 (literal upstream)
 TRACKER_HZ = 1000                          # tracker.py:114
 DLL_GAIN = 0.002                           # tracker.py:298
 DLL_PHASE_MODULUS = 2046                   # tracker.py:301-303 (hard-coded)
@@ -57,6 +59,7 @@ WATCHDOG_NUDGE_BELOW = 0.93                # tracker.py:380
 WATCHDOG_NUDGE_HZ = 5                      # tracker.py:385
 ACQ_INITIAL_SPREAD_HZ = 7000.0             # acquisition.py:79
 ACQ_MIN_SPREAD_HZ = 10                     # acquisition.py:81
+ACQ_BINS_PER_SPREAD = 10                   # acquisition.py:166 (literal upstream)
 
 # G2 output tap pairs per SV (IS-GPS-200 table 3-Ia; gps_ca_prn_codes.py:145-178)
 G2_TAPS: Dict[int, Tuple[int, int]] = {
@@ -212,7 +215,7 @@ class AcquisitionResult:
 
 def doppler_bins(center: float, spread: float) -> range:
     """acquisition.py:163-167: range(int(c-s), int(c+s), int(s/10)) -- half-open, int() truncation."""
-    return range(int(center - spread), int(center + spread), int(spread / 10))
+    return range(int(center - spread), int(center + spread), int(spread / ACQ_BINS_PER_SPREAD))
 
 
 def best_doppler_bin(center: float, spread: float, antenna_data: np.ndarray, fs: int, n: int,
@@ -307,6 +310,7 @@ class TrackStepRecord:
     carrier_phase_after: float
     start_of_pseudosymbol: float
     end_of_pseudosymbol: float
+    nudged: bool = False        # the circularity watchdog changed Doppler / carrier phase after this millisecond
 
 
 class TrackingState:
@@ -341,10 +345,10 @@ class TrackingState:
             mean_neg = np.mean(neg) if len(neg) >= 2 else 0
             nvar = np.var(neg.real) if len(neg) >= 2 else 0
             pvar = np.var(pos.real) if len(pos) >= 2 else 0
-            i_ok = (nvar + pvar) / 2.0 < 2
+            i_ok = (nvar + pvar) / 2.0 < LOCK_MAX_I_VARIANCE
             angle = 180 - (((np.arctan2(mean_neg.imag, mean_neg.real) / TAU) * 360) % 180)
             centered = angle if angle < 90 else 180 - angle
-            rot_ok = bool(abs(centered < 6))
+            rot_ok = bool(abs(centered < LOCK_MAX_ROTATION_DEG))
         return bool(var_ok and i_ok and rot_ok)
 
 
@@ -395,7 +399,7 @@ class Tracker:
         symbol = int(np.sign(peak.real))
         if symbol == 0:
             raise KeyError(0)                                            # tracker.py:93-96 from_val
-        delay = (s.current_prn_code_phase_shift / DLL_PHASE_MODULUS) * ONE_MILLISECOND
+        delay = (s.current_prn_code_phase_shift / 2046) * ONE_MILLISECOND      # tracker.py:319: its own literal
         # --- process_samples, tracker.py:346-353
         s.correlation_peaks_rolling_buffer.append(peak)
         s.correlation_peak_strengths_rolling_buffer.append(strength)
@@ -432,6 +436,7 @@ class Tracker:
                     if rot is not None:
                         s.current_doppler_shift += -np.sign(rot) * WATCHDOG_NUDGE_HZ
                         s.current_carrier_wave_phase_shift += np.sign(rot) * (math.pi / 2)
+                        rec.nudged = True
         return rec
 
 

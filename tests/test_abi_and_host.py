@@ -41,7 +41,7 @@ def test_record_layouts_match_the_header(tmp_path):
     structs = {"gyp_cell_desc": _lib.CELL_DESC, "gyp_cell": _lib.CELL, "gyp_acq_result": _lib.ACQ_RESULT,
                "gyp_chan_in": _lib.CHAN_IN, "gyp_chan_out": _lib.CHAN_OUT, "gyp_chan_init": _lib.CHAN_INIT,
                "gyp_track_rec": _lib.TRACK_REC, "gyp_synth_sat": _lib.SYNTH_SAT, "gyp_bit_event": _lib.BIT_EVENT,
-               "gyp_bits_state": _lib.BITS_STATE, "gyp_best_bin": _lib.BEST_BIN}
+               "gyp_bits_state": _lib.BITS_STATE, "gyp_best_bin": _lib.BEST_BIN, "gyp_params": _lib.PARAMS}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for name, dt in structs.items():
         lines.append(f'printf("{name} size %zu\\n", sizeof({name}));')

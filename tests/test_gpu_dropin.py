@@ -36,8 +36,18 @@ def test_utils_level_seam_matches_oracle():
     assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
     with pytest.raises(ValueError):
         utils.frequency_domain_correlation(one[:-1], prn)
+    # rolled replicas, as tracker.py:289-309 passes them (early / prompt / late)
+    for s in (5, 1, n - 1, 1000):
+        got = utils.frequency_domain_correlation(one, np.roll(prn, s))
+        ref = orc.frequency_domain_correlation(one, np.roll(prn, s))
+        assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+        assert int(np.argmax(np.abs(got))) == int(np.argmax(np.abs(ref)))
+    assert utils.identify_satellite_and_roll(np.roll(prn, 77)) == (19, 77)
     with pytest.raises(NotImplementedError):
-        utils.frequency_domain_correlation(one, np.roll(prn, 5))
+        utils.frequency_domain_correlation(one, -np.roll(prn, 5) * 1j)       # not a +-1 code
+    bad = prn.copy(); bad[3] = -bad[3]
+    with pytest.raises(NotImplementedError):
+        utils.frequency_domain_correlation(one, bad)
 
 
 def test_detector_drop_in_matches_reference_results():
