@@ -1070,7 +1070,10 @@ int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stri
     p.codes = CodeTables{ctx->d_trans, ctx->d_ntrans, ctx->d_chipf};
     {
         const gyp_params& g = ctx->params;
-        p.lp = LoopParams{g.dll_gain, g.dll_phase_modulus, g.pll_bandwidth_locked_hz, g.pll_bandwidth_unlocked_hz,
+        // tracker.py:227-244: alpha = 4 zeta B dt, beta = 4 B^2 dt with zeta = 1/sqrt(2), dt = 1/fs, in the reference's order
+        const double dt = 1.0 / (double)ctx->fs, bl = g.pll_bandwidth_locked_hz, bu = g.pll_bandwidth_unlocked_hz;
+        p.lp = LoopParams{g.dll_gain, g.dll_phase_modulus, 4.0 * (1.0 / std::sqrt(2.0)) * bl * dt, 4.0 * (bl * bl) * dt,
+                          4.0 * (1.0 / std::sqrt(2.0)) * bu * dt, 4.0 * (bu * bu) * dt,
                           g.lock_error_variance_max, g.lock_i_variance_max, g.lock_rotation_max_deg,
                           std::tan(g.lock_rotation_max_deg * M_PI / 180.0),
                           g.watchdog_period_s, g.watchdog_drop_below, g.watchdog_nudge_below, g.watchdog_nudge_hz, (double)ctx->n};

@@ -1336,7 +1336,7 @@ __device__ __forceinline__ double pymod(double a, double b) {
 // The tunables of the reference's loops (gyp_params; tracker.py:157-203, 227-262, 297-303, 370-387, config.py:23-25).
 struct LoopParams {
     double dll_gain, dll_modulus;
-    double bw_locked, bw_unlocked;
+    double alpha_locked, beta_locked, alpha_unlocked, beta_unlocked;   // tracker.py:227-244 for the two bandwidths, formed on the host
     double err_var_max, i_var_max, rot_deg, rot_tan;     // rot_tan = tan(rot_deg)
     double wd_period, wd_drop, wd_nudge, wd_nudge_hz;
     double n_samples;                                      // samples per millisecond
@@ -1397,7 +1397,8 @@ __device__ __forceinline__ LockVerdict lock_from_sums(const LockSums& s, int64_t
 // Out of line (it runs about once per thousand milliseconds): inlined, its dozens of live float64 values raise the
 // register pressure of every tracking loop that contains it.
 __device__ __attribute__((noinline)) bool is_locked_exact_wave(const ChanState* st, int64_t n_err, int64_t n_peaks, int lane,
-                                                               LockSums& fresh, const LoopParams& lp) {
+                                                               LockSums& fresh, double err_var_max, double i_var_max, double rot_deg) {
+    // (the thresholds by value: a reference into the kernel's parameter block would force the block into scratch memory)
     const int e_newest = (int)((n_err - 1 + kLockWindow) % kLockWindow), p_newest = (int)((n_peaks - 1) % kPeakHistory);
     const int ne = (int)(n_err < kLockWindow ? n_err : kLockWindow);
     const int np = (int)(n_peaks < kLockWindow ? n_peaks : kLockWindow);
@@ -1446,7 +1447,7 @@ __device__ __attribute__((noinline)) bool is_locked_exact_wave(const ChanState* 
     const double mr = fresh.cn >= 2 ? fresh.nr / fresh.cn : 0.0, mi = fresh.cn >= 2 ? fresh.ni / fresh.cn : 0.0;
     const double ang = 180.0 - pymod((atan2(mi, mr) / 6.283185307179586) * 360.0, 180.0);
     const double centered = ang < 90.0 ? ang : 180.0 - ang;
-    return ve < lp.err_var_max && (vneg + vpos) / 2.0 < lp.i_var_max && centered < lp.rot_deg;
+    return ve < err_var_max && (vneg + vpos) / 2.0 < i_var_max && centered < rot_deg;
 }
 
 // utils.py:134-144 circularity and :119-131 rotation over the last min(n_peaks, 1000) peaks, by wavefront 0.
@@ -1607,13 +1608,11 @@ __device__ __forceinline__ void costas_update(const TrackBlockParams& p, ChanSta
     if (uniform(lv.marginal || pos_refresh == kLockRefresh - 1)) {
         workgroup_mem_fence_wave();                 // lane 0's ring stores -> every lane of this wavefront
         LockSums fresh;
-        locked = is_locked_exact_wave(st, n, n + 1, lane, fresh, lp);
+        locked = is_locked_exact_wave(st, n, n + 1, lane, fresh, lp.err_var_max, lp.i_var_max, lp.rot_deg);
         sums = fresh;
     }
-    const double bw = locked ? lp.bw_locked : lp.bw_unlocked;
-    const double tps = p.inv_fs;                // == 1.0 / samples_per_second, formed on the host
-    const double alpha = 4.0 * (1.0 / sqrt(2.0)) * bw * tps;
-    const double beta = 4.0 * (bw * bw) * tps;
+    const double alpha = locked ? lp.alpha_locked : lp.alpha_unlocked;
+    const double beta = locked ? lp.beta_locked : lp.beta_unlocked;
     double nphi = pymod_uniform(phi + err * alpha, 6.283185307179586);
     double nf = f + err * beta;
     // the error joins its window after is_locked() has been evaluated (tracker.py:251,261)
@@ -1679,11 +1678,8 @@ __device__ __forceinline__ void rec_flush(const RedScratch* red, gyp_track_rec* 
 // ---- the Costas half again, split three ways for the speculative tracker (see RedScratch::cc) ----------------
 // One candidate: tracker.py:246-262 with the given loop bandwidth.
 __device__ __forceinline__ void costas_candidate(const TrackBlockParams& p, RedScratch* red, cf peak, double f, double phi,
-                                                 double bw, int slot, int lane) {
+                                                 double alpha, double beta, int slot, int lane) {
     const double err = (double)peak.x * (double)peak.y;
-    const double tps = p.inv_fs;
-    const double alpha = 4.0 * (1.0 / sqrt(2.0)) * bw * tps;
-    const double beta = 4.0 * (bw * bw) * tps;
     const double nphi = pymod_uniform(phi + err * alpha, 6.283185307179586);
     const double nf = f + err * beta;
     const double2 rot = carrier64_small(nf * p.inv_fs);
@@ -1748,7 +1744,7 @@ __device__ __forceinline__ void verdict_finish(const TrackBlockParams& p, ChanSt
     if (uniform(marginal || pos_refresh == kLockRefresh - 1)) {
         workgroup_mem_fence_wave();
         LockSums fresh;
-        locked = is_locked_exact_wave(st, n, n + 1, lane, fresh, p.lp);
+        locked = is_locked_exact_wave(st, n, n + 1, lane, fresh, p.lp.err_var_max, p.lp.i_var_max, p.lp.rot_deg);
         sums = fresh;
     }
     sums.se -= n >= kLockWindow ? v.leave_e : 0.0; sums.see -= n >= kLockWindow ? v.leave_e * v.leave_e : 0.0;
@@ -1767,9 +1763,8 @@ __device__ __forceinline__ void verdict_finish(const TrackBlockParams& p, ChanSt
         if (cs[0] >= 0.0) {
             if (cs[0] < p.lp.wd_drop) { status = 1; lost = 1; }
             else if (cs[0] < p.lp.wd_nudge && cs[2] != 0.0) {
-                const double bw = locked ? p.lp.bw_locked : p.lp.bw_unlocked, tps = p.inv_fs;
-                double nphi = pymod_uniform(phi + err * (4.0 * (1.0 / sqrt(2.0)) * bw * tps), 6.283185307179586);
-                double nf = f + err * (4.0 * (bw * bw) * tps);
+                double nphi = pymod_uniform(phi + err * (locked ? p.lp.alpha_locked : p.lp.alpha_unlocked), 6.283185307179586);
+                double nf = f + err * (locked ? p.lp.beta_locked : p.lp.beta_unlocked);
                 const double sg = cs[1] > 0.0 ? 1.0 : (cs[1] < 0.0 ? -1.0 : 0.0);
                 nf += -sg * p.lp.wd_nudge_hz;
                 nphi += sg * (3.141592653589793 / 2.0);
@@ -2189,8 +2184,8 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         if constexpr (SPEC) {
             if (wave == 0) verdict_finish<K>(p, st, sm.red, t0, lane, m, f, phi);
             if (wave == 1) dll_update(sm.red, m.disc, lane, p.lp);
-            if (wave == 2) costas_candidate(p, sm.red, m.peak, f, phi, p.lp.bw_locked, 0, lane);
-            if (wave == 3) costas_candidate(p, sm.red, m.peak, f, phi, p.lp.bw_unlocked, 1, lane);
+            if (wave == 2) costas_candidate(p, sm.red, m.peak, f, phi, p.lp.alpha_locked, p.lp.beta_locked, 0, lane);
+            if (wave == 3) costas_candidate(p, sm.red, m.peak, f, phi, p.lp.alpha_unlocked, p.lp.beta_unlocked, 1, lane);
         } else if (wave == 0) {
             fetch_leaving(st, sm.red, leave);
             dll_update(sm.red, m.disc, lane, p.lp);

@@ -206,7 +206,7 @@ def test_code_phase_beyond_int32(engine_factory):
     and the prompt it is built on is float32.)"""
     fs, n = 2_046_000, 2046
     eng = engine_factory(fs, n)
-    scene = synth.random_scene(fs, 6, 1, 5150, amplitude=3.0e4, noise_sigma=1.0e3)
+    scene = synth.random_scene(fs, 6, 1, 5150, amplitude=1.5e5, noise_sigma=5.0e3)
     iq = synth.render(scene)
     s = scene.sats[0]
     inits = np.zeros(1, dtype=_lib.CHAN_INIT)
