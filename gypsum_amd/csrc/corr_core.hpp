@@ -455,13 +455,10 @@ template <int K>
 __device__ __forceinline__ void stage_fetch_own(const cf* __restrict__ block, OwnSamples<K>& s, int tid) {
 #pragma unroll
     for (int c = 0; c < OwnSamples<K>::CH; ++c) {
-        const int m = tid + c * OwnSamples<K>::T;
-        if (m < kChips) {
-            load_samples<K>(block + K * m, s.w[c]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < K; ++i) s.w[c][i] = make_float2(0.f, 0.f);   // the padding chip: S = P = 0
-        }
+        // the padding chip (m == 1023, one thread's last chip) re-reads chip 1022: stage_emit_own_anchored wipes it with a
+        // zero carrier, so that S = P = 0 without a branch or sixteen register clears in every thread
+        const int m = c + 1 < OwnSamples<K>::CH ? tid + c * OwnSamples<K>::T : min(tid + c * OwnSamples<K>::T, kChips - 1);
+        load_samples<K>(block + K * m, s.w[c]);
     }
 }
 __device__ __forceinline__ cf next_lane(cf v) {   // lane i <- lane i+1, lane 63 <- 0
@@ -480,6 +477,10 @@ __device__ __forceinline__ void stage_emit_own_anchored(OwnSamples<K>& s, const 
         const int m = tid + c * OwnSamples<K>::T;   // m == kChips (padding chip) carries zeros: writes y_r[1023] = 0
         cf (&w)[K] = s.w[c];
         cf car = anchor[c];
+        if (c + 1 == OwnSamples<K>::CH) {   // see stage_fetch_own
+            car.x = m < kChips ? car.x : 0.f;
+            car.y = m < kChips ? car.y : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             w[i] = cmul(w[i], car);

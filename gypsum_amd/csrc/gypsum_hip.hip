@@ -97,7 +97,9 @@ static void make_replica_lane_layout(const uint8_t* chips, float* out /*32*64*2*
 // context
 // ---------------------------------------------------------------------------------------------------------
 // samples per chip (multiples of 1.023 MHz) the kernels are instantiated for
+#ifndef GYP_FOR_EACH_RATE   // a development build may pass a shorter list (-D'GYP_FOR_EACH_RATE(X)=X(2) X(8)'): fewer instantiations
 #define GYP_FOR_EACH_RATE(X) X(1) X(2) X(3) X(4) X(5) X(6) X(8) X(10) X(12) X(16) X(20) X(48)
+#endif
 static bool rate_supported(int k) {
     switch (k) {
 #define X(K) case K:

@@ -1677,13 +1677,13 @@ __device__ __forceinline__ void rec_flush(const RedScratch* red, gyp_track_rec* 
 
 // ---- the Costas half again, split three ways for the speculative tracker (see RedScratch::cc) ----------------
 // One candidate: tracker.py:246-262 with the given loop bandwidth.
-__device__ __forceinline__ void costas_candidate(const TrackBlockParams& p, RedScratch* red, cf peak, double f, double phi,
+__device__ __forceinline__ void costas_candidate(double inv_fs, RedScratch* red, cf peak, double f, double phi,
                                                  double alpha, double beta, int slot, int lane) {
     const double err = (double)peak.x * (double)peak.y;
     const double nphi = pymod_uniform(phi + err * alpha, 6.283185307179586);
     const double nf = f + err * beta;
-    const double2 rot = carrier64_small(nf * p.inv_fs);
-    const cf step = carrier_from_cycles_fast(nf * p.inv_fs * 4096.0);
+    const double2 rot = carrier64_small(nf * inv_fs);
+    const cf step = carrier_from_cycles_fast(nf * inv_fs * 4096.0);
     if (lane == 0) {
         red->cc[slot].nf = nf; red->cc[slot].nphi = nphi;
         red->cc[slot].rot1 = make_float2((float)rot.x, (float)rot.y);
@@ -1711,7 +1711,7 @@ __device__ __forceinline__ void verdict_prepare(RedScratch* red, const double (&
     }
 }
 template <int K>
-__device__ __forceinline__ void verdict_finish(const TrackBlockParams& p, ChanState* st, RedScratch* red, double t0, int lane,
+__device__ __forceinline__ void verdict_finish(const LoopParams& lp, double inv_fs, ChanState* st, RedScratch* red, double t0, int lane,
                                                const MsMeasure& r, double f, double phi) {
     constexpr int N = K * kChips;
     int lost = 0;
@@ -1732,9 +1732,9 @@ __device__ __forceinline__ void verdict_finish(const TrackBlockParams& p, ChanSt
         const bool n2 = sums.cn >= 2, p2 = sums.cp >= 2;
         const double a = n2 ? sums.nrr * cn - sums.nr * sums.nr : 0.0, b = p2 ? sums.prr * cp - sums.pr * sums.pr : 0.0;
         const double cn2 = n2 ? cn * cn : 1.0, cp2 = p2 ? cp * cp : 1.0;
-        const double xi = a * cp2 + b * cn2, ti = 2.0 * p.lp.i_var_max * cn2 * cp2;
+        const double xi = a * cp2 + b * cn2, ti = 2.0 * lp.i_var_max * cn2 * cp2;
         const bool i_ok = xi < ti;
-        const double lhs = fabs(sums.ni), rhs = p.lp.rot_tan * fabs(sums.nr);
+        const double lhs = fabs(sums.ni), rhs = lp.rot_tan * fabs(sums.nr);
         const bool rot_tested = v.var_ok && i_ok && n2;
         const bool rot_ok = !rot_tested || lhs < rhs;
         const bool full = n >= kLockWindow;
@@ -1744,7 +1744,7 @@ __device__ __forceinline__ void verdict_finish(const TrackBlockParams& p, ChanSt
     if (uniform(marginal || pos_refresh == kLockRefresh - 1)) {
         workgroup_mem_fence_wave();
         LockSums fresh;
-        locked = is_locked_exact_wave(st, n, n + 1, lane, fresh, p.lp.err_var_max, p.lp.i_var_max, p.lp.rot_deg);
+        locked = is_locked_exact_wave(st, n, n + 1, lane, fresh, lp.err_var_max, lp.i_var_max, lp.rot_deg);
         sums = fresh;
     }
     sums.se -= n >= kLockWindow ? v.leave_e : 0.0; sums.see -= n >= kLockWindow ? v.leave_e * v.leave_e : 0.0;
@@ -1755,23 +1755,23 @@ __device__ __forceinline__ void verdict_finish(const TrackBlockParams& p, ChanSt
     pos_refresh = pos_refresh + 1 == kLockRefresh ? 0 : pos_refresh + 1;
     int status = 0, nudged = 0, sel = locked ? 0 : 1;
     const int rec_sel = sel;                    // the record carries the values before any watchdog nudge
-    if (uniform(t0 - last_watchdog >= p.lp.wd_period)) {
+    if (uniform(t0 - last_watchdog >= lp.wd_period)) {
         workgroup_mem_fence_wave();
         double cs[3];
         constellation_stats_wave(st, n + 1, lane, cs);
         last_watchdog = t0;
         if (cs[0] >= 0.0) {
-            if (cs[0] < p.lp.wd_drop) { status = 1; lost = 1; }
-            else if (cs[0] < p.lp.wd_nudge && cs[2] != 0.0) {
-                double nphi = pymod_uniform(phi + err * (locked ? p.lp.alpha_locked : p.lp.alpha_unlocked), 6.283185307179586);
-                double nf = f + err * (locked ? p.lp.beta_locked : p.lp.beta_unlocked);
+            if (cs[0] < lp.wd_drop) { status = 1; lost = 1; }
+            else if (cs[0] < lp.wd_nudge && cs[2] != 0.0) {
+                double nphi = pymod_uniform(phi + err * (locked ? lp.alpha_locked : lp.alpha_unlocked), 6.283185307179586);
+                double nf = f + err * (locked ? lp.beta_locked : lp.beta_unlocked);
                 const double sg = cs[1] > 0.0 ? 1.0 : (cs[1] < 0.0 ? -1.0 : 0.0);
-                nf += -sg * p.lp.wd_nudge_hz;
+                nf += -sg * lp.wd_nudge_hz;
                 nphi += sg * (3.141592653589793 / 2.0);
                 nudged = 1;
                 sel = 2;
-                const double2 rot = carrier64_small(nf * p.inv_fs);
-                const cf step = carrier_from_cycles_fast(nf * p.inv_fs * 4096.0);
+                const double2 rot = carrier64_small(nf * inv_fs);
+                const cf step = carrier_from_cycles_fast(nf * inv_fs * 4096.0);
                 if (lane == 0) {
                     red->cc[2].nf = nf; red->cc[2].nphi = nphi;
                     red->cc[2].rot1 = make_float2((float)rot.x, (float)rot.y);
@@ -1817,11 +1817,22 @@ constexpr int kSpecFinBytes = 256;               // fin64[8], win16 below
 constexpr int kSpecWinBytes = 32 * 8;
 constexpr int kSpecChipBytes = 2048 * 4;
 constexpr int kSpecTransBytes = kMaxTrans * 2;
+// The loop constants of the launch, copied to LDS once: as kernel arguments they sit in ~40 scalar registers which the
+// allocator spills to vector-register lanes and restores sixteen at a time (v_readlane) around every use -- a quarter of
+// the loop-update section's instructions.  A uniform-address LDS read costs one instruction per field.
+struct SpecConst {
+    LoopParams lp;
+    double inv_fs;
+};
+constexpr int kSpecConstBytes = 128;
+static_assert(sizeof(SpecConst) <= kSpecConstBytes, "SpecConst");
 template <int K>
 constexpr int lds_bytes_spec() {
-    return lds_bytes<K>() + kTablesBytes + kSpecChipBytes + kSpecTransBytes + kSpecPartBytes + kSpecEinBytes + kSpecFinBytes + kSpecWinBytes;
+    return lds_bytes<K>() + kTablesBytes + kSpecChipBytes + kSpecTransBytes + kSpecPartBytes + kSpecEinBytes + kSpecFinBytes + kSpecWinBytes +
+           kSpecConstBytes;
 }
 struct SpecLds {
+    const SpecConst* k;
     float* chipf;     // [2048] +-1.0f, this channel's code twice over
     uint16_t* trans;  // [kMaxTrans] this channel's chip transitions
     double* part;     // [4][512]
@@ -1867,13 +1878,14 @@ __device__ __forceinline__ void spec_window(const Smem& sm, const SpecLds& sl, i
     }
     const cf* row = sm.xch + rw * kXchWave + lane;
     float ar = 0.f, ai = 0.f;
+    {   // all seventeen LDS reads are in flight before the first product (one exposed latency instead of eight)
+        cf y[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const cf y = row[64 * k];
-        ar = fmaf(wc.c[k], y.x, ar); ai = fmaf(wc.c[k], y.y, ai);
-    }
-    {
+        for (int k = 0; k < 16; ++k) y[k] = row[64 * k];
         const cf hv = sm.halo[hrow + rw];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { ar = fmaf(wc.c[k], y[k].x, ar); ai = fmaf(wc.c[k], y[k].y, ai); }
         ar = fmaf(wc.ch, hv.x, ar); ai = fmaf(wc.ch, hv.y, ai);
     }
     ar = wave_sum_last(ar); ai = wave_sum_last(ai);
@@ -1952,7 +1964,10 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         sl.part = reinterpret_cast<double*>(b); b += kSpecPartBytes;
         sl.ein_part = reinterpret_cast<float*>(b); b += kSpecEinBytes;
         sl.fin = reinterpret_cast<double*>(b); b += kSpecFinBytes;
-        sl.win = reinterpret_cast<cf*>(b);
+        sl.win = reinterpret_cast<cf*>(b); b += kSpecWinBytes;
+        SpecConst* k = reinterpret_cast<SpecConst*>(b);
+        if (threadIdx.x == 0) { k->lp = p.lp; k->inv_fs = p.inv_fs; }
+        sl.k = k;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
@@ -2053,7 +2068,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         }
         {
             const int code_phase = sm.red->istate[0];
-            const double u0 = f * t0 + phi * 0.15915494309189533577, du = f * p.inv_fs;
+            const double u0 = f * t0 + phi * 0.15915494309189533577, du = f * (SPEC ? sl.k->inv_fs : p.inv_fs);
             const cf* block = stream + (int64_t)ms * N;
             if constexpr (SPEC) {
                 const int tid = launder(threadIdx.x);
@@ -2067,10 +2082,12 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
                 el1.nl = -1;
                 if (nt > Geom<K>::kThreads) el1 = el_fetch_const<K>(block, sN, el_off1, el_g1);   // uniform
                 GYP_STAMP(1);
+                // (the last thread's second chip is the padding chip: its registers hold a copy of chip 1022, see stage_fetch_own)
+                const bool chip1 = tid + OwnSamples<K>::T < kChips;
                 const float e_in = (smp.w[0][0].x * smp.w[0][0].x + smp.w[0][0].y * smp.w[0][0].y) +
                                    (smp.w[0][4].x * smp.w[0][4].x + smp.w[0][4].y * smp.w[0][4].y) +
-                                   (smp.w[1][0].x * smp.w[1][0].x + smp.w[1][0].y * smp.w[1][0].y) +
-                                   (smp.w[1][4].x * smp.w[1][4].x + smp.w[1][4].y * smp.w[1][4].y);
+                                   (chip1 ? smp.w[1][0].x * smp.w[1][0].x + smp.w[1][0].y * smp.w[1][0].y : 0.f) +
+                                   (chip1 ? smp.w[1][4].x * smp.w[1][4].x + smp.w[1][4].y * smp.w[1][4].y : 0.f);
                 cf* y_rows[K];
 #pragma unroll
                 for (int r = 0; r < K; ++r) y_rows[r] = sm.xch + r * kXchWave;
@@ -2095,7 +2112,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
                 // wavefront 0: the ring entries leaving the lock windows were requested at the top of the millisecond and are
                 // consumed here, BEFORE the next millisecond's samples are requested -- the vector-memory counter retires
                 // in order, so a later wait for those three loads would also wait for the eight sample loads behind them
-                if (wave == 0) verdict_prepare(sm.red, leave, lane, p.lp);
+                if (wave == 0) verdict_prepare(sm.red, leave, lane, sl.k->lp);
                 // the raw samples are consumed: request the next millisecond now, the loads fly under the window sums
                 if (ms + 1 < p.ms_end) stage_fetch_own<K>(stream + (int64_t)(ms + 1) * N, smp, launder(threadIdx.x));
                 if (prof) t_b = (long long)__builtin_readcyclecounter();
@@ -2182,10 +2199,10 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         GYP_STAMP(8);
         asm volatile("; MARK_UPDATE_BEGIN");
         if constexpr (SPEC) {
-            if (wave == 0) verdict_finish<K>(p, st, sm.red, t0, lane, m, f, phi);
-            if (wave == 1) dll_update(sm.red, m.disc, lane, p.lp);
-            if (wave == 2) costas_candidate(p, sm.red, m.peak, f, phi, p.lp.alpha_locked, p.lp.beta_locked, 0, lane);
-            if (wave == 3) costas_candidate(p, sm.red, m.peak, f, phi, p.lp.alpha_unlocked, p.lp.beta_unlocked, 1, lane);
+            if (wave == 0) verdict_finish<K>(sl.k->lp, sl.k->inv_fs, st, sm.red, t0, lane, m, f, phi);
+            if (wave == 1) dll_update(sm.red, m.disc, lane, sl.k->lp);
+            if (wave == 2) costas_candidate(sl.k->inv_fs, sm.red, m.peak, f, phi, sl.k->lp.alpha_locked, sl.k->lp.beta_locked, 0, lane);
+            if (wave == 3) costas_candidate(sl.k->inv_fs, sm.red, m.peak, f, phi, sl.k->lp.alpha_unlocked, sl.k->lp.beta_unlocked, 1, lane);
         } else if (wave == 0) {
             fetch_leaving(st, sm.red, leave);
             dll_update(sm.red, m.disc, lane, p.lp);
