@@ -38,6 +38,17 @@ __device__ __forceinline__ int launder(int v) {
     asm volatile("" : "+v"(v));
     return v;
 }
+// The same for a pointer into LDS: the address goes through a vector register here, so that the fields behind it are
+// addressed as `base + immediate` where they are used.  Left alone, LLVM hoists every field address of a loop-invariant
+// LDS struct into its own scalar register, runs out of them, spills them to vector-register lanes and pays
+// v_readlane + v_mov per access (a third of the instructions of the loop-update code was that).
+template <typename T>
+__device__ __forceinline__ T* launder_lds(T* p) {
+    typedef __attribute__((address_space(3))) T* lds_ptr;
+    unsigned a = (unsigned)(size_t)(lds_ptr)p;
+    asm volatile("" : "+v"(a));
+    return (T*)(lds_ptr)(size_t)a;
+}
 // Forces the 32 values to be materialised at this point of the program: without it LLVM sinks pure VALU work (a
 // whole FFT32 + the spectrum multiply) below a later conditional block, which puts that block's loads -- and the
 // s_waitcnt the register allocator's copies need -- in front of the arithmetic they were meant to overlap.

@@ -89,7 +89,11 @@ struct RedScratch {
     // speculative tracker: the Costas update for either loop bandwidth is formed by its own wavefront while a third works
     // out the lock verdict; cand_sel says which one the next millisecond runs with (2: the watchdog's nudged values)
     // verdict_prepare -> verdict_finish hand-over (kept here rather than in registers across the window barrier)
-    struct VerdictPrepLds { LockSums sums; double leave_e; int32_t var_ok, var_marginal; } vprep;
+    struct VerdictPrepLds {
+        double nr, ni, nrr, pr, prr; int32_t cn, cp;   // pole side: the pole sums with the leaving peak removed
+        double leave_e; int32_t var_ok, var_marginal;    // error side
+    } vprep;
+    int32_t defer, pad3;   // 1: the last millisecond's error has not joined se / see and its ring entries are not stored yet
     struct CostasCand { double nf, nphi; cf rot1; cf step; } cc[3];   // step: the carrier over 4096 samples (second chip of a thread)
     int cand_sel, rec_sel, pad2[2];
 };
@@ -1690,42 +1694,87 @@ __device__ __forceinline__ void costas_candidate(double inv_fs, RedScratch* red,
         red->cc[slot].step = step;
     }
 }
-// Everything else of costas_update -- histories, lock verdict, watchdog, the record's fields -- in two steps: what does
-// not depend on this millisecond's peak (state read, the entries leaving the windows, the error-variance test, which
-// is_locked() evaluates before the new error joins) is done while the window sums are still being formed.
-__device__ __forceinline__ void verdict_prepare(RedScratch* red, const double (&leave)[3], int lane, const LoopParams& lp) {
-    const int64_t n = red->loop.n_steps;
-    LockSums s = red->loop.sums;
-    const double leave_pr = leave[1], leave_pi = leave[2];
-    const bool full = n >= kLockWindow;
-    const bool ln = full && leave_pr < 0.0, lpos = full && !(leave_pr < 0.0);
-    s.nr -= ln ? leave_pr : 0.0; s.ni -= ln ? leave_pi : 0.0; s.nrr -= ln ? leave_pr * leave_pr : 0.0; s.cn -= ln ? 1 : 0;
-    s.pr -= lpos ? leave_pr : 0.0; s.prr -= lpos ? leave_pr * leave_pr : 0.0; s.cp -= lpos ? 1 : 0;
+// Everything else of costas_update -- histories, lock verdict, watchdog, the record's fields -- arranged so that ONLY the
+// lock verdict (it selects the loop bandwidth of the next wipe-off) sits between a millisecond's peak and the next
+// millisecond's staging:
+//   window phase of ms  wavefront 0 (error side): stores ms-1's ring entries and lets ms-1's error join se/see if that was
+//                       deferred, then the error-variance test of ms (is_locked() evaluates it before the new error joins);
+//                       wavefront 1 (pole side): removes the peak leaving the window from the pole sums, flushes ms-1's record;
+//   update phase of ms  wavefront 0: the new peak joins the pole sums, pole-variance and rotation tests -> locked, cand_sel.
+//                       Anything rare -- a test within 1e-9 of its threshold or the 1024-ms refresh (exact two-pass
+//                       evaluation), the 6-second watchdog -- takes the slow path, which completes the millisecond's
+//                       histories on the spot exactly as costas_update orders them; otherwise they are deferred (above);
+//                       wavefront 4 (idle otherwise) assembles the record's fields.
+// The rings are only ever written by wavefront 0, so its own fence orders them for the slow path's reads.
+__device__ __forceinline__ void spec_error_side(ChanState* st, RedScratch* red_, double leave_e, int lane, const LoopParams& lp) {
+    RedScratch* red = launder_lds(red_);
+    const int64_t n = red->loop.n_steps;            // steps before this millisecond
+    double se = red->loop.sums.se, see = red->loop.sums.see;
+    if (uniform(red->defer != 0)) {                 // the previous millisecond (step n-1) took the fast path
+        const double e = red->rec.error, pr = (double)red->rec.peak_re, pim = (double)red->rec.peak_im;
+        const double le = red->vprep.leave_e;       // still the previous millisecond's
+        const int pos_e = red->loop.pos_e, pos_p = red->loop.pos_p;
+        const int pe = pos_e == 0 ? kLockWindow - 1 : pos_e - 1, pp = pos_p == 0 ? kPeakHistory - 1 : pos_p - 1;
+        if (lane == 0) { st->peak_re[pp] = pr; st->peak_im[pp] = pim; st->err_ring[pe] = e; }
+        const bool full = n - 1 >= kLockWindow;
+        se -= full ? le : 0.0; see -= full ? le * le : 0.0;
+        se += e; see += e * e;
+    }
     constexpr double W = (double)kLockWindow;
-    const double xe = s.see * W - s.se * s.se, te = lp.err_var_max * W * W;     // see lock_from_sums
+    const double xe = see * W - se * se, te = lp.err_var_max * W * W;     // see lock_from_sums
     if (lane == 0) {
-        red->vprep.sums = s;                       // the leaving peak already removed
-        red->vprep.leave_e = leave[0];
+        red->loop.sums.se = se; red->loop.sums.see = see;
+        red->defer = 0;
+        red->vprep.leave_e = leave_e;
         red->vprep.var_ok = xe < te ? 1 : 0;
         red->vprep.var_marginal = fabs(xe - te) <= 1e-9 * te ? 1 : 0;
     }
 }
+__device__ __forceinline__ void spec_pole_side(RedScratch* red_, double leave_pr, double leave_pi, int lane) {
+    RedScratch* red = launder_lds(red_);
+    const int64_t n = red->loop.n_steps;
+    LockSums s = red->loop.sums;                    // (se / see are the error side's: not used here)
+    const bool full = n >= kLockWindow;
+    const bool ln = full && leave_pr < 0.0, lpos = full && !(leave_pr < 0.0);
+    s.nr -= ln ? leave_pr : 0.0; s.ni -= ln ? leave_pi : 0.0; s.nrr -= ln ? leave_pr * leave_pr : 0.0; s.cn -= ln ? 1 : 0;
+    s.pr -= lpos ? leave_pr : 0.0; s.prr -= lpos ? leave_pr * leave_pr : 0.0; s.cp -= lpos ? 1 : 0;
+    if (lane == 0) {
+        red->vprep.nr = s.nr; red->vprep.ni = s.ni; red->vprep.nrr = s.nrr; red->vprep.pr = s.pr; red->vprep.prr = s.prr;
+        red->vprep.cn = s.cn; red->vprep.cp = s.cp;
+    }
+}
+// The entries leaving the 250-ms windows in this millisecond's update, one side each (see fetch_leaving).
+__device__ __forceinline__ double fetch_leaving_error(const ChanState* st, const RedScratch* red) {
+    return red->loop.n_steps >= kLockWindow ? st->err_ring[red->loop.pos_e] : 0.0;
+}
+__device__ __forceinline__ void fetch_leaving_peak(const ChanState* st, const RedScratch* red, double& re, double& im) {
+    re = im = 0.0;
+    if (red->loop.n_steps >= kLockWindow) {
+        const int pos_p = red->loop.pos_p;
+        const int pos_leave = pos_p >= kLockWindow ? pos_p - kLockWindow : pos_p - kLockWindow + kPeakHistory;
+        re = st->peak_re[pos_leave];
+        im = st->peak_im[pos_leave];
+    }
+}
 template <int K>
-__device__ __forceinline__ void verdict_finish(const LoopParams& lp, double inv_fs, ChanState* st, RedScratch* red, double t0, int lane,
-                                               const MsMeasure& r, double f, double phi) {
-    constexpr int N = K * kChips;
+__device__ __forceinline__ void spec_lock_verdict(const LoopParams& lp, double inv_fs, ChanState* st, RedScratch* red_, double t0, int lane,
+                                                  cf peak, double f, double phi) {
+    RedScratch* red = launder_lds(red_);
     int lost = 0;
     const int64_t n = red->loop.n_steps;
     double last_watchdog = red->loop.last_watchdog;
-    LockSums sums = red->vprep.sums;
+    LockSums sums;
+    sums.se = red->loop.sums.se; sums.see = red->loop.sums.see;   // through the previous millisecond's error
+    sums.nr = red->vprep.nr; sums.ni = red->vprep.ni; sums.nrr = red->vprep.nrr; sums.pr = red->vprep.pr; sums.prr = red->vprep.prr;
+    sums.cn = red->vprep.cn; sums.cp = red->vprep.cp;            // the leaving peak already removed
     struct { bool var_ok, var_marginal; double leave_e; } v{red->vprep.var_ok != 0, red->vprep.var_marginal != 0, red->vprep.leave_e};
     int pos_e = red->loop.pos_e, pos_p = red->loop.pos_p, pos_refresh = red->loop.pos_refresh;
-    const double pr = (double)r.peak.x, pim = (double)r.peak.y;
-    if (lane == 0) { st->peak_re[pos_p] = pr; st->peak_im[pos_p] = pim; }
+    const double pr = (double)peak.x, pim = (double)peak.y;
     const bool nn = pr < 0.0;
     sums.nr += nn ? pr : 0.0; sums.ni += nn ? pim : 0.0; sums.nrr += nn ? pr * pr : 0.0; sums.cn += nn ? 1 : 0;
     sums.pr += nn ? 0.0 : pr; sums.prr += nn ? 0.0 : pr * pr; sums.cp += nn ? 0 : 1;
     const double err = pr * pim;
+    const bool full = n >= kLockWindow;
     bool locked, marginal;
     {   // the pole half of lock_from_sums
         const double cn = (double)sums.cn, cp = (double)sums.cp;
@@ -1737,71 +1786,100 @@ __device__ __forceinline__ void verdict_finish(const LoopParams& lp, double inv_
         const double lhs = fabs(sums.ni), rhs = lp.rot_tan * fabs(sums.nr);
         const bool rot_tested = v.var_ok && i_ok && n2;
         const bool rot_ok = !rot_tested || lhs < rhs;
-        const bool full = n >= kLockWindow;
         marginal = full && (v.var_marginal || fabs(xi - ti) <= 1e-9 * ti || (rot_tested && fabs(lhs - rhs) <= 1e-9 * (lhs + rhs)));
         locked = full && v.var_ok && i_ok && rot_ok;
     }
-    if (uniform(marginal || pos_refresh == kLockRefresh - 1)) {
-        workgroup_mem_fence_wave();
-        LockSums fresh;
-        locked = is_locked_exact_wave(st, n, n + 1, lane, fresh, lp.err_var_max, lp.i_var_max, lp.rot_deg);
-        sums = fresh;
-    }
-    sums.se -= n >= kLockWindow ? v.leave_e : 0.0; sums.see -= n >= kLockWindow ? v.leave_e * v.leave_e : 0.0;
-    sums.se += err; sums.see += err * err;
-    if (lane == 0) st->err_ring[pos_e] = err;
-    pos_e = pos_e + 1 == kLockWindow ? 0 : pos_e + 1;
-    pos_p = pos_p + 1 == kPeakHistory ? 0 : pos_p + 1;
-    pos_refresh = pos_refresh + 1 == kLockRefresh ? 0 : pos_refresh + 1;
-    int status = 0, nudged = 0, sel = locked ? 0 : 1;
-    const int rec_sel = sel;                    // the record carries the values before any watchdog nudge
-    if (uniform(t0 - last_watchdog >= lp.wd_period)) {
-        workgroup_mem_fence_wave();
-        double cs[3];
-        constellation_stats_wave(st, n + 1, lane, cs);
-        last_watchdog = t0;
-        if (cs[0] >= 0.0) {
-            if (cs[0] < lp.wd_drop) { status = 1; lost = 1; }
-            else if (cs[0] < lp.wd_nudge && cs[2] != 0.0) {
-                double nphi = pymod_uniform(phi + err * (locked ? lp.alpha_locked : lp.alpha_unlocked), 6.283185307179586);
-                double nf = f + err * (locked ? lp.beta_locked : lp.beta_unlocked);
-                const double sg = cs[1] > 0.0 ? 1.0 : (cs[1] < 0.0 ? -1.0 : 0.0);
-                nf += -sg * lp.wd_nudge_hz;
-                nphi += sg * (3.141592653589793 / 2.0);
-                nudged = 1;
-                sel = 2;
-                const double2 rot = carrier64_small(nf * inv_fs);
-                const cf step = carrier_from_cycles_fast(nf * inv_fs * 4096.0);
-                if (lane == 0) {
-                    red->cc[2].nf = nf; red->cc[2].nphi = nphi;
-                    red->cc[2].rot1 = make_float2((float)rot.x, (float)rot.y);
-                    red->cc[2].step = step;
+    const bool exact = marginal || pos_refresh == kLockRefresh - 1;
+    const bool watchdog = t0 - last_watchdog >= lp.wd_period;
+    int status = 0, nudged = 0, sel, rec_sel;
+    if (uniform(exact || watchdog)) {
+        // the slow path: this millisecond's histories now, in costas_update's order (tracker.py:346-389)
+        if (lane == 0) { st->peak_re[pos_p] = pr; st->peak_im[pos_p] = pim; }
+        if (uniform(exact)) {
+            workgroup_mem_fence_wave();
+            LockSums fresh;
+            locked = is_locked_exact_wave(st, n, n + 1, lane, fresh, lp.err_var_max, lp.i_var_max, lp.rot_deg);
+            sums = fresh;
+        }
+        sums.se -= full ? v.leave_e : 0.0; sums.see -= full ? v.leave_e * v.leave_e : 0.0;
+        sums.se += err; sums.see += err * err;
+        if (lane == 0) st->err_ring[pos_e] = err;
+        sel = locked ? 0 : 1;
+        rec_sel = sel;                              // the record carries the values before any watchdog nudge
+        if (uniform(watchdog)) {
+            workgroup_mem_fence_wave();
+            double cs[3];
+            constellation_stats_wave(st, n + 1, lane, cs);
+            last_watchdog = t0;
+            if (cs[0] >= 0.0) {
+                if (cs[0] < lp.wd_drop) { status = 1; lost = 1; }
+                else if (cs[0] < lp.wd_nudge && cs[2] != 0.0) {
+                    double nphi = pymod_uniform(phi + err * (locked ? lp.alpha_locked : lp.alpha_unlocked), 6.283185307179586);
+                    double nf = f + err * (locked ? lp.beta_locked : lp.beta_unlocked);
+                    const double sg = cs[1] > 0.0 ? 1.0 : (cs[1] < 0.0 ? -1.0 : 0.0);
+                    nf += -sg * lp.wd_nudge_hz;
+                    nphi += sg * (3.141592653589793 / 2.0);
+                    nudged = 1;
+                    sel = 2;
+                    const double2 rot = carrier64_small(nf * inv_fs);
+                    const cf step = carrier_from_cycles_fast(nf * inv_fs * 4096.0);
+                    if (lane == 0) {
+                        red->cc[2].nf = nf; red->cc[2].nphi = nphi;
+                        red->cc[2].rot1 = make_float2((float)rot.x, (float)rot.y);
+                        red->cc[2].step = step;
+                    }
                 }
             }
         }
+        if (lane == 0) {
+            red->loop.sums = sums;
+            red->loop.last_watchdog = last_watchdog;
+            red->istate[1] = lost;
+            red->defer = 0;
+        }
+    } else {
+        sel = rec_sel = locked ? 0 : 1;
+        if (lane == 0) {   // the error joins se / see, and the rings take this millisecond's entries, in the next window phase
+            red->loop.sums.nr = sums.nr; red->loop.sums.ni = sums.ni; red->loop.sums.nrr = sums.nrr;
+            red->loop.sums.pr = sums.pr; red->loop.sums.prr = sums.prr; red->loop.sums.cn = sums.cn; red->loop.sums.cp = sums.cp;
+            red->defer = 1;
+        }
     }
+    pos_e = pos_e + 1 == kLockWindow ? 0 : pos_e + 1;
+    pos_p = pos_p + 1 == kPeakHistory ? 0 : pos_p + 1;
+    pos_refresh = pos_refresh + 1 == kLockRefresh ? 0 : pos_refresh + 1;
     if (lane == 0) {
-        red->loop.last_watchdog = last_watchdog; red->loop.n_steps = n + 1; red->loop.sums = sums;
+        red->loop.n_steps = n + 1;
         red->loop.pos_e = pos_e; red->loop.pos_p = pos_p; red->loop.pos_refresh = pos_refresh;
-        red->istate[1] = lost;
         red->cand_sel = sel; red->rec_sel = rec_sel;
+        gyp_track_rec& o = red->rec;
+        o.pseudosymbol = (int8_t)(pr > 0.0 ? 1 : (pr < 0.0 ? -1 : 0));
+        o.locked = locked ? 1 : 0; o.status = (int8_t)status; o.nudged = (int8_t)nudged;
+    }
+}
+// The record's measurement fields (an otherwise idle wavefront of the update phase; error is also what the deferred
+// histories read back).
+template <int K>
+__device__ __forceinline__ void spec_record_fields(RedScratch* red_, const MsMeasure& r, int lane) {
+    RedScratch* red = launder_lds(red_);
+    constexpr int N = K * kChips;
+    if (lane == 0) {
         gyp_track_rec& o = red->rec;
         o.peak_re = r.peak.x; o.peak_im = r.peak.y;
         if (r.strength_pending) {
-            o.strength = 0.0f;
+            o.strength = 0.0f;                  // filled in by track_verify_kernel
         } else {
             const float mean_excl = (float)((r.sum - (double)r.n_max * (double)r.peak_mag) / (double)(N - r.n_max));
             o.strength = r.peak_mag / mean_excl;
         }
-        o.error = err;
+        o.error = (double)r.peak.x * (double)r.peak.y;
         o.peak_offset = r.key;
-        o.pseudosymbol = (int8_t)(pr > 0.0 ? 1 : (pr < 0.0 ? -1 : 0));
-        o.locked = locked ? 1 : 0; o.status = (int8_t)status; o.nudged = (int8_t)nudged;
         o.path_info = r.path_info;
     }
 }
 // rec_flush for the split form: doppler_hz / carrier_phase (dwords 4..7 of the record) come from the chosen candidate.
-__device__ __forceinline__ void rec_flush_spec(const RedScratch* red, gyp_track_rec* rec, int lane) {
+__device__ __forceinline__ void rec_flush_spec(const RedScratch* red_, gyp_track_rec* rec, int lane) {
+    const RedScratch* red = launder_lds(red_);
     static_assert(offsetof(gyp_track_rec, doppler_hz) == 16 && offsetof(gyp_track_rec, carrier_phase) == 24, "record layout");
     if (rec && lane < 14) {
         const uint32_t* c = reinterpret_cast<const uint32_t*>(&red->cc[red->rec_sel]);
@@ -2008,6 +2086,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         sm.red->cc[0].rot1 = sm.red->steps.rot1;
         sm.red->cc[0].step = carrier_from_cycles_fast(st->doppler * p.inv_fs * 4096.0);
         sm.red->cand_sel = 0; sm.red->rec_sel = 0;
+        sm.red->defer = 0;
     }
     __syncthreads();
     const bool prof = PROF && p.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
@@ -2035,9 +2114,14 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         if (e0 < nt) { const unsigned t = trans[e0]; el_off0 = K * (int)(t & 0x3ffu); el_g0 = (t & 0x8000u) ? -2.0f : 2.0f; }
         if (e1 < nt) { const unsigned t = trans[e1]; el_off1 = K * (int)(t & 0x3ffu); el_g1 = (t & 0x8000u) ? -2.0f : 2.0f; }
     }
+    bool have_prev = false;   // speculative mode: the previous millisecond's record (and possibly its histories) await completion
     for (int ms = p.ms_begin; ms < p.ms_end; ++ms) {
         gyp_track_rec* rec = p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + ms : nullptr;
         if (sm.red->istate[1]) {  // a dropped channel stays dropped until the host re-creates it (receiver.py:259-267)
+            if (SPEC && have_prev) {   // the millisecond that dropped it took the slow path: only its record is outstanding
+                if (wave == 1) rec_flush_spec(sm.red, rec ? rec - 1 : nullptr, lane);
+                have_prev = false;
+            }
             if (threadIdx.x == 0) {
                 if (rec) {
                     gyp_track_rec z = {};
@@ -2076,7 +2160,8 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
                 asm volatile("; MARK_STAGE_BEGIN");
                 GYP_STAMP(0);
                 // the boundary samples of the float64 early/late sums are requested first, consumed after the staging
-                if (wave == 0) fetch_leaving(st, sm.red, leave);
+                if (wave == 0) leave[0] = fetch_leaving_error(st, sm.red);
+                if (wave == 1) fetch_leaving_peak(st, sm.red, leave[1], leave[2]);
                 const ElSample el0 = el_fetch_const<K>(block, sN, el_off0, el_g0);
                 ElSample el1;
                 el1.nl = -1;
@@ -2112,7 +2197,11 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
                 // wavefront 0: the ring entries leaving the lock windows were requested at the top of the millisecond and are
                 // consumed here, BEFORE the next millisecond's samples are requested -- the vector-memory counter retires
                 // in order, so a later wait for those three loads would also wait for the eight sample loads behind them
-                if (wave == 0) verdict_prepare(sm.red, leave, lane, sl.k->lp);
+                if (wave == 0) spec_error_side(st, sm.red, leave[0], lane, launder_lds(sl.k)->lp);
+                if (wave == 1) {
+                    spec_pole_side(sm.red, leave[1], leave[2], lane);
+                    if (have_prev) rec_flush_spec(sm.red, rec ? rec - 1 : nullptr, lane);
+                }
                 // the raw samples are consumed: request the next millisecond now, the loads fly under the window sums
                 if (ms + 1 < p.ms_end) stage_fetch_own<K>(stream + (int64_t)(ms + 1) * N, smp, launder(threadIdx.x));
                 if (prof) t_b = (long long)__builtin_readcyclecounter();
@@ -2199,10 +2288,12 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         GYP_STAMP(8);
         asm volatile("; MARK_UPDATE_BEGIN");
         if constexpr (SPEC) {
-            if (wave == 0) verdict_finish<K>(sl.k->lp, sl.k->inv_fs, st, sm.red, t0, lane, m, f, phi);
-            if (wave == 1) dll_update(sm.red, m.disc, lane, sl.k->lp);
-            if (wave == 2) costas_candidate(sl.k->inv_fs, sm.red, m.peak, f, phi, sl.k->lp.alpha_locked, sl.k->lp.beta_locked, 0, lane);
-            if (wave == 3) costas_candidate(sl.k->inv_fs, sm.red, m.peak, f, phi, sl.k->lp.alpha_unlocked, sl.k->lp.beta_unlocked, 1, lane);
+            const SpecConst* kc = launder_lds(sl.k);
+            if (wave == 0) spec_lock_verdict<K>(kc->lp, kc->inv_fs, st, sm.red, t0, lane, m.peak, f, phi);
+            if (wave == 4) spec_record_fields<K>(sm.red, m, lane);
+            if (wave == 1) dll_update(launder_lds(sm.red), m.disc, lane, kc->lp);
+            if (wave == 2) costas_candidate(kc->inv_fs, launder_lds(sm.red), m.peak, f, phi, kc->lp.alpha_locked, kc->lp.beta_locked, 0, lane);
+            if (wave == 3) costas_candidate(kc->inv_fs, launder_lds(sm.red), m.peak, f, phi, kc->lp.alpha_unlocked, kc->lp.beta_unlocked, 1, lane);
         } else if (wave == 0) {
             fetch_leaving(st, sm.red, leave);
             dll_update(sm.red, m.disc, lane, p.lp);
@@ -2214,12 +2305,16 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         long long t_d = prof ? (long long)__builtin_readcyclecounter() : 0;
         GYP_STAMP(9);
         if constexpr (SPEC) lds_barrier(); else __syncthreads();
-        if (SPEC && wave == 2) rec_flush_spec(sm.red, rec, lane);   // assembled by wavefronts 0..3 before the barrier
+        if (SPEC) have_prev = true;   // the record is flushed by wavefront 1 in the next window phase (or after the loop)
         if (prof) {
             const long long t_e = (long long)__builtin_readcyclecounter();
             tp[0] += t_b - t_a; tp[1] += t_c - t_b; tp[2] += t_d - t_c; tp[3] += t_e - t_d; tp[4] += 1;
         }
 #undef GYP_STAMP
+    }
+    if (SPEC && have_prev) {   // the last millisecond's deferred part
+        if (wave == 0) spec_error_side(st, sm.red, 0.0, lane, sl.k->lp);
+        if (wave == 1) rec_flush_spec(sm.red, p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + (p.ms_end - 1) : nullptr, lane);
     }
     if (threadIdx.x == 0) {
         st->doppler = SPEC ? sm.red->cc[sm.red->cand_sel].nf : sm.red->dstate[0];
