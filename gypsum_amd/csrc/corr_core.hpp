@@ -486,7 +486,7 @@ __device__ __forceinline__ void stage_emit_own_anchored(OwnSamples<K>& s, const 
 #pragma unroll
     for (int c = 0; c < OwnSamples<K>::CH; ++c) {
         const int m = tid + c * OwnSamples<K>::T;   // m == kChips (padding chip) carries zeros: writes y_r[1023] = 0
-        cf (&w)[K] = s.w[c];
+        cf w[K];   // (not in place: the raw samples' registers are free for the next prefetch as soon as they are read)
         cf car = anchor[c];
         if (c + 1 == OwnSamples<K>::CH) {   // see stage_fetch_own
             car.x = m < kChips ? car.x : 0.f;
@@ -494,7 +494,7 @@ __device__ __forceinline__ void stage_emit_own_anchored(OwnSamples<K>& s, const 
         }
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-            w[i] = cmul(w[i], car);
+            w[i] = cmul(s.w[c][i], car);
             car = cmul(car, rot1);
         }
         wiped(c, w);

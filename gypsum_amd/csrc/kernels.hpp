@@ -94,6 +94,7 @@ struct RedScratch {
         double leave_e; int32_t var_ok, var_marginal;    // error side
     } vprep;
     int32_t defer, pad3;   // 1: the last millisecond's error has not joined se / see and its ring entries are not stored yet
+    double t0_next;        // start time of the next millisecond's chunk, fetched by an idle wavefront during the loop updates
     struct CostasCand { double nf, nphi; cf rot1; cf step; } cc[3];   // step: the carrier over 4096 samples (second chip of a thread)
     int cand_sel, rec_sel, pad2[2];
 };
@@ -2087,6 +2088,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         sm.red->cc[0].step = carrier_from_cycles_fast(st->doppler * p.inv_fs * 4096.0);
         sm.red->cand_sel = 0; sm.red->rec_sel = 0;
         sm.red->defer = 0;
+        if (SPEC && p.ms_begin < p.ms_end) sm.red->t0_next = p.start_time[p.ms_begin];
     }
     __syncthreads();
     const bool prof = PROF && p.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
@@ -2117,6 +2119,9 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
     bool have_prev = false;   // speculative mode: the previous millisecond's record (and possibly its histories) await completion
     for (int ms = p.ms_begin; ms < p.ms_end; ++ms) {
         gyp_track_rec* rec = p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + ms : nullptr;
+        // (speculative mode: a load issued here would be waited for -- a few hundred cycles -- by the first carrier of the
+        // wipe-off; wavefront 5 fetched the value into LDS during the previous millisecond's loop updates)
+        const double t0 = SPEC ? launder_lds(sm.red)->t0_next : p.start_time[launder(ms)];
         if (sm.red->istate[1]) {  // a dropped channel stays dropped until the host re-creates it (receiver.py:259-267)
             if (SPEC && have_prev) {   // the millisecond that dropped it took the slow path: only its record is outstanding
                 if (wave == 1) rec_flush_spec(sm.red, rec ? rec - 1 : nullptr, lane);
@@ -2139,7 +2144,6 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         t_last = t_a;
         MsMeasure m;
         double leave[3] = {0.0, 0.0, 0.0};
-        const double t0 = p.start_time[launder(ms)];
         double f, phi;
         CarrierSteps cs;
         cf half_step = make_float2(1.f, 0.f);
@@ -2291,6 +2295,10 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
             const SpecConst* kc = launder_lds(sl.k);
             if (wave == 0) spec_lock_verdict<K>(kc->lp, kc->inv_fs, st, sm.red, t0, lane, m.peak, f, phi);
             if (wave == 4) spec_record_fields<K>(sm.red, m, lane);
+            if (wave == 5 && ms + 1 < p.ms_end) {
+                const double tn = p.start_time[launder(ms + 1)];
+                if (lane == 0) launder_lds(sm.red)->t0_next = tn;
+            }
             if (wave == 1) dll_update(launder_lds(sm.red), m.disc, lane, kc->lp);
             if (wave == 2) costas_candidate(kc->inv_fs, launder_lds(sm.red), m.peak, f, phi, kc->lp.alpha_locked, kc->lp.beta_locked, 0, lane);
             if (wave == 3) costas_candidate(kc->inv_fs, launder_lds(sm.red), m.peak, f, phi, kc->lp.alpha_unlocked, kc->lp.beta_unlocked, 1, lane);
