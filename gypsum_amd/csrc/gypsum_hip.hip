@@ -138,8 +138,9 @@ struct gyp_ctx {
     bool no_spec = false;        // GYP_NO_SPEC=1: A/B switch back to the non-speculative latency kernel
     long long* d_prof = nullptr; // debug: per-phase cycle counters of track_block workgroup 0
     // growable scratch for the host-buffer entry points and the acquisition driver
-    void* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    static constexpr int kScratchSlots = 10;
+    void* scratch[kScratchSlots] = {};
+    size_t scratch_cap[kScratchSlots] = {};
 };
 
 struct gyp_bank {
@@ -299,7 +300,7 @@ void gyp_destroy(gyp_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < gyp_ctx::kScratchSlots; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->d_replicas) (void)hipFree(ctx->d_replicas);
     if (ctx->d_tw) (void)hipFree(ctx->d_tw);
@@ -540,9 +541,11 @@ static int launch_track_verify(gyp_ctx* ctx, const TrackVerifyParams& p, hipStre
 extern "C" {
 
 // ---------------------------------------------------------------- correlation cells ----------------------
-int gyp_correlate_cells_dev(gyp_ctx* ctx, const float* iq_dev, int64_t stream_stride_samples, int32_t n_ms,
-                            const gyp_cell_desc* cells_dev, int32_t n_cells, int32_t integration,
-                            gyp_cell* out_dev, float* profile_out_dev) {
+}   // extern "C"
+// order_dev / n_active_dev: optional work list of the acquisition driver (see CellsParams)
+static int correlate_cells_listed(gyp_ctx* ctx, const float* iq_dev, int64_t stream_stride_samples, int32_t n_ms,
+                                  const gyp_cell_desc* cells_dev, int32_t n_cells, int32_t integration,
+                                  gyp_cell* out_dev, float* profile_out_dev, const int32_t* order_dev, const int32_t* n_active_dev) {
     if (!ctx) return GYP_E_BAD_ARG;
     if (!ctx->k) return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
     if (!iq_dev || !cells_dev || !out_dev || n_ms < 0 || n_cells < 0 || (integration != GYP_COHERENT && integration != GYP_NON_COHERENT))
@@ -560,7 +563,16 @@ int gyp_correlate_cells_dev(gyp_ctx* ctx, const float* iq_dev, int64_t stream_st
     p.tw_tables = ctx->d_tw;
     p.inv_fs = 1.0 / (double)ctx->fs;
     p.prof = ctx->d_prof;
+    p.order = order_dev;
+    p.n_active = n_active_dev;
     return launch_cells(ctx, p, integration);
+}
+extern "C" {
+int gyp_correlate_cells_dev(gyp_ctx* ctx, const float* iq_dev, int64_t stream_stride_samples, int32_t n_ms,
+                            const gyp_cell_desc* cells_dev, int32_t n_cells, int32_t integration,
+                            gyp_cell* out_dev, float* profile_out_dev) {
+    return correlate_cells_listed(ctx, iq_dev, stream_stride_samples, n_ms, cells_dev, n_cells, integration, out_dev, profile_out_dev,
+                                  nullptr, nullptr);
 }
 
 int gyp_correlate_cells(gyp_ctx* ctx, const float* iq_host, int32_t n_streams, int32_t n_ms,
@@ -737,6 +749,12 @@ static int acquire_search(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, 
     if ((rc = ensure_scratch(ctx, 1, n_cells * sizeof(gyp_cell_desc)))) return rc;
     if ((rc = ensure_scratch(ctx, 2, n_cells * sizeof(gyp_cell)))) return rc;
     if ((rc = ensure_scratch(ctx, 3, n_cells * sizeof(double)))) return rc;
+    // previous level's records, reuse map, the level's work list and its length
+    if ((rc = ensure_scratch(ctx, 8, n_cells * (sizeof(gyp_cell) + 2 * sizeof(int32_t)) + 64))) return rc;
+    gyp_cell* d_prev_out = (gyp_cell*)ctx->scratch[8];
+    int32_t* d_reuse = (int32_t*)(d_prev_out + n_cells);
+    int32_t* d_order = d_reuse + n_cells;
+    int32_t* d_n_active = d_order + n_cells;
     const size_t profile_bytes = (size_t)n_states * 2 * ctx->n * sizeof(double);
     if ((rc = ensure_scratch(ctx, 7, profile_bytes))) return rc;
     double* d_profiles = (double*)ctx->scratch[7];
@@ -749,9 +767,12 @@ static int acquire_search(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, 
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `init` is a local
     const int tpb = 64, nblk = (n_states + tpb - 1) / tpb;
     for (double spread = spread0; single_level ? spread == spread0 : spread >= ctx->params.acq_min_spread_hz; spread /= 2.0) {  // acquisition.py:81,89
-        hipLaunchKernelGGL(acq_plan_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_cells, ctx->params.acq_bins_per_spread);
-        rc = gyp_correlate_cells_dev(ctx, iq_dev, stream_stride_samples, n_ms, d_cells, (int32_t)n_cells, GYP_NON_COHERENT, d_out, nullptr);
+        hipLaunchKernelGGL(acq_plan_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_cells, d_reuse, ctx->params.acq_bins_per_spread);
+        hipLaunchKernelGGL(acq_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const gyp_cell_desc*)d_cells, (int)n_cells, d_order, d_n_active);
+        rc = correlate_cells_listed(ctx, iq_dev, stream_stride_samples, n_ms, d_cells, (int32_t)n_cells, GYP_NON_COHERENT, d_out, nullptr,
+                                    d_order, d_n_active);
         if (rc) return rc;
+        hipLaunchKernelGGL(acq_reuse_kernel, dim3((unsigned)n_states), dim3(32), 0, ctx->stream, (const int32_t*)d_reuse, d_out, d_prev_out, n_states);
         RefineParams rp;
         rp.iq = reinterpret_cast<const cf*>(iq_dev);
         rp.stream_stride = stream_stride_samples;

@@ -30,6 +30,9 @@ constexpr int kPeakHistory = 1000;  // tracker.py:146 (deque maxlen)
 constexpr int kLockRefresh = 1024;  // exact two-pass recomputation of the sliding sums every this many ms
 constexpr int kTablesBytes = 1024 * 8;  // tw1024 (tw2048 stays in global memory / L1)
 constexpr int kRedBytes = 1536;
+// gyp_cell_desc::reserved of a cell the acquisition search already holds the record of (same satellite and Doppler bin in
+// the previous level): the correlation kernels leave its output slot alone, acq_reuse_kernel fills it.
+constexpr int kCellSkip = 0x5eed;
 // K = samples per chip.  A workgroup has W wavefronts, W = the largest divisor of K that is <= 8; K > 8 is processed in
 // R = K / W rounds of W polyphase branches (branch r = rho*W + wavefront).
 constexpr int largest_divisor_up_to_8(int k) {
@@ -76,6 +79,23 @@ struct LoopState {
     int32_t pos_e, pos_p, pos_refresh, pad;
 };
 
+// The tunables of the reference's loops (gyp_params; tracker.py:157-203, 227-262, 297-303, 370-387, config.py:23-25).
+struct LoopParams {
+    double dll_gain, dll_modulus;
+    double alpha_locked, beta_locked, alpha_unlocked, beta_unlocked;   // tracker.py:227-244 for the two bandwidths, formed on the host
+    double err_var_max, i_var_max, rot_deg, rot_tan;     // rot_tan = tan(rot_deg)
+    double wd_period, wd_drop, wd_nudge, wd_nudge_hz;
+    double n_samples;                                      // samples per millisecond
+};
+
+// The loop constants of a tracking launch as the block kernels read them: copied to LDS once.  As kernel arguments they
+// sit in ~40 scalar registers which the allocator spills to vector-register lanes and restores sixteen at a time
+// (v_readlane) around every use; a uniform-address LDS read costs one instruction per field.
+struct LoopConst {
+    LoopParams lp;
+    double inv_fs;
+};
+
 struct RedScratch {
     WaveCand cand[16];
     float taps[6];      // early re/im, late re/im, probe re/im (the value at one more lag of the caller's choice)
@@ -95,6 +115,7 @@ struct RedScratch {
     } vprep;
     int32_t defer, pad3;   // 1: the last millisecond's error has not joined se / see and its ring entries are not stored yet
     double t0_next;        // start time of the next millisecond's chunk, fetched by an idle wavefront during the loop updates
+    LoopConst kc;
     struct CostasCand { double nf, nphi; cf rot1; cf step; } cc[3];   // step: the carrier over 4096 samples (second chip of a thread)
     int cand_sel, rec_sel, pad2[2];
 };
@@ -339,7 +360,17 @@ struct CellsParams {
     const cf* tw_tables;
     double inv_fs;
     long long* prof;   // optional: per-phase cycle counters of workgroup 0 of the pipelined kernel (debug)
+    // optional work list (the acquisition driver): order[0 .. *n_active) = the cells to evaluate, ascending.  Padding and
+    // cached cells fall at regular positions of the [state][28] layout; walked with a fixed stride they land on the same
+    // workgroups every time (half of them idle through levels 2 and 3), the compacted list spreads what is left evenly.
+    const int32_t* order;
+    const int32_t* n_active;
 };
+__device__ __forceinline__ int cells_work(const CellsParams& p) { return p.order ? *p.n_active : p.n_cells; }
+__device__ __forceinline__ int cells_pick(const CellsParams& p, int v, int n_work) {
+    const int w = xcd_contiguous(v, n_work);
+    return p.order ? p.order[w] : w;
+}
 
 template <int K, bool COHERENT>
 __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void corr_cells_kernel(CellsParams p) {
@@ -348,10 +379,11 @@ __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void 
     constexpr int R = Geom<K>::R;
     const Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
     __syncthreads();
-    for (int v = blockIdx.x; v < p.n_cells; v += gridDim.x) {
-        const int cell = xcd_contiguous(v, p.n_cells);
+    const int n_work = cells_work(p);
+    for (int v = blockIdx.x; v < n_work; v += gridDim.x) {
+        const int cell = cells_pick(p, v, n_work);
         const gyp_cell_desc d = p.cells[cell];
-        if (d.sat_id < 1 || d.sat_id > 32) continue;  // padding cell (uniform across the workgroup)
+        if (d.sat_id < 1 || d.sat_id > 32 || d.reserved == kCellSkip) continue;  // padding / cached cell (uniform across the workgroup)
         const cf* rep = replica_of(p.replica_table, d.sat_id - 1);
         const double du = d.doppler_hz * p.inv_fs;
         const CarrierSteps cs = carrier_steps<K>(du);
@@ -448,10 +480,11 @@ __global__ __launch_bounds__(Geom<K>::kThreads, 2) void corr_cells_pipe_kernel(C
     const bool prof = PROF && p.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
     long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define GYP_TICK(var) const long long var = PROF ? (long long)__builtin_readcyclecounter() : 0
-    for (int v = blockIdx.x; v < p.n_cells; v += gridDim.x) {
-        const int cell = xcd_contiguous(v, p.n_cells);
+    const int n_work = cells_work(p);
+    for (int v = blockIdx.x; v < n_work; v += gridDim.x) {
+        const int cell = cells_pick(p, v, n_work);
         const gyp_cell_desc d = p.cells[cell];
-        if (d.sat_id < 1 || d.sat_id > 32) continue;  // padding cell (uniform across the workgroup)
+        if (d.sat_id < 1 || d.sat_id > 32 || d.reserved == kCellSkip) continue;  // padding / cached cell (uniform across the workgroup)
         const cf* rep = replica_of(p.replica_table, d.sat_id - 1);
         const double du = d.doppler_hz * p.inv_fs;
         const CarrierSteps cs = carrier_steps<K>(du);
@@ -1338,15 +1371,6 @@ __device__ __forceinline__ double pymod(double a, double b) {
     return r;
 }
 
-// The tunables of the reference's loops (gyp_params; tracker.py:157-203, 227-262, 297-303, 370-387, config.py:23-25).
-struct LoopParams {
-    double dll_gain, dll_modulus;
-    double alpha_locked, beta_locked, alpha_unlocked, beta_unlocked;   // tracker.py:227-244 for the two bandwidths, formed on the host
-    double err_var_max, i_var_max, rot_deg, rot_tan;     // rot_tan = tan(rot_deg)
-    double wd_period, wd_drop, wd_nudge, wd_nudge_hz;
-    double n_samples;                                      // samples per millisecond
-};
-
 // pymod for a wave-uniform argument (the loop filters): the library fmod sits behind a SCALAR branch.
 __device__ __forceinline__ bool uniform_true(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 __device__ __forceinline__ double pymod_uniform(double a, double b) {
@@ -1583,7 +1607,7 @@ __device__ __forceinline__ void dll_update(RedScratch* red, double disc, int lan
 // tracker.py:246-262 Costas loop with the is_locked() bandwidth switch, :346-389 histories and circularity watchdog.
 // Owns everything else in LoopState, dstate, istate[1], steps.
 template <int K>
-__device__ __forceinline__ void costas_update(const TrackBlockParams& p, ChanState* st, RedScratch* red, double t0, int lane,
+__device__ __forceinline__ void costas_update(const LoopConst& kc, ChanState* st, RedScratch* red, double t0, int lane,
                                               const MsMeasure& r, const double (&leave)[3]) {
     constexpr int N = K * kChips;
     const double f = red->dstate[0], phi = red->dstate[1];
@@ -1607,7 +1631,7 @@ __device__ __forceinline__ void costas_update(const TrackBlockParams& p, ChanSta
     }
     // ---- Costas loop, tracker.py:246-262
     const double err = pr * pim;
-    const LoopParams& lp = p.lp;
+    const LoopParams& lp = kc.lp;
     LockVerdict lv = lock_from_sums(sums, n, lp);
     bool locked = lv.locked;
     if (uniform(lv.marginal || pos_refresh == kLockRefresh - 1)) {
@@ -1630,16 +1654,16 @@ __device__ __forceinline__ void costas_update(const TrackBlockParams& p, ChanSta
     const double rec_f = nf, rec_phi = nphi;
     // ---- circularity watchdog, tracker.py:370-387
     int status = 0, nudged = 0;
-    if (uniform(t0 - last_watchdog >= p.lp.wd_period)) {
+    if (uniform(t0 - last_watchdog >= kc.lp.wd_period)) {
         workgroup_mem_fence_wave();
         double cs[3];
         constellation_stats_wave(st, n + 1, lane, cs);
         last_watchdog = t0;
         if (cs[0] >= 0.0) {
-            if (cs[0] < p.lp.wd_drop) { status = 1; lost = 1; }
-            else if (cs[0] < p.lp.wd_nudge && cs[2] != 0.0) {
+            if (cs[0] < kc.lp.wd_drop) { status = 1; lost = 1; }
+            else if (cs[0] < kc.lp.wd_nudge && cs[2] != 0.0) {
                 const double sg = cs[1] > 0.0 ? 1.0 : (cs[1] < 0.0 ? -1.0 : 0.0);
-                nf += -sg * p.lp.wd_nudge_hz;
+                nf += -sg * kc.lp.wd_nudge_hz;
                 nphi += sg * (3.141592653589793 / 2.0);
                 nudged = 1;
             }
@@ -1651,13 +1675,13 @@ __device__ __forceinline__ void costas_update(const TrackBlockParams& p, ChanSta
         red->dstate[0] = nf; red->dstate[1] = nphi;
         red->istate[1] = lost;
         if (kOwnStaging<K>) {   // only the one-sample rotation is used by the halo-free staging
-            const double2 rot = carrier64_small(nf * p.inv_fs);
+            const double2 rot = carrier64_small(nf * kc.inv_fs);
             CarrierSteps cs;
             cs.rot1 = make_float2((float)rot.x, (float)rot.y);
             cs.rot_wrap = make_float2(1.f, 0.f);
             red->steps = cs;
         } else {
-            red->steps = carrier_steps<K>(nf * p.inv_fs);
+            red->steps = carrier_steps<K>(nf * kc.inv_fs);
         }
         gyp_track_rec& o = red->rec;
         o.peak_re = r.peak.x; o.peak_im = r.peak.y;
@@ -1896,22 +1920,11 @@ constexpr int kSpecFinBytes = 256;               // fin64[8], win16 below
 constexpr int kSpecWinBytes = 32 * 8;
 constexpr int kSpecChipBytes = 2048 * 4;
 constexpr int kSpecTransBytes = kMaxTrans * 2;
-// The loop constants of the launch, copied to LDS once: as kernel arguments they sit in ~40 scalar registers which the
-// allocator spills to vector-register lanes and restores sixteen at a time (v_readlane) around every use -- a quarter of
-// the loop-update section's instructions.  A uniform-address LDS read costs one instruction per field.
-struct SpecConst {
-    LoopParams lp;
-    double inv_fs;
-};
-constexpr int kSpecConstBytes = 128;
-static_assert(sizeof(SpecConst) <= kSpecConstBytes, "SpecConst");
 template <int K>
 constexpr int lds_bytes_spec() {
-    return lds_bytes<K>() + kTablesBytes + kSpecChipBytes + kSpecTransBytes + kSpecPartBytes + kSpecEinBytes + kSpecFinBytes + kSpecWinBytes +
-           kSpecConstBytes;
+    return lds_bytes<K>() + kTablesBytes + kSpecChipBytes + kSpecTransBytes + kSpecPartBytes + kSpecEinBytes + kSpecFinBytes + kSpecWinBytes;
 }
 struct SpecLds {
-    const SpecConst* k;
     float* chipf;     // [2048] +-1.0f, this channel's code twice over
     uint16_t* trans;  // [kMaxTrans] this channel's chip transitions
     double* part;     // [4][512]
@@ -2043,10 +2056,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         sl.part = reinterpret_cast<double*>(b); b += kSpecPartBytes;
         sl.ein_part = reinterpret_cast<float*>(b); b += kSpecEinBytes;
         sl.fin = reinterpret_cast<double*>(b); b += kSpecFinBytes;
-        sl.win = reinterpret_cast<cf*>(b); b += kSpecWinBytes;
-        SpecConst* k = reinterpret_cast<SpecConst*>(b);
-        if (threadIdx.x == 0) { k->lp = p.lp; k->inv_fs = p.inv_fs; }
-        sl.k = k;
+        sl.win = reinterpret_cast<cf*>(b);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
@@ -2074,6 +2084,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
     // Loop state lives in LDS between milliseconds (RedScratch::dstate / istate / steps / loop) and is re-read where
     // it is needed, so that no wavefront carries it in registers across the transforms.
     if (threadIdx.x == 0) {
+        sm.red->kc.lp = p.lp; sm.red->kc.inv_fs = p.inv_fs;
         LoopState ls;
         ls.dll_phase = st->dll_phase; ls.last_watchdog = st->last_watchdog_time; ls.n_steps = st->n_steps; ls.sums = st->sums;
         ls.pos_e = (int)(ls.n_steps % kLockWindow); ls.pos_p = (int)(ls.n_steps % kPeakHistory);
@@ -2156,7 +2167,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         }
         {
             const int code_phase = sm.red->istate[0];
-            const double u0 = f * t0 + phi * 0.15915494309189533577, du = f * (SPEC ? sl.k->inv_fs : p.inv_fs);
+            const double u0 = f * t0 + phi * 0.15915494309189533577, du = f * launder_lds(sm.red)->kc.inv_fs;
             const cf* block = stream + (int64_t)ms * N;
             if constexpr (SPEC) {
                 const int tid = launder(threadIdx.x);
@@ -2201,7 +2212,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
                 // wavefront 0: the ring entries leaving the lock windows were requested at the top of the millisecond and are
                 // consumed here, BEFORE the next millisecond's samples are requested -- the vector-memory counter retires
                 // in order, so a later wait for those three loads would also wait for the eight sample loads behind them
-                if (wave == 0) spec_error_side(st, sm.red, leave[0], lane, launder_lds(sl.k)->lp);
+                if (wave == 0) spec_error_side(st, sm.red, leave[0], lane, launder_lds(sm.red)->kc.lp);
                 if (wave == 1) {
                     spec_pole_side(sm.red, leave[1], leave[2], lane);
                     if (have_prev) rec_flush_spec(sm.red, rec ? rec - 1 : nullptr, lane);
@@ -2292,7 +2303,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         GYP_STAMP(8);
         asm volatile("; MARK_UPDATE_BEGIN");
         if constexpr (SPEC) {
-            const SpecConst* kc = launder_lds(sl.k);
+            const LoopConst* kc = &launder_lds(sm.red)->kc;
             if (wave == 0) spec_lock_verdict<K>(kc->lp, kc->inv_fs, st, sm.red, t0, lane, m.peak, f, phi);
             if (wave == 4) spec_record_fields<K>(sm.red, m, lane);
             if (wave == 5 && ms + 1 < p.ms_end) {
@@ -2303,11 +2314,12 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
             if (wave == 2) costas_candidate(kc->inv_fs, launder_lds(sm.red), m.peak, f, phi, kc->lp.alpha_locked, kc->lp.beta_locked, 0, lane);
             if (wave == 3) costas_candidate(kc->inv_fs, launder_lds(sm.red), m.peak, f, phi, kc->lp.alpha_unlocked, kc->lp.beta_unlocked, 1, lane);
         } else if (wave == 0) {
-            fetch_leaving(st, sm.red, leave);
-            dll_update(sm.red, m.disc, lane, p.lp);
-            costas_update<K>(p, st, sm.red, t0, lane, m, leave);
+            RedScratch* red = launder_lds(sm.red);
+            fetch_leaving(st, red, leave);
+            dll_update(red, m.disc, lane, red->kc.lp);
+            costas_update<K>(red->kc, st, red, t0, lane, m, leave);
             workgroup_mem_fence_wave();
-            rec_flush(sm.red, rec, lane);
+            rec_flush(red, rec, lane);
         }
         asm volatile("; MARK_UPDATE_END");
         long long t_d = prof ? (long long)__builtin_readcyclecounter() : 0;
@@ -2321,7 +2333,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
 #undef GYP_STAMP
     }
     if (SPEC && have_prev) {   // the last millisecond's deferred part
-        if (wave == 0) spec_error_side(st, sm.red, 0.0, lane, sl.k->lp);
+        if (wave == 0) spec_error_side(st, sm.red, 0.0, lane, sm.red->kc.lp);
         if (wave == 1) rec_flush_spec(sm.red, p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + (p.ms_end - 1) : nullptr, lane);
     }
     if (threadIdx.x == 0) {
@@ -2438,17 +2450,22 @@ struct AcqSearchState {
     int32_t best_doppler, best_index;
     double best_strength;
     int32_t bins_lo, bins_step, n_bins, pad;
+    int32_t prev_lo, prev_step, prev_n, pad1;   // the previous level's bins (their records are kept: acquisition.py:203's cache)
     // cross-level near-ties (see acq_exact_*): a level winner whose strength is within kStrengthBand of the incumbent's
     int32_t pending, cand_doppler, best_is_exact, pad2;
 };
 
 // Fill the descriptors of the current level: range(int(c-s), int(c+s), int(s/10)), padded to kMaxBins.
-__global__ void acq_plan_kernel(AcqSearchState* states, int n_states, gyp_cell_desc* cells, double bins_per_spread) {
+// A bin the previous level already evaluated (every other bin of levels 2 and 3 with the reference's spreads: the grid is
+// refined by exactly 2) is not correlated again -- the reference returns it from its cache (acquisition.py:200-219), here
+// `reuse` says which of the previous level's records acq_reuse_kernel copies into the slot.
+__global__ void acq_plan_kernel(AcqSearchState* states, int n_states, gyp_cell_desc* cells, int32_t* reuse, double bins_per_spread) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_states) return;
     AcqSearchState s = states[i];
     const int lo = (int)(s.center - s.spread), hi = (int)(s.center + s.spread), step = (int)(s.spread / bins_per_spread);
     const int nb = hi > lo ? min((hi - lo + step - 1) / step, kMaxBins) : 0;     // gyp_set_params keeps every level within kMaxBins
+    states[i].prev_lo = s.bins_lo; states[i].prev_step = s.bins_step; states[i].prev_n = s.level > 0 ? s.n_bins : 0;
     states[i].bins_lo = lo; states[i].bins_step = step; states[i].n_bins = nb;
     for (int b = 0; b < kMaxBins; ++b) {
         gyp_cell_desc d;
@@ -2457,8 +2474,51 @@ __global__ void acq_plan_kernel(AcqSearchState* states, int n_states, gyp_cell_d
         d.doppler_hz = (double)(lo + b * step);
         d.tap_index = -1;
         d.reserved = 0;
+        int from = -1;
+        if (b < nb && s.level > 0 && s.bins_step > 0) {
+            const int off = lo + b * step - s.bins_lo;
+            if (off >= 0 && off % s.bins_step == 0 && off / s.bins_step < s.n_bins) from = off / s.bins_step;
+        }
+        if (from >= 0) d.reserved = kCellSkip;
+        reuse[i * kMaxBins + b] = from;
         cells[i * kMaxBins + b] = d;
     }
+}
+// The level's work list: indices of the cells that are neither padding nor cached, ascending (one block).
+__global__ __launch_bounds__(1024) void acq_compact_kernel(const gyp_cell_desc* __restrict__ cells, int n_cells, int32_t* order, int32_t* n_active) {
+    __shared__ int wave_tot[16];
+    __shared__ int base;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n_cells; c0 += 1024) {
+        const int c = c0 + threadIdx.x;
+        bool on = false;
+        if (c < n_cells) { const gyp_cell_desc d = cells[c]; on = d.sat_id >= 1 && d.sat_id <= 32 && d.reserved != kCellSkip; }
+        const unsigned long long m = __ballot(on);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        if (on) order[off + before] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wave_tot[w]; base += t; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_active = base;
+}
+// out[i][b] <- the previous level's record of the same bin; then the level's records become "the previous level's".
+__global__ void acq_reuse_kernel(const int32_t* __restrict__ reuse, gyp_cell* out, gyp_cell* prev_out, int n_states) {
+    const int i = blockIdx.x;                       // one 32-thread block per state
+    const int b = threadIdx.x;
+    gyp_cell c = {};
+    if (b < kMaxBins) {
+        const int from = reuse[i * kMaxBins + b];
+        c = from >= 0 ? prev_out[i * kMaxBins + from] : out[i * kMaxBins + b];
+    }
+    __syncthreads();                                // every read of prev_out precedes its overwrite
+    if (b < kMaxBins) { out[i * kMaxBins + b] = c; prev_out[i * kMaxBins + b] = c; }
 }
 
 __device__ __forceinline__ double cell_strength(const gyp_cell& c, int n) {
