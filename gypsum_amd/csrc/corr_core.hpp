@@ -450,16 +450,23 @@ __device__ __forceinline__ void stage_ms(const cf* __restrict__ block, double u0
 
 // Split staging for kernels that fetch the next block's samples while the transforms of the current one run
 // (stage_fetch_own issues the global loads into registers, stage_emit_own wipes, pre-sums and writes the K rows), in
-// halo-free form (K >= 2, workgroup of K wavefronts): a thread fetches and wipes ONLY its
+// halo-free form (all K rows resident in LDS, 512 threads): a thread fetches and wipes ONLY its
 // chips' own K samples (half the loads, half the wipes, 2K instead of 4K-2 registers per chip) and forms
 //   y_r[m] = S_r(m) + P_r(m+1),   S_r = sum_{i>=r} w[i]  (suffix sums),  P_r = sum_{i<r} w[i]  (prefix sums),
 // where the neighbour chip's prefix sums arrive from the next lane through the DPP network (wave_shl:1).  Lane 63
 // has no next lane: it receives 0, and the prefix sums of every wavefront's lane-0 chips are published in a small
 // LDS table `halo[m / 64][r]` (16 x K entries) from which the row loader (halo_fixup) completes those sixteen chips.
+// K = samples per chip.  A workgroup has W wavefronts, W = the largest divisor of K that is <= 8.
+constexpr int largest_divisor_up_to_8(int k) {
+    for (int w = 8; w > 1; --w)
+        if (k % w == 0) return w;
+    return 1;
+}
 template <int K>
 struct OwnSamples {
-    static constexpr int T = 64 * K;
+    static constexpr int T = 64 * largest_divisor_up_to_8(K);   // threads of the workgroup (512 for K = 8 and K = 16)
     static constexpr int CH = (kChips + T - 1) / T;
+    static_assert(T * CH == 1024, "every thread owns CH chips, the last one of the last thread being the padding chip");
     cf w[CH][K];
 };
 template <int K>

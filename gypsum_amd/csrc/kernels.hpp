@@ -33,13 +33,8 @@ constexpr int kRedBytes = 1536;
 // gyp_cell_desc::reserved of a cell the acquisition search already holds the record of (same satellite and Doppler bin in
 // the previous level): the correlation kernels leave its output slot alone, acq_reuse_kernel fills it.
 constexpr int kCellSkip = 0x5eed;
-// K = samples per chip.  A workgroup has W wavefronts, W = the largest divisor of K that is <= 8; K > 8 is processed in
-// R = K / W rounds of W polyphase branches (branch r = rho*W + wavefront).
-constexpr int largest_divisor_up_to_8(int k) {
-    for (int w = 8; w > 1; --w)
-        if (k % w == 0) return w;
-    return 1;
-}
+// K = samples per chip.  A workgroup has W wavefronts, W = the largest divisor of K that is <= 8 (corr_core.hpp); K > 8 is
+// processed in R = K / W rounds of W polyphase branches (branch r = rho*W + wavefront).
 template <int K>
 struct Geom {
     static constexpr int W = largest_divisor_up_to_8(K);   // K itself up to 8; 8 for 16/24/48; 5 for 10/20; 6 for 12 ...
@@ -49,8 +44,19 @@ struct Geom {
     // 16 wavefronts per CU (4 per SIMD, 128 VGPRs) for K == 8, 12 (168 VGPRs) below, 8 (256 VGPRs) for branch rounds
     static constexpr int kMinWavesPerSimd = K > 8 ? 2 : (K == 8 ? 4 : 3);
 };
+// Halo-free staging (stage_fetch_own / stage_emit_own / halo_fixup): every sample is wiped once and ALL K polyphase rows
+// of the millisecond are resident in LDS -- K == 8 (one round) and K == 16 (the reference's 16x recordings: two rounds of
+// transforms out of one staging pass, 148 KB, one workgroup per CU).  The other K > 8 stage W rows per round
+// (stage_general): every round wipes every sample again.
 template <int K>
-constexpr int lds_bytes() { return kTablesBytes + Geom<K>::W * kXchWaveBytes + kRedBytes + (K == 8 ? 1024 : 0); }
+constexpr bool kOwnStaging = (K == 8 || K == 16);
+template <int K>
+constexpr int lds_rows() { return kOwnStaging<K> ? K : Geom<K>::W; }
+template <int K>
+constexpr int halo_bytes() { return kOwnStaging<K> ? 16 * K * 8 : 0; }   // [16][K] prefix sums of the lane-0 chips
+template <int K>
+constexpr int lds_bytes() { return kTablesBytes + lds_rows<K>() * kXchWaveBytes + kRedBytes + halo_bytes<K>(); }
+static_assert(lds_bytes<16>() <= 160 * 1024, "K = 16 rows resident");
 
 struct WaveCand {   // one wavefront's candidate for the profile maximum
     float v;
@@ -128,11 +134,7 @@ struct Smem {
     RedScratch* red;
     cf* halo;           // [16][K] prefix sums of the lane-0 chips (halo-free staging, K == 8 only)
 };
-constexpr int kHaloBytes = 16 * 8 * 8;
-// Halo-free staging (stage_fetch_own / stage_emit_own / halo_fixup) is used where all K branches are resident and
-// the workgroup has 8 wavefronts.
-template <int K>
-constexpr bool kOwnStaging = (K == 8);
+constexpr int kHaloBytes = 16 * 8 * 8;   // K == 8 (the pipelined kernels keep two tables)
 
 template <int K>
 __device__ __forceinline__ Smem carve_smem(char* base, const cf* __restrict__ tw_global) {
@@ -140,26 +142,31 @@ __device__ __forceinline__ Smem carve_smem(char* base, const cf* __restrict__ tw
     s.tw1024 = reinterpret_cast<cf*>(base);
     s.tw2048 = tw_global + 1024;
     s.xch = s.tw1024 + 1024;
-    s.red = reinterpret_cast<RedScratch*>(base + kTablesBytes + Geom<K>::W * kXchWaveBytes);
-    s.halo = reinterpret_cast<cf*>(base + kTablesBytes + Geom<K>::W * kXchWaveBytes + kRedBytes);
+    s.red = reinterpret_cast<RedScratch*>(base + kTablesBytes + lds_rows<K>() * kXchWaveBytes);
+    s.halo = reinterpret_cast<cf*>(base + kTablesBytes + lds_rows<K>() * kXchWaveBytes + kRedBytes);
     for (int i = threadIdx.x; i < 1024; i += Geom<K>::kThreads) s.tw1024[i] = tw_global[i];
     return s;
 }
 
 // The transform pair of one branch per wavefront on inputs already staged in LDS.
 // c[j]: complex correlation at lag index K*(l + 32*(j + 16*h)) + rho*W + wavefront.
+// `row0`: LDS row of wavefront 0 (rho*W where all K rows are resident, else 0); `fresh`: the rows were just staged.
 template <int K, bool HALO = false>
-__device__ __forceinline__ void transform_staged(const Smem& sm, const cf* __restrict__ rep_table_sat, cf (&c)[16], int tid) {
+__device__ __forceinline__ void transform_staged(const Smem& sm, const cf* __restrict__ rep_table_sat, cf (&c)[16], int tid, int row0 = 0,
+                                                 bool fresh = true) {
     const int wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
-    if (tid < Geom<K>::W) sm.xch[tid * kXchWave + kChips] = make_float2(0.f, 0.f);
-    __syncthreads();
+    if (fresh) {   // uniform
+        if (tid < lds_rows<K>()) sm.xch[tid * kXchWave + kChips] = make_float2(0.f, 0.f);
+        __syncthreads();
+    }
+    const int row = row0 + wave;
     cf x[32];
-    const cf* yw = sm.xch + wave * kXchWave;
+    const cf* yw = sm.xch + row * kXchWave;
 #pragma unroll
     for (int j = 0; j < 32; ++j) x[j] = yw[32 * j + l];
-    if (HALO) halo_fixup<K>(x, sm.halo, wave, l);
+    if (HALO) halo_fixup<K>(x, sm.halo, row, l);
     wave_lds_fence();
-    float* tile_half = reinterpret_cast<float*>(sm.xch + wave * kXchWave) + h * kXchTile;
+    float* tile_half = reinterpret_cast<float*>(sm.xch + row * kXchWave) + h * kXchTile;
     const LdsTables t{sm.tw1024, sm.tw2048};
     wave_fft_fwd(x, tile_half, t, l, h);
     spectrum_mul_from(x, rep_table_sat, lane);
@@ -175,16 +182,21 @@ __device__ __forceinline__ void correlate_round(const cf* __restrict__ block, in
                                                 const cf* __restrict__ rep_table_sat, cf (&c)[16], Wiped&& wiped, Staged&& staged) {
     constexpr int W = Geom<K>::W;
     const int tid = launder(threadIdx.x);
-    cf* y_rows[W];
-#pragma unroll
-    for (int r = 0; r < W; ++r) y_rows[r] = sm.xch + r * kXchWave;
     if constexpr (kOwnStaging<K>) {
-        OwnSamples<K> smp;
-        stage_fetch_own<K>(block, smp, tid);
-        stage_emit_own<K>(smp, u0, du, cs, y_rows, sm.halo, tid, wiped);
-        staged(tid);
-        transform_staged<K, true>(sm, rep_table_sat, c, tid);
+        if (rho == 0) {   // (uniform) one staging pass serves every round; the caller's barrier precedes the next millisecond's
+            cf* y_all[K];
+#pragma unroll
+            for (int r = 0; r < K; ++r) y_all[r] = sm.xch + r * kXchWave;
+            OwnSamples<K> smp;
+            stage_fetch_own<K>(block, smp, tid);
+            stage_emit_own<K>(smp, u0, du, cs, y_all, sm.halo, tid, wiped);
+            staged(tid);
+        }
+        transform_staged<K, true>(sm, rep_table_sat, c, tid, rho * W, rho == 0);
     } else {
+        cf* y_rows[W];
+#pragma unroll
+        for (int r = 0; r < W; ++r) y_rows[r] = sm.xch + r * kXchWave;
         if (Geom<K>::R == 1) stage_ms<W>(block, u0, du, cs, y_rows, tid);
         else stage_general<K, W>(block, 1, rho, u0, 0.0, du, cs, y_rows, tid);
         transform_staged<K>(sm, rep_table_sat, c, tid);
@@ -424,7 +436,8 @@ __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void 
                     correlate_round<K>(stream + (int64_t)ms * N, rho, u0_step * (double)ms, du, cs, sm, rep, c);
 #pragma unroll
                     for (int j = 0; j < 16; ++j) mag[rho][j] += __builtin_amdgcn_sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
-                    __syncthreads();
+                    // the rows are re-staged by the next round -- or, where all K rows are resident, by the next millisecond
+                    if (!kOwnStaging<K> || rho == R - 1) __syncthreads();
                 }
             }
             const int tid = launder(threadIdx.x);
@@ -1257,6 +1270,21 @@ __device__ __forceinline__ EplResult track_ms(const cf* __restrict__ block, doub
         return epl_finish_wave<K>(sm.red);
     }
     LaneStats ls = lane_stats_init();
+    if constexpr (kOwnStaging<K>) {
+        // all K rows resident: one staging pass (round 0), no barrier between the rounds; epl_finish's barrier is the one
+        // that precedes the next millisecond's staging
+        ElOwn<K> el;
+        el.init(job);
+        const int tid0 = launder(threadIdx.x);
+#pragma unroll 1
+        for (int rho = 0; rho < Geom<K>::R; ++rho) {
+            cf c[16];
+            correlate_round<K>(block, rho, u0, du, cs, sm, rep, c, [&](int ci, const cf (&w)[K]) { if (WANT_EL) el.chip(ci, w, tid0); },
+                               [&](int tid) { if (WANT_EL) el.finish(sm.red, tid); });
+            epl_round<K>(c, rho, s, probe, ls, sm.red, profile_row, launder(threadIdx.x));
+        }
+        return epl_finish<K>(ls, sm.red, launder(threadIdx.x));
+    }
 #pragma unroll 1
     for (int rho = 0; rho < Geom<K>::R; ++rho) {
         cf c[16];

@@ -218,7 +218,7 @@ def make_bits() -> None:
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["prn", "grid", "acq", "track", "lock", "long", "long8184", "bits"]
+    what = sys.argv[1:] or ["prn", "grid", "acq", "track", "track16368", "lock", "long", "long8184", "bits"]
     if "prn" in what:
         make_prn()
     if "grid" in what:
@@ -229,6 +229,9 @@ if __name__ == "__main__":
     if "track" in what:
         make_tracking("2046", 2_046_000, 20260928, 700, 3)
         make_tracking("8184", 8_184_000, 20260929, 300, 2)
+    if "track16368" in what:
+        # the reference's 16x recording format (radio_input.py: 16.368 Msps): acquisition seeds + closed loop
+        make_tracking("16368", 16_368_000, 20260933, 300, 2)
     if "lock" in what:
         make_tracking("2046_lock", 2_046_000, 20260931, 1500, 2, n_sats=4, noise_sigma=0.02)
     if "long" in what:
