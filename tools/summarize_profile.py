@@ -8,7 +8,7 @@ import sys
 from pathlib import Path
 
 REPO = Path(__file__).resolve().parents[1]
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = REPO / "gpurun_out" / f"prof_{tag}"
 dst = REPO / "profiles"
 dst.mkdir(exist_ok=True)
@@ -37,9 +37,9 @@ for wl in ("cfg3", "cfg2"):
         for k, v in pmc(f"pmc_{c}_{wl}").items():
             entry.setdefault(k, {}).update(v)
     summary[wl] = entry
-b = src / "bench_cfg3_single_stream.json"
-if b.exists() and b.read_text().strip():
-    shutil.copy(b, dst / f"{tag}_bench_cfg3_single_stream.json")
+ks = src / "kt_single" / "bench_kernel_stats.csv"
+if ks.exists():
+    shutil.copy(ks, dst / f"{tag}_single_stream_kernel_stats.csv")
 for name in ("pmc_sq1_cfg3", "pmc_sq2_cfg3"):
     for k, v in pmc(name).items():
         summary.setdefault("sq_cfg3", {}).setdefault(k, {}).update(v)
