@@ -83,18 +83,46 @@ def make_scene(rng, n_streams: int, n_visible: int, fs: int, amplitude: float):
 # ---------------------------------------------------------------------------------------------------------------
 class Comm:
     def __init__(self, eng: GypsumEngine, rank: int, world: int, force: bool) -> None:
-        self.rank, self.world, self.dist = rank, world, None
+        self.rank, self.world, self.dist, self.eng = rank, world, None, eng
+        self.fallback = None          # why the library's own collective is not in use, if it is not
         if world > 1 or force:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29517")
             import torch.distributed as dist
             dist.init_process_group("gloo", rank=rank, world_size=world)
             self.dist = dist
-            box = [eng.comm_unique_id() if rank == 0 else None]
+            err = None
+            try:
+                box = [eng.comm_unique_id() if rank == 0 else None]
+            except Exception as e:       # librccl missing / unusable on rank 0: every rank must take the same decision
+                box, err = [None], repr(e)
             dist.broadcast_object_list(box, src=0)
-            eng.comm_init(rank, world, box[0])
+            if box[0] is not None:
+                try:
+                    eng.comm_init(rank, world, box[0])
+                except Exception as e:
+                    err = repr(e)
+            else:
+                err = err or "rank 0 could not create an RCCL id"
+            flags = [None] * world
+            dist.all_gather_object(flags, err)
+            bad = [f for f in flags if f]
+            if bad:   # measured anyway, and said so in the JSON line: records cross through host memory over gloo
+                self.fallback = f"RCCL communicator not available ({bad[0]}); records gathered through the host over gloo"
+                eng.comm_init(0, 1, None)
         else:
             eng.comm_init(0, 1, None)
+
+    def allgather(self, send, recv, nbytes: int) -> None:
+        """One all-gather of `nbytes` opaque record bytes per rank: ncclAllGather issued by the library on its stream."""
+        if self.fallback is None:
+            self.eng.allgather_dev(send.ptr.value, recv.ptr.value, nbytes)
+            return
+        import torch
+        mine = torch.from_numpy(send.download(np.uint8, nbytes).copy())
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine)
+        recv.upload(torch.cat(parts).numpy())
 
     def barrier(self) -> None:
         if self.dist is not None:
@@ -318,7 +346,7 @@ def run_cfg3(eng, comm, args, rng) -> dict:
     def step(i: int) -> None:
         s0 = (i * A) % max(1, B - A + 1)
         eng.acquire_dev(su.iq.ptr.value + s0 * su.stride * 8, A, su.stride, 10, ALL_IDS, acq_send.ptr.value)
-        eng.allgather_dev(acq_send.ptr.value, acq_recv.ptr.value, acq_bytes)      # on the engine's stream, no host sync
+        comm.allgather(acq_send, acq_recv, acq_bytes)      # on the engine's stream, no host sync
         su.track()
 
     elapsed = timed_steps(eng, comm, step, args.warmup, args.steps)
@@ -493,7 +521,7 @@ def run_grid(eng, comm, args, rng, workload: str, steps: int, warmup: int) -> di
         eng.correlate_grid_dev(iq.ptr.value, n_units, n, 1, ALL_IDS, bins, GYP_NON_COHERENT, out_dev.ptr.value)
         if send is not None:
             eng.grid_best_bins_dev(out_dev.ptr.value, n_units * 32, len(bins), send.ptr.value)
-            eng.allgather_dev(send.ptr.value, recv.ptr.value, pad_rows * BEST_BIN.itemsize)
+            comm.allgather(send, recv, pad_rows * BEST_BIN.itemsize)
 
     elapsed = timed_steps(eng, comm, step, warmup, steps)
     eng.timer_start(); step(0); k_ms = eng.timer_stop()
@@ -544,7 +572,7 @@ def run_cfg5(eng, comm, args, steps: int, warmup: int) -> dict:
 
     def step(i: int) -> None:
         eng.correlate_grid_dev(iq.ptr.value, n_streams, n_ms * n, n_ms, ALL_IDS, my_bins, 0, send.ptr.value)
-        eng.allgather_dev(send.ptr.value, recv.ptr.value, pad * CELL.itemsize)
+        comm.allgather(send, recv, pad * CELL.itemsize)
 
     elapsed = timed_steps(eng, comm, step, warmup, steps)
     eng.timer_start()
@@ -618,8 +646,14 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world == 1 and args.gpus > 1:
         raise SystemExit("launch with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
+    force_dist = bool(os.environ.get("GYP_BENCH_FORCE_DIST"))   # the env switch exercises RCCL on a 1-GPU box
+    if world > 1 or force_dist:
+        # torch (gloo rendezvous only) brings its own copies of the HIP / HSA / RCCL libraries: load them BEFORE
+        # libgypsum_hip so that the process holds ONE ROCm stack.  The other order leaves RCCL talking to a second,
+        # uninitialised HSA runtime (ncclCommInitRank: "no ROCm-capable device is detected").
+        import torch  # noqa: F401
     eng = GypsumEngine(local_rank)
-    comm = Comm(eng, rank, world, bool(os.environ.get("GYP_BENCH_FORCE_DIST")))   # the env switch exercises RCCL on a 1-GPU box
+    comm = Comm(eng, rank, world, force_dist)
     rng = np.random.default_rng(20260925 + 7919 * rank)
 
     if args.workload == "cfg3":
@@ -684,7 +718,7 @@ def main() -> None:
                               "achieved": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12, 3), "peak": VALU_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 5),
                               "kernel_ms_per_launch": round(dom["ms"], 4)},
-            "collective": eng.comm_info(),
+            "collective": {**eng.comm_info(), **({"fallback": comm.fallback} if comm.fallback else {})},
             **result["extra"], **extras,
         }
         for k in ("cpu_baseline", "cpu_baseline_all_cores"):
