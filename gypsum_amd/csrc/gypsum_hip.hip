@@ -179,7 +179,19 @@ bool rccl_load() {
     if (g_rccl.lib) return true;
     const char* names[] = {"librccl.so", "librccl.so.1"};
     void* h = nullptr;
-    for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // the copy already in the process, if any
+    // First choice: the librccl that sits next to the HIP runtime THIS library is bound to.  A process may hold two ROCm
+    // stacks (PyTorch ships its own libamdhip64 / libhsa-runtime64 / librccl): an RCCL from the other stack talks to an
+    // HSA runtime nobody initialised (ncclCommInitRank: "no ROCm-capable device is detected").
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void*>(&hipStreamSynchronize), &info) && info.dli_fname) {
+        std::string dir(info.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) {
+            dir.resize(slash + 1);
+            for (const char* n : {"librccl.so.1", "librccl.so"}) if (!h) h = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_GLOBAL);
+        }
+    }
+    for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // else a copy already in the process, if any
     for (const char* n : {"librccl.so.1", "librccl.so"}) if (!h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     if (!h) { g_rccl.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return false; }
     g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
