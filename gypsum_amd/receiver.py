@@ -110,6 +110,17 @@ class GpsReceiver:
         self.satellite_ids_eligible_for_acquisition.append(satellite_id)
 
 
+def first_step_at_least(time_after, i: int, last: float, gap: float) -> int:
+    """Smallest step j >= i with time_after(j) - last >= gap, for a clock of (about) one millisecond per step --
+    evaluated with the provider's own rounded timestamps, which is what the reference compares."""
+    j = max(i, int((last + gap) * 1000) - 3)
+    while j > i and time_after(j - 1) - last >= gap:
+        j -= 1
+    while time_after(j) - last < gap:
+        j += 1
+    return j
+
+
 class BatchedGpsReceiver:
     """The receiver loop of `gypsum/receiver.py:85-267` advanced a block of milliseconds per call:
     acquisition scans at exactly the milliseconds `GpsReceiver.step()` would run them (first when ten chunks are
@@ -117,8 +128,11 @@ class BatchedGpsReceiver:
     all acquired satellites between scans in device-resident loops (`gyp_track_block`, one bank slot per satellite),
     pseudosymbols integrated into navigation bits natively (`gyp_bits_push_block`).
 
-    Equivalent to calling `step()` once per millisecond as long as no satellite loses lock inside a block; a dropped
-    satellite is handed back to the search when its block ends, i.e. at most `block_ms` later than upstream would.
+    Equivalent to calling `step()` once per millisecond.  A satellite can only be dropped by the circularity watchdog
+    (tracker.py:370-387), which looks at a channel every `watchdog_period_s` seconds of receiver time from a start the host
+    knows (0 for a fresh tracker): every block is cut so that such a millisecond is its LAST one, the dropped satellite
+    is back in the search list before the next millisecond, and the re-scan `step()` would run then (receiver.py:158-163,
+    when the scan period has already passed) happens at the same millisecond here.
     """
 
     def __init__(self, antenna_samples_provider: AntennaSampleProvider,
@@ -142,6 +156,7 @@ class BatchedGpsReceiver:
         self.emitted_pseudosymbols: Dict[GpsSatelliteId, List[Any]] = {}
         self.steps_done = 0
         self._time_of_last_scan: Optional[float] = None
+        self._last_watchdog: Dict[GpsSatelliteId, float] = {}   # host mirror of each channel's last watchdog time
         self._recent = np.zeros(0, dtype=np.complex64)     # the last (up to) 9 chunks before the current block
         self._engine = default_engine(self.attrs.samples_per_second, n, device)
         inits = np.zeros(32, dtype=CHAN_INIT)
@@ -167,6 +182,14 @@ class BatchedGpsReceiver:
                 j += 1
         return j
 
+    def _next_watchdog_step(self, i: int) -> Optional[int]:
+        """First step j >= i whose chunk makes some tracked channel's circularity watchdog look (the only place a
+        satellite can be dropped): chunk start time - the channel's last look >= the watchdog period (tracker.py:370-373)."""
+        if not self._last_watchdog:
+            return None
+        period = float(self._engine.get_params()["watchdog_period_s"])
+        return min(first_step_at_least(self._time_after, i, last, period) for last in self._last_watchdog.values())
+
     def _scan(self, samples: np.ndarray, now: float) -> None:
         from .tracker import GpsSatelliteTrackingParameters
         self._time_of_last_scan = now
@@ -178,6 +201,7 @@ class BatchedGpsReceiver:
             self._bank.set_channel(slot, (0, sid.id, float(r.doppler_shift), float(r.carrier_wave_phase_shift),
                                           int(r.prn_phase_shift), 0))
             self._bits.reset(slot)                           # a new pipeline starts with a new integrator (pipeline.py:70)
+            self._last_watchdog[sid] = 0.0                   # a new tracker's watchdog clock starts at 0 (tracker.py:222)
             self.tracked_satellite_ids_to_tracking_params[sid] = GpsSatelliteTrackingParameters(
                 satellite=self.satellites_by_id[sid], current_doppler_shift=r.doppler_shift,
                 current_carrier_wave_phase_shift=r.carrier_wave_phase_shift,
@@ -201,6 +225,9 @@ class BatchedGpsReceiver:
             length = min(remaining, self.block_ms)
             if s is not None and s > i:
                 length = min(length, s - i)                  # stop right before the millisecond that scans
+            w = self._next_watchdog_step(i)
+            if w is not None:
+                length = min(length, w - i + 1)              # a millisecond that may drop a satellite ends its block
             try:
                 block = self.antenna_samples_provider.get_block(length)
             except NoMoreSamplesError:
@@ -224,12 +251,19 @@ class BatchedGpsReceiver:
                     self.emitted_pseudosymbols[sid].extend(emitted)
                     if lost:                                 # receiver.py:248-267
                         del self.tracked_satellite_ids_to_tracking_params[sid]
+                        del self._last_watchdog[sid]
                         self.satellite_ids_eligible_for_acquisition.append(sid)
                     else:
                         k = sid.id - 1
                         p.current_doppler_shift = float(state["doppler_hz"][k])
                         p.current_carrier_wave_phase_shift = float(state["carrier_phase"][k])
                         p.current_prn_code_phase_shift = int(state["code_phase"][k])
+            period = float(self._engine.get_params()["watchdog_period_s"])
+            for sid, last in list(self._last_watchdog.items()):    # the channels that looked during this block
+                for k in range(length):
+                    if self._time_after(i + k) - last >= period:
+                        self._last_watchdog[sid] = self._time_after(i + k)
+                        break
             self._recent = np.concatenate([self._recent, iq])[-(ACQUISITION_INTEGRATION_PERIOD_MS - 1) * n:]
             self.steps_done += length
             remaining -= length

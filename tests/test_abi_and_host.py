@@ -161,3 +161,17 @@ def test_file_provider_reads_gnuradio_float32_like_the_reference(tmp_path):
         assert (a.start_time, a.end_time) == (b.start_time, b.end_time) == orc.chunk_times(ms * 2046, 2046, 2_046_000)
     with pytest.raises(NoMoreSamplesError):   # the reference's bound is `>=`: the final full chunk is not served
         fp.get_samples(2046)
+
+
+def test_block_scheduler_finds_the_watchdog_millisecond_with_the_providers_clock():
+    """BatchedGpsReceiver cuts its blocks at the milliseconds whose chunk start time makes a channel's watchdog look
+    (tracker.py:370-373: start_time - last >= 6): same answer as stepping the reference's rounded clock one chunk at a time."""
+    from gypsum_amd.receiver import first_step_at_least
+
+    for fs, n in ((2_046_000, 2046), (8_184_000, 8184), (16_368_000, 16368)):
+        def clock(k, n=n, fs=fs):
+            return round(k * n / fs, 6)
+        for last in (0.0, 6.0, 7.013, 12.000001, 41.999):
+            for i in (0, 5990, 6000, 6001, 13020, 47998, 60000):
+                want = next(j for j in range(i, i + 70000) if clock(j) - last >= 6.0)
+                assert first_step_at_least(clock, i, last, 6.0) == want, (fs, last, i)
