@@ -768,8 +768,12 @@ static int acquire_search(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, 
     int32_t* d_order = d_reuse + n_cells;
     int32_t* d_n_active = d_order + n_cells;
     const size_t profile_bytes = (size_t)n_states * 2 * ctx->n * sizeof(double);
+    const void* profiles_before = ctx->scratch[7];
     if ((rc = ensure_scratch(ctx, 7, profile_bytes))) return rc;
     double* d_profiles = (double*)ctx->scratch[7];
+    // float64 profile rows of the (rare) cross-level near-ties: cleared when the buffer is (re)allocated, and again by
+    // acq_exact_decide_kernel for the rows it consumed -- not 54 MB of memset per level
+    if (ctx->scratch[7] != profiles_before) HIP_TRY(ctx, hipMemsetAsync(d_profiles, 0, ctx->scratch_cap[7], ctx->stream));
     double* d_refined = (double*)ctx->scratch[3];
     AcqSearchState* d_states = (AcqSearchState*)ctx->scratch[4];
     gyp_cell_desc* d_cells = (gyp_cell_desc*)ctx->scratch[1];
@@ -800,7 +804,6 @@ static int acquire_search(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, 
         hipLaunchKernelGGL(acq_refine_kernel, dim3((unsigned)n_cells), dim3(256), 0, ctx->stream, rp);
         hipLaunchKernelGGL(acq_reduce_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_out, d_refined, ctx->n);
         // cross-level near-ties in strength: float64 profiles for the (few) pending pairs, else immediate exits
-        HIP_TRY(ctx, hipMemsetAsync(d_profiles, 0, profile_bytes, ctx->stream));
         ExactParams ep;
         ep.iq = rp.iq; ep.stream_stride = stream_stride_samples; ep.n_ms = n_ms; ep.n_per_ms = ctx->n; ep.k = ctx->k; ep.n_states = n_states;
         ep.states = d_states; ep.ones = ctx->d_ones; ep.inv_fs = rp.inv_fs; ep.profiles = d_profiles;

@@ -2796,6 +2796,10 @@ __global__ __launch_bounds__(256) void acq_exact_decide_kernel(ExactParams p) {
         st.pending = 0;
         p.states[state] = st;
     }
+    // the rows go back to zero for the next pending pair (acq_exact_profile_kernel accumulates with atomics): the host
+    // clears the scratch once, not per level (each thread re-visits exactly the elements it read)
+    double* rows = p.profiles + (int64_t)state * 2 * N;
+    for (int i = threadIdx.x; i < 2 * N; i += 256) rows[i] = 0.0;
 }
 
 // One coherent cell per (stream, satellite) at the winning Doppler, tapped at the winning code phase (:122-136).
