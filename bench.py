@@ -91,24 +91,30 @@ class Comm:
             import torch.distributed as dist
             dist.init_process_group("gloo", rank=rank, world_size=world)
             self.dist = dist
-            err = None
+            # every rank first checks that it can load librccl at all (creating an id is local), and all ranks take the
+            # same decision: a rank that cannot join would leave the others waiting inside ncclCommInitRank
+            err, my_id = None, None
             try:
-                box = [eng.comm_unique_id() if rank == 0 else None]
-            except Exception as e:       # librccl missing / unusable on rank 0: every rank must take the same decision
-                box, err = [None], repr(e)
-            dist.broadcast_object_list(box, src=0)
-            if box[0] is not None:
+                my_id = eng.comm_unique_id()
+            except Exception as e:
+                err = repr(e)
+            flags = [None] * world
+            dist.all_gather_object(flags, err)
+            if not any(flags):
+                box = [my_id if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
                 try:
                     eng.comm_init(rank, world, box[0])
                 except Exception as e:
                     err = repr(e)
-            else:
-                err = err or "rank 0 could not create an RCCL id"
-            flags = [None] * world
-            dist.all_gather_object(flags, err)
+                dist.all_gather_object(flags, err)
             bad = [f for f in flags if f]
             if bad:   # measured anyway, and said so in the JSON line: records cross through host memory over gloo
                 self.fallback = f"RCCL communicator not available ({bad[0]}); records gathered through the host over gloo"
+                try:
+                    eng.comm_destroy()           # a rank whose own communicator did come up
+                except Exception:
+                    pass
                 eng.comm_init(0, 1, None)
         else:
             eng.comm_init(0, 1, None)
