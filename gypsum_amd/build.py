@@ -29,8 +29,13 @@ def find_hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm); libgypsum_hip has no CPU fallback")
 
 
+STAMP = CSRC / "libgypsum_hip.so.rates"   # "full", or the rate list of a development build (tools/dev_build.sh)
+
+
 def is_stale() -> bool:
     if not LIB.exists():
+        return True
+    if not STAMP.exists() or STAMP.read_text().strip() != "full":   # a K = 8-only development build must not ship
         return True
     t = LIB.stat().st_mtime
     return any(p.stat().st_mtime > t for p in SOURCES + HEADERS)
@@ -43,6 +48,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     if verbose:
         print("[gypsum_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=str(CSRC))
+    STAMP.write_text("full\n")
     return LIB
 
 
