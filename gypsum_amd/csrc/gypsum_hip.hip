@@ -135,7 +135,7 @@ struct gyp_ctx {
     void* comm = nullptr;
     int comm_rank = 0, comm_world = 1;
     gyp_params params;
-    bool no_spec = false;        // GYP_NO_SPEC=1: A/B switch back to the non-speculative latency kernel
+    bool no_spec = false;        // GYP_NO_SPEC=1: A/B switch: lightly loaded banks use the throughput kernel too
     long long* d_prof = nullptr; // debug: per-phase cycle counters of track_block workgroup 0
     // growable scratch for the host-buffer entry points and the acquisition driver
     static constexpr int kScratchSlots = 10;
@@ -528,7 +528,6 @@ template <bool PROF>
 static int launch_track_block_t(gyp_ctx* ctx, const TrackBlockParams& p, int mode) {
     const int grid = p.n_chan;
     if (mode == 2) return launch_k(ctx, track_block_kernel<8, PROF, 2>, 8, grid, p, lds_bytes_spec<8>());
-    if (mode == 1) return launch_k(ctx, track_block_kernel<8, PROF, 1>, 8, grid, p, lds_bytes<8>() + kTablesBytes);
     switch (ctx->k) {
 #define X(K) case K: return launch_k(ctx, track_block_kernel<K, PROF, 0>, K, grid, p, lds_bytes<K>());
         GYP_FOR_EACH_RATE(X)
@@ -536,7 +535,7 @@ static int launch_track_block_t(gyp_ctx* ctx, const TrackBlockParams& p, int mod
     }
     return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
 }
-// mode 0: throughput kernel; 1: latency variant (at most one workgroup per CU); 2: latency variant + speculation
+// mode 0: throughput kernel; 2: latency form + speculation (at most one workgroup per CU)
 static int launch_track_block(gyp_ctx* ctx, const TrackBlockParams& p, int mode) {
     return p.prof ? launch_track_block_t<true>(ctx, p, mode) : launch_track_block_t<false>(ctx, p, mode);
 }
@@ -1123,7 +1122,7 @@ int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stri
     p.dbg = nullptr;
     const bool light = ctx->k == 8 && p.n_chan <= ctx->n_cus && !ctx->no_pipe;   // one workgroup per CU anyway
     if (light && !ctx->no_spec) return track_block_speculative(bank, p);
-    return launch_track_block(ctx, p, light ? 1 : 0);
+    return launch_track_block(ctx, p, 0);
 }
 
 int gyp_track_block(gyp_bank* bank, const float* iq_host, int32_t n_streams, int32_t n_ms, const double* start_time_host,

@@ -45,11 +45,12 @@ struct Geom {
     static constexpr int kMinWavesPerSimd = K > 8 ? 2 : (K == 8 ? 4 : 3);
 };
 // Halo-free staging (stage_fetch_own / stage_emit_own / halo_fixup): every sample is wiped once and ALL K polyphase rows
-// of the millisecond are resident in LDS -- K == 8 (one round) and K == 16 (the reference's 16x recordings: two rounds of
-// transforms out of one staging pass, 148 KB, one workgroup per CU).  The other K > 8 stage W rows per round
-// (stage_general): every round wipes every sample again.
+// of the millisecond are resident in LDS -- K == 2, 4, 8 (one round; 2x and 8x are the reference's recording formats)
+// and K == 16 (its 16x recordings: two rounds of transforms out of one staging pass, 148 KB, one workgroup per CU): the
+// workgroup's 64 W threads own the 1024 chip slots evenly.  The other K <= 8 stage with a halo (stage_ms: every thread
+// also loads and wipes the next chip's first K - 1 samples), the other K > 8 stage W rows per round (stage_general).
 template <int K>
-constexpr bool kOwnStaging = (K == 8 || K == 16);
+constexpr bool kOwnStaging = (K == 2 || K == 4 || K == 8 || K == 16);
 template <int K>
 constexpr int lds_rows() { return kOwnStaging<K> ? K : Geom<K>::W; }
 template <int K>
@@ -1253,7 +1254,7 @@ __device__ __forceinline__ EplResult track_ms(const cf* __restrict__ block, doub
     const ElJob job{block, u0, du, s, trans, nt, chipf};
     if constexpr (Geom<K>::R == 1) {
         cf c[16];
-        if constexpr (kOwnStaging<K> && WANT_EL) {
+        if constexpr (kOwnStaging<K> && K >= 8 && WANT_EL) {   // (K = 2, 4: few transitions per thread, float64 gather kept)
             // the boundary sums come from the samples the staging holds anyway (reduced per wavefront at once: nothing
             // stays live across the transforms)
             ElOwn<K> el;
@@ -1294,42 +1295,6 @@ __device__ __forceinline__ EplResult track_ms(const cf* __restrict__ block, doub
     }
     if constexpr (WANT_EL) el_wave_partials<K>(job, sm.red, launder(threadIdx.x));
     return epl_finish<K>(ls, sm.red, launder(threadIdx.x));
-}
-
-// Latency form of one tracking millisecond for lightly loaded chips (one workgroup per CU, 256 VGPRs): the samples
-// were requested one loop-filter update earlier (stage_fetch_own), the replica spectrum is resident in registers,
-// and sm.tw2048 points into LDS -- no global-load latency is left on the millisecond's critical path.
-template <int K>
-__device__ __forceinline__ EplResult track_ms_fetched(OwnSamples<K>& smp, double u0, double du, const CarrierSteps& cs,
-                                                      int code_phase, const Smem& sm, const cf (&prn)[32], const ElJob& job) {
-    static_assert(kOwnStaging<K>, "halo-free staging only");
-    constexpr int N = K * kChips;
-    constexpr int W = Geom<K>::W;
-    const int s = mod_n(code_phase, N);
-    const int tid = launder(threadIdx.x);
-    const int wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
-    cf* y_rows[W];
-#pragma unroll
-    for (int r = 0; r < W; ++r) y_rows[r] = sm.xch + r * kXchWave;
-    stage_emit_own<K>(smp, u0, du, cs, y_rows, sm.halo, tid);
-    __syncthreads();
-    cf x[32];
-    const cf* yw = sm.xch + wave * kXchWave;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) x[j] = yw[32 * j + l];
-    halo_fixup<K>(x, sm.halo, wave, l);
-    wave_lds_fence();
-    float* tile_half = reinterpret_cast<float*>(sm.xch + wave * kXchWave) + h * kXchTile;
-    const LdsTables t{sm.tw1024, sm.tw2048};
-    cf c[16];
-    wave_fft_fwd(x, tile_half, t, l, h);
-#pragma unroll
-    for (int i = 0; i < 32; ++i) x[i] = cmul(x[i], prn[i]);
-    __builtin_amdgcn_sched_barrier(0);
-    wave_fft_inv(x, c, tile_half, t, l, h);
-    epl_round_wave<K>(c, s, s, sm.red, nullptr, tid);
-    el_wave_partials<K>(job, sm.red, tid);
-    return epl_finish_wave<K>(sm.red);
 }
 
 template <int K>
@@ -1610,6 +1575,21 @@ __device__ __forceinline__ void fetch_leaving(const ChanState* st, const RedScra
     }
 }
 
+// The wipe-off's rotation constants for a tracked channel at du cycles per sample.  Halo-free staging only uses the
+// one-sample rotation; it is rounded from a float64 evaluation (the loop updates run in float64 anyway).
+template <int K>
+__device__ __forceinline__ CarrierSteps tracking_steps(double du) {
+    if constexpr (kOwnStaging<K>) {
+        const double2 rot = carrier64_small(du);
+        CarrierSteps cs;
+        cs.rot1 = make_float2((float)rot.x, (float)rot.y);
+        cs.rot_wrap = make_float2(1.f, 0.f);
+        return cs;
+    } else {
+        return carrier_steps<K>(du);
+    }
+}
+
 // The loop updates of one millisecond of one channel, in two independent halves so that two wavefronts can run them
 // side by side (all lanes, uniform values).  Loop state lives in `red` (LDS), the history rings in `st`; the
 // millisecond's record is assembled in red->rec and written out by rec_flush.
@@ -1702,15 +1682,7 @@ __device__ __forceinline__ void costas_update(const LoopConst& kc, ChanState* st
         red->loop.pos_e = pos_e; red->loop.pos_p = pos_p; red->loop.pos_refresh = pos_refresh;
         red->dstate[0] = nf; red->dstate[1] = nphi;
         red->istate[1] = lost;
-        if (kOwnStaging<K>) {   // only the one-sample rotation is used by the halo-free staging
-            const double2 rot = carrier64_small(nf * kc.inv_fs);
-            CarrierSteps cs;
-            cs.rot1 = make_float2((float)rot.x, (float)rot.y);
-            cs.rot_wrap = make_float2(1.f, 0.f);
-            red->steps = cs;
-        } else {
-            red->steps = carrier_steps<K>(nf * kc.inv_fs);
-        }
+        red->steps = tracking_steps<K>(nf * kc.inv_fs);
         gyp_track_rec& o = red->rec;
         o.peak_re = r.peak.x; o.peak_im = r.peak.y;
         if (r.strength_pending) {
@@ -2057,8 +2029,8 @@ __device__ __attribute__((noinline)) EplResult spec_transform_path(const Smem& s
     return epl_finish_wave<K>(sm.red);
 }
 
-// MODE 0: throughput form (several workgroups per CU).  MODE 1: latency variant for at most one workgroup per CU
-// (see track_ms_fetched); needs kTablesBytes more LDS.  MODE 2: latency variant + speculation: the millisecond's
+// MODE 0: throughput form (several workgroups per CU).  MODE 2: the latency form for at most one workgroup per CU (the
+// next millisecond's samples requested a phase early, both twiddle tables in LDS) with speculation: the millisecond's
 // prompt correlation is evaluated only at the 8 lags around the previous peak lag, directly from the staged rows; if the
 // window maximum is interior and dominates the sample energy (so that no lag outside the window can plausibly exceed
 // it) the loop filters advance on it at once and the full profile -- needed for the strength record, and to PROVE that
@@ -2066,8 +2038,9 @@ __device__ __attribute__((noinline)) EplResult spec_transform_path(const Smem& s
 // pairs in parallel afterwards.  Otherwise the millisecond takes the transform path right here, from the same rows.
 template <int K, bool PROF, int MODE = 0>
 __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPerSimd) void track_block_kernel(TrackBlockParams p) {
-    constexpr bool LAT = MODE >= 1, SPEC = MODE == 2;
-    static_assert(!LAT || kOwnStaging<K>, "the latency variants exist for the own-staging rates");
+    static_assert(MODE == 0 || MODE == 2, "r01's non-speculative latency variant (MODE 1) is gone: superseded by MODE 2");
+    constexpr bool LAT = MODE == 2, SPEC = MODE == 2;
+    static_assert(!LAT || kOwnStaging<K>, "the latency form exists for the own-staging rates");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int N = K * kChips;
     Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
@@ -2121,7 +2094,8 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         sm.red->dstate[0] = st->doppler; sm.red->dstate[1] = st->carrier_phase;
         sm.red->istate[0] = st->code_phase; sm.red->istate[1] = st->lost;
         sm.red->istate[2] = mod_n(st->code_phase, N);   // speculative window centre: no peak seen yet in this launch
-        sm.red->steps = carrier_steps<K>(st->doppler * p.inv_fs);
+        sm.red->steps = tracking_steps<K>(st->doppler * p.inv_fs);   // the same expression as after an update: a block gives
+                                                                        // the same records however it is cut into launches
         sm.red->cc[0].nf = st->doppler; sm.red->cc[0].nphi = st->carrier_phase;
         sm.red->cc[0].rot1 = sm.red->steps.rot1;
         sm.red->cc[0].step = carrier_from_cycles_fast(st->doppler * p.inv_fs * 4096.0);
@@ -2136,13 +2110,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
     // speculative mode: tp[6 + i] accumulates the cycles between stamp i-1 and stamp i of workgroup 0's thread 0
 #define GYP_STAMP(i) do { if (prof) { const long long now_ = (long long)__builtin_readcyclecounter(); tp[6 + (i)] += now_ - t_last; t_last = now_; } } while (0)
     OwnSamples<LAT ? K : 1> smp;          // LAT: the next millisecond's raw samples
-    cf prn[MODE == 1 ? 32 : 1];           // MODE 1: this satellite's replica spectrum
     if constexpr (LAT) {
-        if constexpr (MODE == 1) {
-            const cf* row = rep + launder(lane);
-#pragma unroll
-            for (int i = 0; i < 32; ++i) prn[i] = row[64 * i];
-        }
         if (p.ms_begin < p.ms_end) stage_fetch_own<K>(stream + (int64_t)p.ms_begin * N, smp, launder(threadIdx.x));
     }
     // speculative mode: this thread's chip transitions (sample offset K*m, coefficient +-2), fixed for the whole launch
@@ -2311,15 +2279,8 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
                     sm.red->istate[2] = next_centre;
                 }
             } else {
-                EplResult r;
-                if constexpr (MODE == 1) {
-                    r = track_ms_fetched<K>(smp, u0, du, cs, code_phase, sm, prn, ElJob{block, u0, du, mod_n(code_phase, N), trans, nt, nullptr});
-                    // request the next millisecond now: the loads fly while the boundary sums and the loop filters run
-                    if (ms + 1 < p.ms_end) stage_fetch_own<K>(stream + (int64_t)(ms + 1) * N, smp, launder(threadIdx.x));
-                } else {
-                    r = track_ms<K, true>(block, u0, du, cs, code_phase, mod_n(code_phase, N), sm, rep, nullptr, trans, nt,
-                                          p.codes.chipf + sat_index * 2048);
-                }
+                const EplResult r = track_ms<K, true>(block, u0, du, cs, code_phase, mod_n(code_phase, N), sm, rep, nullptr, trans, nt,
+                                                      p.codes.chipf + sat_index * 2048);
                 if (prof) t_b = (long long)__builtin_readcyclecounter();
                 m.peak = r.peak; m.peak_mag = r.best.v; m.key = r.best.key; m.sum = r.sum; m.n_max = r.n_max;
                 m.strength_pending = false;

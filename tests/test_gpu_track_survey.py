@@ -114,8 +114,9 @@ def test_tracking_survey_one_million_channel_ms(engine_factory):
 
 @pytest.mark.parametrize("env", ["GYP_NO_SPEC", "GYP_NO_PIPE"])
 def test_tracking_survey_transform_kernels(env):
-    """The same comparison through the latency kernel without speculation (GYP_NO_SPEC) and through the throughput
-    kernel (GYP_NO_PIPE): 6 scenes x 12 channels x 1000 ms each."""
+    """The same comparison through the throughput (transform) tracking kernel, which lightly loaded banks otherwise never
+    reach: GYP_NO_SPEC switches the speculation off, GYP_NO_PIPE every latency / pipelined form (acquisition's included):
+    6 scenes x 12 channels x 1000 ms each."""
     from gypsum_amd.engine import GypsumEngine
 
     os.environ[env] = "1"
