@@ -123,7 +123,8 @@ struct RedScratch {
     int32_t defer, pad3;   // 1: the last millisecond's error has not joined se / see and its ring entries are not stored yet
     double t0_next;        // start time of the next millisecond's chunk, fetched by an idle wavefront during the loop updates
     LoopConst kc;
-    struct CostasCand { double nf, nphi; cf rot1; cf step; } cc[3];   // step: the carrier over 4096 samples (second chip of a thread)
+    struct CostasCand { double nf, nphi; cf rot1; cf step; double pscale; } cc[3];   // step: the carrier over 4096 samples (second chip of a thread)
+    double pscale;         // throughput kernels: prompt_scale of the wipe-off in force (see prompt_scale)
     int cand_sel, rec_sel, pad2[2];
 };
 static_assert(sizeof(RedScratch) <= kRedBytes, "reduction scratch too large");
@@ -1590,6 +1591,21 @@ __device__ __forceinline__ CarrierSteps tracking_steps(double du) {
     }
 }
 
+// The wipe-off multiplies sample i of every chip by anchor * rot1^i in float32; rot1 (and, in the speculative kernel, the
+// half-block rotation that takes a thread's first carrier to its second chip) is rounded to float32, so its modulus is
+// 1 + e with |e| < 6e-8 -- the SAME e for every chip and for as long as the Doppler estimate stays put.  The prompt value P
+// comes out scaled by 1 + (K-1)/2 * e (+ e_step / 2), a bias, not noise: through Re(P conj(L - E)) it shifts the DLL
+// accumulator by bias x (net travel of the accumulator), ~1e-6 of a sample after a few hundred milliseconds, and the
+// reference's code loop dithers across integer boundaries (tracker.py:297-303), where int(self.phase) then comes out
+// different for some milliseconds (one such passage in 3e6 channel-ms surveyed).  The discriminator therefore takes P
+// times this factor, formed in float64 from the very float32 constants the wipe-off uses.
+template <int K>
+__device__ __forceinline__ double prompt_scale(cf rot1, cf step) {
+    const double e1 = fma((double)rot1.x, (double)rot1.x, (double)rot1.y * (double)rot1.y) - 1.0;      // |rot1|^2 - 1
+    const double es = fma((double)step.x, (double)step.x, (double)step.y * (double)step.y) - 1.0;
+    return 1.0 - (0.25 * (double)(K - 1)) * e1 - 0.25 * es;     // 1 / (mean_i |rot1|^i * (1 + |step|) / 2) to first order
+}
+
 // The loop updates of one millisecond of one channel, in two independent halves so that two wavefronts can run them
 // side by side (all lanes, uniform values).  Loop state lives in `red` (LDS), the history rings in `st`; the
 // millisecond's record is assembled in red->rec and written out by rec_flush.
@@ -1683,6 +1699,7 @@ __device__ __forceinline__ void costas_update(const LoopConst& kc, ChanState* st
         red->dstate[0] = nf; red->dstate[1] = nphi;
         red->istate[1] = lost;
         red->steps = tracking_steps<K>(nf * kc.inv_fs);
+        red->pscale = kOwnStaging<K> ? prompt_scale<K>(red->steps.rot1, make_float2(1.f, 0.f)) : 1.0;
         gyp_track_rec& o = red->rec;
         o.peak_re = r.peak.x; o.peak_im = r.peak.y;
         if (r.strength_pending) {
@@ -1715,8 +1732,10 @@ __device__ __forceinline__ void costas_candidate(double inv_fs, RedScratch* red,
     const cf step = carrier_from_cycles_fast(nf * inv_fs * 4096.0);
     if (lane == 0) {
         red->cc[slot].nf = nf; red->cc[slot].nphi = nphi;
-        red->cc[slot].rot1 = make_float2((float)rot.x, (float)rot.y);
+        const cf rot1 = make_float2((float)rot.x, (float)rot.y);
+        red->cc[slot].rot1 = rot1;
         red->cc[slot].step = step;
+        red->cc[slot].pscale = prompt_scale<8>(rot1, step);
     }
 }
 // Everything else of costas_update -- histories, lock verdict, watchdog, the record's fields -- arranged so that ONLY the
@@ -1850,8 +1869,10 @@ __device__ __forceinline__ void spec_lock_verdict(const LoopParams& lp, double i
                     const cf step = carrier_from_cycles_fast(nf * inv_fs * 4096.0);
                     if (lane == 0) {
                         red->cc[2].nf = nf; red->cc[2].nphi = nphi;
-                        red->cc[2].rot1 = make_float2((float)rot.x, (float)rot.y);
+                        const cf rot1 = make_float2((float)rot.x, (float)rot.y);
+                        red->cc[2].rot1 = rot1;
                         red->cc[2].step = step;
+                        red->cc[2].pscale = prompt_scale<8>(rot1, step);
                     }
                 }
             }
@@ -2099,6 +2120,8 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         sm.red->cc[0].nf = st->doppler; sm.red->cc[0].nphi = st->carrier_phase;
         sm.red->cc[0].rot1 = sm.red->steps.rot1;
         sm.red->cc[0].step = carrier_from_cycles_fast(st->doppler * p.inv_fs * 4096.0);
+        sm.red->cc[0].pscale = prompt_scale<8>(sm.red->cc[0].rot1, sm.red->cc[0].step);
+        sm.red->pscale = kOwnStaging<K> ? prompt_scale<K>(sm.red->steps.rot1, make_float2(1.f, 0.f)) : 1.0;
         sm.red->cand_sel = 0; sm.red->rec_sel = 0;
         sm.red->defer = 0;
         if (SPEC && p.ms_begin < p.ms_end) sm.red->t0_next = p.start_time[p.ms_begin];
@@ -2154,12 +2177,15 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         double f, phi;
         CarrierSteps cs;
         cf half_step = make_float2(1.f, 0.f);
+        double pscale;        // see prompt_scale
         if constexpr (SPEC) {
             const auto cand = sm.red->cc[sm.red->cand_sel];
             f = cand.nf; phi = cand.nphi; cs.rot1 = cand.rot1; cs.rot_wrap = make_float2(1.f, 0.f);
             half_step = cand.step;
+            pscale = cand.pscale;
         } else {
             f = sm.red->dstate[0]; phi = sm.red->dstate[1]; cs = sm.red->steps;
+            pscale = sm.red->pscale;
         }
         {
             const int code_phase = sm.red->istate[0];
@@ -2270,7 +2296,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
                 if (wave == 1) {   // the code loop runs beside the Costas loop (wavefront 0)
                     const cf p0 = sl.win[2 * kSpecHalf], p1 = sl.win[2 * kSpecHalf + 1], p2 = sl.win[2 * kSpecHalf + 2], p3 = sl.win[2 * kSpecHalf + 3];
                     const double d[4] = {sl.fin[0] + sl.fin[1], sl.fin[2] + sl.fin[3], sl.fin[4] + sl.fin[5], sl.fin[6] + sl.fin[7]};
-                    m.disc = dll_discriminator((double)((p0.x + p1.x) + (p2.x + p3.x)), (double)((p0.y + p1.y) + (p2.y + p3.y)), d);
+                    m.disc = dll_discriminator((double)((p0.x + p1.x) + (p2.x + p3.x)) * pscale, (double)((p0.y + p1.y) + (p2.y + p3.y)) * pscale, d);
                 }
                 if (wave == 3 && lane == 0) {
                     SpecIn si;
@@ -2285,7 +2311,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
                 m.peak = r.peak; m.peak_mag = r.best.v; m.key = r.best.key; m.sum = r.sum; m.n_max = r.n_max;
                 m.strength_pending = false;
                 m.path_info = 0;
-                m.disc = dll_discriminator((double)r.probe.x, (double)r.probe.y, r.eld);
+                m.disc = dll_discriminator((double)r.probe.x * pscale, (double)r.probe.y * pscale, r.eld);
                 if (prof) t_c = (long long)__builtin_readcyclecounter();
             }
         }
