@@ -462,20 +462,23 @@ constexpr int largest_divisor_up_to_8(int k) {
         if (k % w == 0) return w;
     return 1;
 }
-template <int K>
+// T: threads of the workgroup that stages the millisecond (they own the 1024 chip slots evenly).  The kernels use
+// 64 * W(K) (512 for K = 8 and 16, 128 for K = 2); the speculative tracker stages every rate with 512.
+template <int K, int T_ = 64 * largest_divisor_up_to_8(K)>
 struct OwnSamples {
-    static constexpr int T = 64 * largest_divisor_up_to_8(K);   // threads of the workgroup (512 for K = 8 and K = 16)
+    static constexpr int T = T_;
     static constexpr int CH = (kChips + T - 1) / T;
     static_assert(T * CH == 1024, "every thread owns CH chips, the last one of the last thread being the padding chip");
     cf w[CH][K];
 };
-template <int K>
-__device__ __forceinline__ void stage_fetch_own(const cf* __restrict__ block, OwnSamples<K>& s, int tid) {
+template <int K, int T>
+__device__ __forceinline__ void stage_fetch_own(const cf* __restrict__ block, OwnSamples<K, T>& s, int tid) {
+    constexpr int CH = OwnSamples<K, T>::CH;
 #pragma unroll
-    for (int c = 0; c < OwnSamples<K>::CH; ++c) {
+    for (int c = 0; c < CH; ++c) {
         // the padding chip (m == 1023, one thread's last chip) re-reads chip 1022: stage_emit_own_anchored wipes it with a
         // zero carrier, so that S = P = 0 without a branch or sixteen register clears in every thread
-        const int m = c + 1 < OwnSamples<K>::CH ? tid + c * OwnSamples<K>::T : min(tid + c * OwnSamples<K>::T, kChips - 1);
+        const int m = c + 1 < CH ? tid + c * T : min(tid + c * T, kChips - 1);
         load_samples<K>(block + K * m, s.w[c]);
     }
 }
@@ -485,17 +488,18 @@ __device__ __forceinline__ cf next_lane(cf v) {   // lane i <- lane i+1, lane 63
 }
 // `anchor[c]`: the carrier at the first sample of the thread's c-th chip.
 // `wiped(c, w)` sees chip c's K wiped samples before they are summed (the tracking kernels take boundary samples there).
-template <int K, typename Wiped>
-__device__ __forceinline__ void stage_emit_own_anchored(OwnSamples<K>& s, const cf (&anchor)[OwnSamples<K>::CH], const CarrierSteps& cs,
+template <int K, int T, typename Wiped>
+__device__ __forceinline__ void stage_emit_own_anchored(OwnSamples<K, T>& s, const cf (&anchor)[OwnSamples<K, T>::CH], const CarrierSteps& cs,
                                                         cf* (&y_rows)[K], cf* __restrict__ halo, int tid, Wiped&& wiped) {
+    constexpr int CH = OwnSamples<K, T>::CH;
     const cf rot1 = cs.rot1;
     const int lane = tid & 63;
 #pragma unroll
-    for (int c = 0; c < OwnSamples<K>::CH; ++c) {
-        const int m = tid + c * OwnSamples<K>::T;   // m == kChips (padding chip) carries zeros: writes y_r[1023] = 0
+    for (int c = 0; c < CH; ++c) {
+        const int m = tid + c * T;   // m == kChips (padding chip) carries zeros: writes y_r[1023] = 0
         cf w[K];   // (not in place: the raw samples' registers are free for the next prefetch as soon as they are read)
         cf car = anchor[c];
-        if (c + 1 == OwnSamples<K>::CH) {   // see stage_fetch_own
+        if (c + 1 == CH) {   // see stage_fetch_own
             car.x = m < kChips ? car.x : 0.f;
             car.y = m < kChips ? car.y : 0.f;
         }
@@ -522,24 +526,24 @@ __device__ __forceinline__ void stage_emit_own_anchored(OwnSamples<K>& s, const 
         y_rows[0][m] = cadd(suf, w[0]);
     }
 }
-template <int K>
-__device__ __forceinline__ void stage_emit_own_anchored(OwnSamples<K>& s, const cf (&anchor)[OwnSamples<K>::CH], const CarrierSteps& cs,
+template <int K, int T>
+__device__ __forceinline__ void stage_emit_own_anchored(OwnSamples<K, T>& s, const cf (&anchor)[OwnSamples<K, T>::CH], const CarrierSteps& cs,
                                                         cf* (&y_rows)[K], cf* __restrict__ halo, int tid) {
-    stage_emit_own_anchored<K>(s, anchor, cs, y_rows, halo, tid, [](int, const cf (&)[K]) {});
+    stage_emit_own_anchored<K, T>(s, anchor, cs, y_rows, halo, tid, [](int, const cf (&)[K]) {});
 }
-template <int K, typename Wiped>
-__device__ __forceinline__ void stage_emit_own(OwnSamples<K>& s, double u0, double du, const CarrierSteps& cs,
+template <int K, int T, typename Wiped>
+__device__ __forceinline__ void stage_emit_own(OwnSamples<K, T>& s, double u0, double du, const CarrierSteps& cs,
                                                cf* (&y_rows)[K], cf* __restrict__ halo, int tid, Wiped&& wiped) {
-    cf anchor[OwnSamples<K>::CH];
+    cf anchor[OwnSamples<K, T>::CH];
 #pragma unroll
-    for (int c = 0; c < OwnSamples<K>::CH; ++c)
-        anchor[c] = carrier_from_cycles_fast(u0 + du * (double)(K * (tid + c * OwnSamples<K>::T)));
-    stage_emit_own_anchored<K>(s, anchor, cs, y_rows, halo, tid, wiped);
+    for (int c = 0; c < OwnSamples<K, T>::CH; ++c)
+        anchor[c] = carrier_from_cycles_fast(u0 + du * (double)(K * (tid + c * T)));
+    stage_emit_own_anchored<K, T>(s, anchor, cs, y_rows, halo, tid, wiped);
 }
-template <int K>
-__device__ __forceinline__ void stage_emit_own(OwnSamples<K>& s, double u0, double du, const CarrierSteps& cs,
+template <int K, int T>
+__device__ __forceinline__ void stage_emit_own(OwnSamples<K, T>& s, double u0, double du, const CarrierSteps& cs,
                                                cf* (&y_rows)[K], cf* __restrict__ halo, int tid) {
-    stage_emit_own<K>(s, u0, du, cs, y_rows, halo, tid, [](int, const cf (&)[K]) {});
+    stage_emit_own<K, T>(s, u0, du, cs, y_rows, halo, tid, [](int, const cf (&)[K]) {});
 }
 // Row loader side: x[j] holds y[32*j + l] of branch `r`; chips 63 + 64*k (k = 0..14) take P_r of chip 64*(k+1),
 // chip 1022 takes P_r of chip 0 (the block is circular; the wipe-off of a wrapped sample is the one of its index).

@@ -527,7 +527,10 @@ static int launch_track_step(gyp_ctx* ctx, const TrackStepParams& p) {
 template <bool PROF>
 static int launch_track_block_t(gyp_ctx* ctx, const TrackBlockParams& p, int mode) {
     const int grid = p.n_chan;
-    if (mode == 2) return launch_k(ctx, track_block_kernel<8, PROF, 2>, 8, grid, p, lds_bytes_spec<8>());
+    if (mode == 2) {   // 512 threads whatever the rate (launch_k's block size follows its rate argument: 8 -> 512)
+        if (ctx->k == 2) return launch_k(ctx, track_block_kernel<2, PROF, 2>, 8, grid, p, lds_bytes_spec<2>());
+        return launch_k(ctx, track_block_kernel<8, PROF, 2>, 8, grid, p, lds_bytes_spec<8>());
+    }
     switch (ctx->k) {
 #define X(K) case K: return launch_k(ctx, track_block_kernel<K, PROF, 0>, K, grid, p, lds_bytes<K>());
         GYP_FOR_EACH_RATE(X)
@@ -541,10 +544,16 @@ static int launch_track_block(gyp_ctx* ctx, const TrackBlockParams& p, int mode)
 }
 static int launch_track_verify(gyp_ctx* ctx, const TrackVerifyParams& p, hipStream_t stream) {
     const int n_units = p.n_chan * (p.ms_end - p.ms_begin);
-    const int grid = std::max(8, std::min(n_units, ctx->n_cus * blocks_per_cu(8)) & ~7);
-    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(track_verify_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds_bytes<8>()));
-    hipLaunchKernelGGL(track_verify_kernel<8>, dim3(grid), dim3(threads_for(8)), lds_bytes<8>(), stream, p);
+    const int grid = std::max(8, std::min(n_units, ctx->n_cus * blocks_per_cu(ctx->k)) & ~7);
+    if (ctx->k == 2) {
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(track_verify_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds_bytes<2>()));
+        hipLaunchKernelGGL(track_verify_kernel<2>, dim3(grid), dim3(threads_for(2)), lds_bytes<2>(), stream, p);
+    } else {
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(track_verify_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds_bytes<8>()));
+        hipLaunchKernelGGL(track_verify_kernel<8>, dim3(grid), dim3(threads_for(8)), lds_bytes<8>(), stream, p);
+    }
     HIP_TRY(ctx, hipGetLastError());
     return GYP_OK;
 }
@@ -1120,7 +1129,7 @@ int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stri
     p.only_if = nullptr;
     p.restore_from = nullptr;
     p.dbg = nullptr;
-    const bool light = ctx->k == 8 && p.n_chan <= ctx->n_cus && !ctx->no_pipe;   // one workgroup per CU anyway
+    const bool light = (ctx->k == 8 || ctx->k == 2) && p.n_chan <= ctx->n_cus && !ctx->no_pipe;   // one workgroup per CU anyway
     if (light && !ctx->no_spec) return track_block_speculative(bank, p);
     return launch_track_block(ctx, p, 0);
 }

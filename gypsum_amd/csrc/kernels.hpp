@@ -1346,6 +1346,8 @@ struct ChanState {
     int64_t n_steps;                 // milliseconds processed (== entries ever appended to the histories)
     int32_t code_phase;              // current_prn_code_phase_shift
     int32_t lost;
+    int32_t win_centre1, pad0;       // speculative tracker: its window's centre lag + 1 (0: none yet), so that a block gives the
+                                     // same records however it is cut into launches
     LockSums sums;
     double err_ring[kLockWindow];    // carrier_wave_phase_errors, last 250
     double peak_re[kPeakHistory];    // correlation_peaks_rolling_buffer
@@ -1721,21 +1723,27 @@ __device__ __forceinline__ void rec_flush(const RedScratch* red, gyp_track_rec* 
     if (rec && lane < 14) reinterpret_cast<uint32_t*>(rec)[lane] = reinterpret_cast<const uint32_t*>(&red->rec)[lane];
 }
 
+// The speculative tracker runs every rate it supports with eight wavefronts (one window lag each): 512 threads own the
+// 1024 chip slots two apiece whatever K is (K = 8: the workgroup the other kernels use; K = 2: four times theirs).
+constexpr int kSpecThreads = 512;
+template <int K>
+constexpr bool kSpecRate = (K == 2 || K == 8);
 // ---- the Costas half again, split three ways for the speculative tracker (see RedScratch::cc) ----------------
 // One candidate: tracker.py:246-262 with the given loop bandwidth.
+template <int K>
 __device__ __forceinline__ void costas_candidate(double inv_fs, RedScratch* red, cf peak, double f, double phi,
                                                  double alpha, double beta, int slot, int lane) {
     const double err = (double)peak.x * (double)peak.y;
     const double nphi = pymod_uniform(phi + err * alpha, 6.283185307179586);
     const double nf = f + err * beta;
     const double2 rot = carrier64_small(nf * inv_fs);
-    const cf step = carrier_from_cycles_fast(nf * inv_fs * 4096.0);
+    const cf step = carrier_from_cycles_fast(nf * inv_fs * (double)(K * kSpecThreads));   // a thread's first chip -> its second
     if (lane == 0) {
         red->cc[slot].nf = nf; red->cc[slot].nphi = nphi;
         const cf rot1 = make_float2((float)rot.x, (float)rot.y);
         red->cc[slot].rot1 = rot1;
         red->cc[slot].step = step;
-        red->cc[slot].pscale = prompt_scale<8>(rot1, step);
+        red->cc[slot].pscale = prompt_scale<K>(rot1, step);
     }
 }
 // Everything else of costas_update -- histories, lock verdict, watchdog, the record's fields -- arranged so that ONLY the
@@ -1866,13 +1874,13 @@ __device__ __forceinline__ void spec_lock_verdict(const LoopParams& lp, double i
                     nudged = 1;
                     sel = 2;
                     const double2 rot = carrier64_small(nf * inv_fs);
-                    const cf step = carrier_from_cycles_fast(nf * inv_fs * 4096.0);
+                    const cf step = carrier_from_cycles_fast(nf * inv_fs * (double)(K * kSpecThreads));
                     if (lane == 0) {
                         red->cc[2].nf = nf; red->cc[2].nphi = nphi;
                         const cf rot1 = make_float2((float)rot.x, (float)rot.y);
                         red->cc[2].rot1 = rot1;
                         red->cc[2].step = step;
-                        red->cc[2].pscale = prompt_scale<8>(rot1, step);
+                        red->cc[2].pscale = prompt_scale<K>(rot1, step);
                     }
                 }
             }
@@ -1971,7 +1979,7 @@ struct WinCache {
 };
 template <int K>
 __device__ __forceinline__ void spec_window(const Smem& sm, const SpecLds& sl, int centre, int sN, int tid, WinCache& wc) {
-    static_assert(K == 8 && Geom<K>::W == 8, "one window lag per wavefront");
+    static_assert(kSpecRate<K>, "one window lag per wavefront of the 512-thread workgroup");
     constexpr int N = K * kChips;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     int la = __builtin_amdgcn_readfirstlane(centre) + wave - kSpecHalf;
@@ -2034,19 +2042,21 @@ template <int K>
 __device__ __attribute__((noinline)) EplResult spec_transform_path(const Smem& sm, const cf* __restrict__ rep, int sN) {
     const int tid = launder(threadIdx.x);
     const int wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
-    cf x[32];
-    const cf* yw = sm.xch + wave * kXchWave;
+    if (wave < K) {   // (uniform) one polyphase row per wavefront; at K = 2 six of the eight wavefronts only join the barrier
+        cf x[32];
+        const cf* yw = sm.xch + wave * kXchWave;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) x[j] = yw[32 * j + l];
-    halo_fixup<K>(x, sm.halo, wave, l);
-    wave_lds_fence();
-    float* tile_half = reinterpret_cast<float*>(sm.xch + wave * kXchWave) + h * kXchTile;
-    const LdsTables t{sm.tw1024, sm.tw2048};
-    cf c[16];
-    wave_fft_fwd(x, tile_half, t, l, h);
-    spectrum_mul_from(x, rep, lane);
-    wave_fft_inv(x, c, tile_half, t, l, h);
-    epl_round_wave<K>(c, sN, sN, sm.red, nullptr, tid);
+        for (int j = 0; j < 32; ++j) x[j] = yw[32 * j + l];
+        halo_fixup<K>(x, sm.halo, wave, l);
+        wave_lds_fence();
+        float* tile_half = reinterpret_cast<float*>(sm.xch + wave * kXchWave) + h * kXchTile;
+        const LdsTables t{sm.tw1024, sm.tw2048};
+        cf c[16];
+        wave_fft_fwd(x, tile_half, t, l, h);
+        spectrum_mul_from(x, rep, lane);
+        wave_fft_inv(x, c, tile_half, t, l, h);
+        epl_round_wave<K>(c, sN, sN, sm.red, nullptr, tid);
+    }
     return epl_finish_wave<K>(sm.red);
 }
 
@@ -2058,17 +2068,18 @@ __device__ __attribute__((noinline)) EplResult spec_transform_path(const Smem& s
 // the window held the global arg-max -- is left to track_verify_kernel, which runs the transforms of all (channel, ms)
 // pairs in parallel afterwards.  Otherwise the millisecond takes the transform path right here, from the same rows.
 template <int K, bool PROF, int MODE = 0>
-__global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPerSimd) void track_block_kernel(TrackBlockParams p) {
+__global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPerSimd) void track_block_kernel(TrackBlockParams p) {
     static_assert(MODE == 0 || MODE == 2, "r01's non-speculative latency variant (MODE 1) is gone: superseded by MODE 2");
     constexpr bool LAT = MODE == 2, SPEC = MODE == 2;
-    static_assert(!LAT || kOwnStaging<K>, "the latency form exists for the own-staging rates");
+    static_assert(!LAT || kSpecRate<K>, "the speculative form exists for K = 2 and K = 8");
+    constexpr int kThreadsHere = SPEC ? kSpecThreads : Geom<K>::kThreads;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int N = K * kChips;
     Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
     SpecLds sl{};
     if (LAT) {
         cf* tw2048 = reinterpret_cast<cf*>(smem_raw + lds_bytes<K>());
-        for (int i = threadIdx.x; i < 1024; i += Geom<K>::kThreads) tw2048[i] = p.tw_tables[1024 + i];
+        for (int i = threadIdx.x; i < 1024; i += kThreadsHere) tw2048[i] = p.tw_tables[1024 + i];
         sm.tw2048 = tw2048;
     }
     if (SPEC) {
@@ -2089,7 +2100,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
     if (p.restore_from) {   // re-run of a channel whose speculation failed verification: back to the state before the block
         const uint32_t* src = reinterpret_cast<const uint32_t*>(p.restore_from + ch);
         uint32_t* dst = reinterpret_cast<uint32_t*>(st);
-        for (int i = threadIdx.x; i < (int)(sizeof(ChanState) / 4); i += Geom<K>::kThreads) dst[i] = src[i];
+        for (int i = threadIdx.x; i < (int)(sizeof(ChanState) / 4); i += kThreadsHere) dst[i] = src[i];
         __threadfence();
         __syncthreads();
     }
@@ -2100,8 +2111,8 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
     const int nt = p.codes.n_trans[sat_index];
     if (SPEC) {
         const float* src = p.codes.chipf + sat_index * 2048;
-        for (int i = threadIdx.x; i < 2048; i += Geom<K>::kThreads) sl.chipf[i] = src[i];
-        for (int i = threadIdx.x; i < kMaxTrans; i += Geom<K>::kThreads) sl.trans[i] = trans[i];
+        for (int i = threadIdx.x; i < 2048; i += kThreadsHere) sl.chipf[i] = src[i];
+        for (int i = threadIdx.x; i < kMaxTrans; i += kThreadsHere) sl.trans[i] = trans[i];
     }
     // Loop state lives in LDS between milliseconds (RedScratch::dstate / istate / steps / loop) and is re-read where
     // it is needed, so that no wavefront carries it in registers across the transforms.
@@ -2114,13 +2125,13 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         sm.red->loop = ls;
         sm.red->dstate[0] = st->doppler; sm.red->dstate[1] = st->carrier_phase;
         sm.red->istate[0] = st->code_phase; sm.red->istate[1] = st->lost;
-        sm.red->istate[2] = mod_n(st->code_phase, N);   // speculative window centre: no peak seen yet in this launch
+        sm.red->istate[2] = st->win_centre1 > 0 ? st->win_centre1 - 1 : mod_n(st->code_phase, N);   // speculative window centre
         sm.red->steps = tracking_steps<K>(st->doppler * p.inv_fs);   // the same expression as after an update: a block gives
                                                                         // the same records however it is cut into launches
         sm.red->cc[0].nf = st->doppler; sm.red->cc[0].nphi = st->carrier_phase;
         sm.red->cc[0].rot1 = sm.red->steps.rot1;
-        sm.red->cc[0].step = carrier_from_cycles_fast(st->doppler * p.inv_fs * 4096.0);
-        sm.red->cc[0].pscale = prompt_scale<8>(sm.red->cc[0].rot1, sm.red->cc[0].step);
+        sm.red->cc[0].step = carrier_from_cycles_fast(st->doppler * p.inv_fs * (double)(K * kSpecThreads));
+        sm.red->cc[0].pscale = prompt_scale<K>(sm.red->cc[0].rot1, sm.red->cc[0].step);
         sm.red->pscale = kOwnStaging<K> ? prompt_scale<K>(sm.red->steps.rot1, make_float2(1.f, 0.f)) : 1.0;
         sm.red->cand_sel = 0; sm.red->rec_sel = 0;
         sm.red->defer = 0;
@@ -2132,7 +2143,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
     long long t_last = 0;
     // speculative mode: tp[6 + i] accumulates the cycles between stamp i-1 and stamp i of workgroup 0's thread 0
 #define GYP_STAMP(i) do { if (prof) { const long long now_ = (long long)__builtin_readcyclecounter(); tp[6 + (i)] += now_ - t_last; t_last = now_; } } while (0)
-    OwnSamples<LAT ? K : 1> smp;          // LAT: the next millisecond's raw samples
+    OwnSamples<LAT ? K : 1, LAT ? kSpecThreads : 64> smp;   // LAT: the next millisecond's raw samples
     if constexpr (LAT) {
         if (p.ms_begin < p.ms_end) stage_fetch_own<K>(stream + (int64_t)p.ms_begin * N, smp, launder(threadIdx.x));
     }
@@ -2142,7 +2153,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
     int el_off0 = -1, el_off1 = -1;
     float el_g0 = 0.f, el_g1 = 0.f;
     if constexpr (SPEC) {
-        const int e0 = launder(threadIdx.x), e1 = e0 + Geom<K>::kThreads;
+        const int e0 = launder(threadIdx.x), e1 = e0 + kSpecThreads;
         if (e0 < nt) { const unsigned t = trans[e0]; el_off0 = K * (int)(t & 0x3ffu); el_g0 = (t & 0x8000u) ? -2.0f : 2.0f; }
         if (e1 < nt) { const unsigned t = trans[e1]; el_off1 = K * (int)(t & 0x3ffu); el_g1 = (t & 0x8000u) ? -2.0f : 2.0f; }
     }
@@ -2202,19 +2213,20 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
                 const ElSample el0 = el_fetch_const<K>(block, sN, el_off0, el_g0);
                 ElSample el1;
                 el1.nl = -1;
-                if (nt > Geom<K>::kThreads) el1 = el_fetch_const<K>(block, sN, el_off1, el_g1);   // uniform
+                if (nt > kSpecThreads) el1 = el_fetch_const<K>(block, sN, el_off1, el_g1);   // uniform
                 GYP_STAMP(1);
                 // (the last thread's second chip is the padding chip: its registers hold a copy of chip 1022, see stage_fetch_own)
-                const bool chip1 = tid + OwnSamples<K>::T < kChips;
+                const bool chip1 = tid + kSpecThreads < kChips;
+                constexpr int kEs = K >= 2 ? K / 2 : 1;   // two samples per chip are summed: every (K / 2)-th
                 const float e_in = (smp.w[0][0].x * smp.w[0][0].x + smp.w[0][0].y * smp.w[0][0].y) +
-                                   (smp.w[0][4].x * smp.w[0][4].x + smp.w[0][4].y * smp.w[0][4].y) +
+                                   (smp.w[0][kEs].x * smp.w[0][kEs].x + smp.w[0][kEs].y * smp.w[0][kEs].y) +
                                    (chip1 ? smp.w[1][0].x * smp.w[1][0].x + smp.w[1][0].y * smp.w[1][0].y : 0.f) +
-                                   (chip1 ? smp.w[1][4].x * smp.w[1][4].x + smp.w[1][4].y * smp.w[1][4].y : 0.f);
+                                   (chip1 ? smp.w[1][kEs].x * smp.w[1][kEs].x + smp.w[1][kEs].y * smp.w[1][kEs].y : 0.f);
                 cf* y_rows[K];
 #pragma unroll
                 for (int r = 0; r < K; ++r) y_rows[r] = sm.xch + r * kXchWave;
                 {
-                    static_assert(OwnSamples<K>::CH == 2 && OwnSamples<K>::T * K == 4096, "second chip = first + 4096 samples");
+                    static_assert(OwnSamples<K, kSpecThreads>::CH == 2, "second chip = first + K * 512 samples");
                     cf anchor[2];
                     anchor[0] = carrier_from_cycles_fast(u0 + du * (double)(K * tid));
                     anchor[1] = cmul(anchor[0], half_step);
@@ -2223,9 +2235,9 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
                 GYP_STAMP(2);
                 double acc[4] = {0.0, 0.0, 0.0, 0.0};
                 el_accumulate<K>(el0, u0, du, acc);
-                if (nt > Geom<K>::kThreads && __any(el1.nl >= 0)) el_accumulate<K>(el1, u0, du, acc);
+                if (nt > kSpecThreads && __any(el1.nl >= 0)) el_accumulate<K>(el1, u0, du, acc);
 #pragma unroll
-                for (int v = 0; v < 4; ++v) sl.part[v * Geom<K>::kThreads + tid] = acc[v];
+                for (int v = 0; v < 4; ++v) sl.part[v * kSpecThreads + tid] = acc[v];
                 sl.ein_part[tid] = e_in;
                 asm volatile("; MARK_STAGE_END");
                 GYP_STAMP(3);
@@ -2268,7 +2280,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
                 int wbest = blag - centre + kSpecHalf;
                 wbest = wbest < 0 ? wbest + N : (wbest >= N ? wbest - N : wbest);
                 const float2 eq = *reinterpret_cast<const float2*>(sl.fin + 8);
-                const float energy = 4.0f * (eq.x + eq.y);   // every 4th sample was summed
+                const float energy = (float)(K >= 2 ? K / 2 : 1) * (eq.x + eq.y);   // every (K / 2)-th sample was summed
                 const bool fast = wbest != 0 && wbest != 2 * kSpecHalf - 1 && b.v >= p.spec_kappa * energy;
                 if (prof) { t_c = (long long)__builtin_readcyclecounter(); tp[5] += fast ? 0 : 1; }
                 if (p.dbg && wave == 0 && lane < 20) {
@@ -2326,8 +2338,8 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
                 if (lane == 0) launder_lds(sm.red)->t0_next = tn;
             }
             if (wave == 1) dll_update(launder_lds(sm.red), m.disc, lane, kc->lp);
-            if (wave == 2) costas_candidate(kc->inv_fs, launder_lds(sm.red), m.peak, f, phi, kc->lp.alpha_locked, kc->lp.beta_locked, 0, lane);
-            if (wave == 3) costas_candidate(kc->inv_fs, launder_lds(sm.red), m.peak, f, phi, kc->lp.alpha_unlocked, kc->lp.beta_unlocked, 1, lane);
+            if (wave == 2) costas_candidate<K>(kc->inv_fs, launder_lds(sm.red), m.peak, f, phi, kc->lp.alpha_locked, kc->lp.beta_locked, 0, lane);
+            if (wave == 3) costas_candidate<K>(kc->inv_fs, launder_lds(sm.red), m.peak, f, phi, kc->lp.alpha_unlocked, kc->lp.beta_unlocked, 1, lane);
         } else if (wave == 0) {
             RedScratch* red = launder_lds(sm.red);
             fetch_leaving(st, red, leave);
@@ -2355,6 +2367,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPer
         st->doppler = SPEC ? sm.red->cc[sm.red->cand_sel].nf : sm.red->dstate[0];
         st->carrier_phase = SPEC ? sm.red->cc[sm.red->cand_sel].nphi : sm.red->dstate[1];
         st->code_phase = sm.red->istate[0]; st->lost = sm.red->istate[1];
+        st->win_centre1 = SPEC ? sm.red->istate[2] + 1 : 0;
         const LoopState ls = sm.red->loop;
         st->dll_phase = ls.dll_phase; st->n_steps = ls.n_steps; st->last_watchdog_time = ls.last_watchdog;
         st->sums = ls.sums;
@@ -2431,6 +2444,7 @@ __global__ void bank_reset_kernel(ChanState* states, const gyp_chan_init* inits,
     s->n_steps = 0;
     s->code_phase = in.code_phase;
     s->lost = 0;
+    s->win_centre1 = 0; s->pad0 = 0;
     s->sums = LockSums{};
 }
 

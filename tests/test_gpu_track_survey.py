@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 FS, N = 8_184_000, 8184
 
 
-def _compare(eng, seed, path, inits, traj, n_ms, tally, label):
+def _compare(eng, seed, path, inits, traj, n_ms, tally, label, FS=FS, N=N):
     iq = np.load(path)
     init_rec = np.zeros(len(inits), dtype=_lib.CHAN_INIT)
     for i, (sv, dop, phi, cp) in enumerate(inits):
@@ -53,7 +53,7 @@ def _compare(eng, seed, path, inits, traj, n_ms, tally, label):
             assert rec[i, k]["status"] == 1, (label, seed, i, k)
 
 
-def _survey(engine, seeds, n_ms, n_sats, label):
+def _survey(engine, seeds, n_ms, n_sats, label, FS=FS, N=N):
     procs = max(1, min(64, (os.cpu_count() or 2) - 2, len(seeds)))
     tally = {"n": 0, "sym": 0, "cp": 0, "off": 0, "lock": 0, "dop": 0.0, "fast": 0, "first": []}
     t_start = time.time()
@@ -62,7 +62,7 @@ def _survey(engine, seeds, n_ms, n_sats, label):
         for seed, path, inits, traj in pool.imap_unordered(survey_worker.run_scene,
                                                            [(FS, n_ms, n_sats, s, None) for s in seeds]):
             try:
-                _compare(engine, seed, path, inits, traj, n_ms, tally, label)
+                _compare(engine, seed, path, inits, traj, n_ms, tally, label, FS, N)
             finally:
                 os.unlink(path)
     print(f"[{label}] {tally['n']} channel-ms over {len(seeds)} scenes at {FS / 1e6:.3f} Msps in {time.time() - t_start:.0f} s "
@@ -110,6 +110,18 @@ def test_tracking_survey_one_million_channel_ms(engine_factory):
     assert t["sym"] == 0 and t["cp"] == 0 and t["off"] == 0 and t["lock"] == 0
     assert t["dop"] < 1e-3
     assert t["fast"] > 0.9 * t["n"]        # the survey really went through the path it is named after
+
+
+def test_tracking_survey_2046(engine_factory):
+    """The reference's 2x recording rate through the speculative tracker (K = 2: eight wavefronts on two polyphase rows,
+    a quarter of the processing gain, so about a quarter of the milliseconds take the in-kernel transform path):
+    40 scenes x 12 channels x 1000 ms."""
+    fs, n = 2_046_000, 2046
+    eng = engine_factory(fs, n)
+    t = _survey(eng, list(range(71000, 71040)), 1009, 12, "speculative 2.046 Msps", fs, n)
+    assert t["n"] >= 470_000
+    assert t["sym"] == 0 and t["cp"] == 0 and t["off"] == 0 and t["lock"] == 0
+    assert 0.5 * t["n"] < t["fast"] < t["n"]
 
 
 @pytest.mark.parametrize("env", ["GYP_NO_SPEC", "GYP_NO_PIPE"])
