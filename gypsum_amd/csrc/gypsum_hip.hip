@@ -769,12 +769,16 @@ static int acquire_search(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, 
     if ((rc = ensure_scratch(ctx, 1, n_cells * sizeof(gyp_cell_desc)))) return rc;
     if ((rc = ensure_scratch(ctx, 2, n_cells * sizeof(gyp_cell)))) return rc;
     if ((rc = ensure_scratch(ctx, 3, n_cells * sizeof(double)))) return rc;
-    // previous level's records, reuse map, the level's work list and its length
-    if ((rc = ensure_scratch(ctx, 8, n_cells * (sizeof(gyp_cell) + 2 * sizeof(int32_t)) + 64))) return rc;
+    // previous level's records, reuse map, the level's work list, the tie-break's candidate list, their lengths
+    if ((rc = ensure_scratch(ctx, 8, n_cells * (sizeof(gyp_cell) + 3 * sizeof(int32_t)) + 64))) return rc;
     gyp_cell* d_prev_out = (gyp_cell*)ctx->scratch[8];
     int32_t* d_reuse = (int32_t*)(d_prev_out + n_cells);
     int32_t* d_order = d_reuse + n_cells;
-    int32_t* d_n_active = d_order + n_cells;
+    int32_t* d_cand = d_order + n_cells;
+    int32_t* d_n_active = d_cand + n_cells;
+    int32_t* d_n_cand = d_n_active + 1;
+    if ((rc = ensure_scratch(ctx, 9, n_cells * (size_t)n_ms * sizeof(double)))) return rc;   // per-ms magnitudes of the candidates
+    double* d_partial = (double*)ctx->scratch[9];
     const size_t profile_bytes = (size_t)n_states * 2 * ctx->n * sizeof(double);
     const void* profiles_before = ctx->scratch[7];
     if ((rc = ensure_scratch(ctx, 7, profile_bytes))) return rc;
@@ -792,11 +796,12 @@ static int acquire_search(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, 
     const int tpb = 64, nblk = (n_states + tpb - 1) / tpb;
     for (double spread = spread0; single_level ? spread == spread0 : spread >= ctx->params.acq_min_spread_hz; spread /= 2.0) {  // acquisition.py:81,89
         hipLaunchKernelGGL(acq_plan_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_cells, d_reuse, ctx->params.acq_bins_per_spread);
-        hipLaunchKernelGGL(acq_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const gyp_cell_desc*)d_cells, (int)n_cells, d_order, d_n_active);
+        hipLaunchKernelGGL(acq_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const gyp_cell_desc*)d_cells, (int)n_cells, d_order, d_n_active, d_n_cand);
         rc = correlate_cells_listed(ctx, iq_dev, stream_stride_samples, n_ms, d_cells, (int32_t)n_cells, GYP_NON_COHERENT, d_out, nullptr,
                                     d_order, d_n_active);
         if (rc) return rc;
-        hipLaunchKernelGGL(acq_reuse_kernel, dim3((unsigned)n_states), dim3(32), 0, ctx->stream, (const int32_t*)d_reuse, d_out, d_prev_out, n_states);
+        hipLaunchKernelGGL(acq_reuse_kernel, dim3((unsigned)n_states), dim3(64), 0, ctx->stream, (const int32_t*)d_reuse, d_out, d_prev_out,
+                           (const AcqSearchState*)d_states, d_refined, d_cand, d_n_cand, n_states);
         RefineParams rp;
         rp.iq = reinterpret_cast<const cf*>(iq_dev);
         rp.stream_stride = stream_stride_samples;
@@ -809,13 +814,17 @@ static int acquire_search(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, 
         rp.refined = d_refined;
         rp.chips = ctx->d_chips;
         rp.inv_fs = 1.0 / (double)ctx->fs;
-        hipLaunchKernelGGL(acq_refine_kernel, dim3((unsigned)n_cells), dim3(256), 0, ctx->stream, rp);
+        rp.cand = d_cand; rp.n_cand = d_n_cand; rp.partial = d_partial;
+        // normally one or two candidates per (stream, satellite): 2 n_states slots x n_ms blocks, strided beyond that
+        hipLaunchKernelGGL(acq_refine_kernel, dim3((unsigned)std::min<size_t>(n_cells, 2 * (size_t)n_states), (unsigned)n_ms), dim3(256), 0, ctx->stream, rp);
+        hipLaunchKernelGGL(acq_refine_sum_kernel, dim3((unsigned)((n_states + 63) / 64)), dim3(64), 0, ctx->stream, rp);
         hipLaunchKernelGGL(acq_reduce_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_out, d_refined, ctx->n);
         // cross-level near-ties in strength: float64 profiles for the (few) pending pairs, else immediate exits
         ExactParams ep;
         ep.iq = rp.iq; ep.stream_stride = stream_stride_samples; ep.n_ms = n_ms; ep.n_per_ms = ctx->n; ep.k = ctx->k; ep.n_states = n_states;
         ep.states = d_states; ep.ones = ctx->d_ones; ep.inv_fs = rp.inv_fs; ep.profiles = d_profiles;
-        hipLaunchKernelGGL(acq_exact_profile_kernel, dim3((unsigned)(ctx->k * n_ms), 2, (unsigned)std::min(n_states, 32)), dim3(1024), 0, ctx->stream, ep);
+        // (pending pairs are rare -- about one acquisition in a hundred: a short z grid whose blocks walk the states)
+        hipLaunchKernelGGL(acq_exact_profile_kernel, dim3((unsigned)(ctx->k * n_ms), 2, (unsigned)std::min(n_states, 4)), dim3(1024), 0, ctx->stream, ep);
         hipLaunchKernelGGL(acq_exact_decide_kernel, dim3((unsigned)n_states), dim3(256), 0, ctx->stream, ep);
     }
     if (single_level) {

@@ -2513,8 +2513,10 @@ __global__ void acq_plan_kernel(AcqSearchState* states, int n_states, gyp_cell_d
         cells[i * kMaxBins + b] = d;
     }
 }
+constexpr float kTieBand = 2e-5f;   // float64 tie-break band of a level's bins (see acq_refine_kernel)
 // The level's work list: indices of the cells that are neither padding nor cached, ascending (one block).
-__global__ __launch_bounds__(1024) void acq_compact_kernel(const gyp_cell_desc* __restrict__ cells, int n_cells, int32_t* order, int32_t* n_active) {
+__global__ __launch_bounds__(1024) void acq_compact_kernel(const gyp_cell_desc* __restrict__ cells, int n_cells, int32_t* order, int32_t* n_active,
+                                                           int32_t* n_cand) {
     __shared__ int wave_tot[16];
     __shared__ int base;
     if (threadIdx.x == 0) base = 0;
@@ -2535,12 +2537,17 @@ __global__ __launch_bounds__(1024) void acq_compact_kernel(const gyp_cell_desc* 
         if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wave_tot[w]; base += t; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) *n_active = base;
+    if (threadIdx.x == 0) { *n_active = base; *n_cand = 0; }
 }
 // out[i][b] <- the previous level's record of the same bin; then the level's records become "the previous level's".
-__global__ void acq_reuse_kernel(const int32_t* __restrict__ reuse, gyp_cell* out, gyp_cell* prev_out, int n_states) {
-    const int i = blockIdx.x;                       // one 32-thread block per state
+// Also the work list of the float64 tie-break (acq_refine_kernel): the bins whose peak is within kTieBand of the level's
+// maximum -- the top bin always -- are appended to `cand` (*n_cand was zeroed by acq_compact_kernel); every other bin's
+// refined value is -1.
+__global__ void acq_reuse_kernel(const int32_t* __restrict__ reuse, gyp_cell* out, gyp_cell* prev_out, const AcqSearchState* states,
+                                 double* refined, int32_t* cand, int32_t* n_cand, int n_states) {
+    const int i = blockIdx.x;                       // one 64-thread block (one wavefront) per state
     const int b = threadIdx.x;
+    const int nb = states[i].n_bins;
     gyp_cell c = {};
     if (b < kMaxBins) {
         const int from = reuse[i * kMaxBins + b];
@@ -2548,6 +2555,12 @@ __global__ void acq_reuse_kernel(const int32_t* __restrict__ reuse, gyp_cell* ou
     }
     __syncthreads();                                // every read of prev_out precedes its overwrite
     if (b < kMaxBins) { out[i * kMaxBins + b] = c; prev_out[i * kMaxBins + b] = c; }
+    const float level_max = wave_max(b < nb ? c.peak : -1.f);
+    if (b < kMaxBins) {
+        const bool on = b < nb && !(c.peak < level_max * (1.0f - kTieBand));
+        refined[i * kMaxBins + b] = -1.0;
+        if (on) cand[atomicAdd(n_cand, 1)] = i * kMaxBins + b;
+    }
 }
 
 __device__ __forceinline__ double cell_strength(const gyp_cell& c, int n) {
@@ -2562,7 +2575,6 @@ __device__ __forceinline__ double cell_strength(const gyp_cell& c, int n) {
 // float64, directly in the time domain, at their own arg-max lag:
 //     V = sum_ms | sum_n x[ms, n] * exp(-2*pi*i*f*t(ms, n)) * code[(n - lag) mod N] |
 // which is exactly the profile value the float64 reference compares.  Usually only the finest levels have ties.
-constexpr float kTieBand = 2e-5f;
 constexpr double kStrengthBand = 3e-7;   // cross-level strength near-tie band (see acq_exact_* below)
 
 struct RefineParams {
@@ -2575,38 +2587,26 @@ struct RefineParams {
     double* refined;                // [n_states][kMaxBins], < 0 where not a candidate
     const uint8_t* chips;           // [32][1023]
     double inv_fs;
+    const int32_t* cand;            // the level's candidate cells (acq_reuse_kernel), *n_cand of them, any order
+    const int32_t* n_cand;
+    double* partial;                // [n_cells][n_ms]: the per-millisecond magnitudes of candidate cell c at partial[c * n_ms ..]
 };
 
 __global__ __launch_bounds__(256) void acq_refine_kernel(RefineParams p) {
+    // grid (candidate slots, n_ms): one block per candidate cell and millisecond; the candidates are walked with a stride so
+    // that any number of them is served
     __shared__ double red_re[4], red_im[4];
-    __shared__ float level_max;
-    const int state = blockIdx.x / kMaxBins, bin = blockIdx.x % kMaxBins;
-    const AcqSearchState st = p.states[state];
-    if (bin >= st.n_bins) return;
-    if (threadIdx.x == 0) {
-        float m = -1.f;
-        int n_close = 0;
-        for (int b = 0; b < st.n_bins; ++b) m = fmaxf(m, p.out[state * kMaxBins + b].peak);
-        for (int b = 0; b < st.n_bins; ++b) n_close += p.out[state * kMaxBins + b].peak >= m * (1.0f - kTieBand) ? 1 : 0;
-        (void)n_close;
-        level_max = m;   // the level's top bin is always refined: its float64 peak also sharpens the strength (below)
-    }
-    __syncthreads();
-    const gyp_cell cell = p.out[blockIdx.x];
-    if (cell.peak < level_max * (1.0f - kTieBand)) {
-        if (threadIdx.x == 0) p.refined[blockIdx.x] = -1.0;
-        return;
-    }
-    const gyp_cell_desc d = p.cells[blockIdx.x];
-    const int n = p.n_per_ms, lag = cell.argmax;
-    const uint8_t* code = p.chips + (d.sat_id - 1) * kChips;
-    const cf* stream = p.iq + (int64_t)d.stream * p.stream_stride;
-    const double du = d.doppler_hz * p.inv_fs;
-    double s_step, c_step;
-    sincospi(2.0 * (du * 256.0 - rint(du * 256.0)), &s_step, &c_step);     // exp(-2*pi*i*du*256) = (c, -s)
-    double total = 0.0;
-    for (int ms = 0; ms < p.n_ms; ++ms) {
-        const cf* block = stream + (int64_t)ms * n;
+    const int n_cand = *p.n_cand, ms = blockIdx.y;
+    for (int c = blockIdx.x; c < n_cand; c += gridDim.x) {
+        const int ci_cell = p.cand[c];
+        const gyp_cell cell = p.out[ci_cell];
+        const gyp_cell_desc d = p.cells[ci_cell];
+        const int n = p.n_per_ms, lag = cell.argmax;
+        const uint8_t* code = p.chips + (d.sat_id - 1) * kChips;
+        const cf* block = p.iq + (int64_t)d.stream * p.stream_stride + (int64_t)ms * n;
+        const double du = d.doppler_hz * p.inv_fs;
+        double s_step, c_step;
+        sincospi(2.0 * (du * 256.0 - rint(du * 256.0)), &s_step, &c_step);     // exp(-2*pi*i*du*256) = (c, -s)
         const double u = d.doppler_hz * (((double)((int64_t)ms * n) + (double)threadIdx.x) * p.inv_fs);
         double sn, cs;
         sincospi(2.0 * (u - rint(u)), &sn, &cs);
@@ -2626,12 +2626,22 @@ __global__ __launch_bounds__(256) void acq_refine_kernel(RefineParams p) {
         acc_im = wave_sum(acc_im);
         if ((threadIdx.x & 63) == 0) { red_re[threadIdx.x >> 6] = acc_re; red_im[threadIdx.x >> 6] = acc_im; }
         __syncthreads();
-        const double re = (red_re[0] + red_re[1]) + (red_re[2] + red_re[3]);
-        const double im = (red_im[0] + red_im[1]) + (red_im[2] + red_im[3]);
-        total += sqrt(re * re + im * im);
+        if (threadIdx.x == 0) {
+            const double re = (red_re[0] + red_re[1]) + (red_re[2] + red_re[3]);
+            const double im = (red_im[0] + red_im[1]) + (red_im[2] + red_im[3]);
+            p.partial[(int64_t)c * p.n_ms + ms] = sqrt(re * re + im * im);
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) p.refined[blockIdx.x] = total;
+}
+// refined[cell] = the candidate's magnitudes summed in millisecond order (the order the reference integrates in).
+__global__ void acq_refine_sum_kernel(RefineParams p) {
+    const int n_cand = *p.n_cand;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_cand; c += gridDim.x * blockDim.x) {
+        double total = 0.0;
+        for (int ms = 0; ms < p.n_ms; ++ms) total += p.partial[(int64_t)c * p.n_ms + ms];
+        p.refined[p.cand[c]] = total;
+    }
 }
 
 // Fold one level's cells into the search state: best bin = first bin holding the largest maximum
