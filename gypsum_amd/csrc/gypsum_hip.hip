@@ -776,7 +776,9 @@ static int acquire_search(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, 
     int32_t* d_order = d_reuse + n_cells;
     int32_t* d_cand = d_order + n_cells;
     int32_t* d_n_active = d_cand + n_cells;
-    int32_t* d_n_cand = d_n_active + 1;
+    int32_t* d_n_cand = d_n_active + 1;      // [0] candidates of the tie-break, [1] pending cross-level pairs
+    int32_t* d_n_pend = d_n_cand + 1;
+    int32_t* d_pend = d_reuse;               // the reuse map is consumed by acq_reuse_kernel before acq_reduce_kernel fills this
     if ((rc = ensure_scratch(ctx, 9, n_cells * (size_t)n_ms * sizeof(double)))) return rc;   // per-ms magnitudes of the candidates
     double* d_partial = (double*)ctx->scratch[9];
     const size_t profile_bytes = (size_t)n_states * 2 * ctx->n * sizeof(double);
@@ -818,14 +820,15 @@ static int acquire_search(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, 
         // normally one or two candidates per (stream, satellite): 2 n_states slots x n_ms blocks, strided beyond that
         hipLaunchKernelGGL(acq_refine_kernel, dim3((unsigned)std::min<size_t>(n_cells, 2 * (size_t)n_states), (unsigned)n_ms), dim3(256), 0, ctx->stream, rp);
         hipLaunchKernelGGL(acq_refine_sum_kernel, dim3((unsigned)((n_states + 63) / 64)), dim3(64), 0, ctx->stream, rp);
-        hipLaunchKernelGGL(acq_reduce_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_out, d_refined, ctx->n);
+        hipLaunchKernelGGL(acq_reduce_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_out, d_refined, ctx->n, d_pend, d_n_pend);
         // cross-level near-ties in strength: float64 profiles for the (few) pending pairs, else immediate exits
         ExactParams ep;
         ep.iq = rp.iq; ep.stream_stride = stream_stride_samples; ep.n_ms = n_ms; ep.n_per_ms = ctx->n; ep.k = ctx->k; ep.n_states = n_states;
         ep.states = d_states; ep.ones = ctx->d_ones; ep.inv_fs = rp.inv_fs; ep.profiles = d_profiles;
+        ep.pend = d_pend; ep.n_pend = d_n_pend;
         // (pending pairs are rare -- about one acquisition in a hundred: a short z grid whose blocks walk the states)
         hipLaunchKernelGGL(acq_exact_profile_kernel, dim3((unsigned)(ctx->k * n_ms), 2, (unsigned)std::min(n_states, 4)), dim3(1024), 0, ctx->stream, ep);
-        hipLaunchKernelGGL(acq_exact_decide_kernel, dim3((unsigned)n_states), dim3(256), 0, ctx->stream, ep);
+        hipLaunchKernelGGL(acq_exact_decide_kernel, dim3((unsigned)std::min(n_states, 32)), dim3(256), 0, ctx->stream, ep);
     }
     if (single_level) {
         hipLaunchKernelGGL(acq_finish_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, (const gyp_cell*)nullptr, out_dev);

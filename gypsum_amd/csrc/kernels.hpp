@@ -2537,7 +2537,7 @@ __global__ __launch_bounds__(1024) void acq_compact_kernel(const gyp_cell_desc* 
         if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wave_tot[w]; base += t; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { *n_active = base; *n_cand = 0; }
+    if (threadIdx.x == 0) { *n_active = base; *n_cand = 0; n_cand[1] = 0; }   // n_cand[1]: the level's pending-pair count
 }
 // out[i][b] <- the previous level's record of the same bin; then the level's records become "the previous level's".
 // Also the work list of the float64 tie-break (acq_refine_kernel): the bins whose peak is within kTieBand of the level's
@@ -2648,7 +2648,7 @@ __global__ void acq_refine_sum_kernel(RefineParams p) {
 // (acquisition.py:180-182; float64 tie-break values where present), centre <- its Doppler, spread halves, overall
 // best replaced on strictly greater strength (:92-101).
 __global__ void acq_reduce_kernel(AcqSearchState* states, int n_states, const gyp_cell* cells, const double* refined,
-                                  int n_samples) {
+                                  int n_samples, int32_t* pend, int32_t* n_pend) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_states) return;
     AcqSearchState s = states[i];
@@ -2680,6 +2680,7 @@ __global__ void acq_reduce_kernel(AcqSearchState* states, int n_states, const gy
         if (fabs(strength - s.best_strength) <= kStrengthBand * s.best_strength) {
             s.pending = 1;                    // too close to call in float32: acq_exact_* decides in float64
             s.cand_doppler = doppler;
+            pend[atomicAdd(n_pend, 1)] = i;   // (*n_pend was zeroed by acq_compact_kernel; the exact kernels walk this list)
         } else if (strength > s.best_strength) {
             s.best_doppler = doppler; s.best_index = c.argmax; s.best_strength = strength; s.best_is_exact = 0;
         }
@@ -2703,6 +2704,8 @@ struct ExactParams {
     const uint16_t* ones;   // [32][512] chip positions holding a one
     double inv_fs;
     double* profiles;   // [n_states][2][N]: candidate, incumbent
+    const int32_t* pend;    // states with a pending cross-level near-tie this level (acq_reduce_kernel), *n_pend of them
+    const int32_t* n_pend;
 };
 
 // grid: (K * n_ms, 2, min(n_states, 32)); block 1024
@@ -2711,7 +2714,9 @@ __global__ __launch_bounds__(1024) void acq_exact_profile_kernel(ExactParams p) 
     __shared__ uint16_t ones[512];
     __shared__ double tot_re[16], tot_im[16];
     const int which = blockIdx.y;
-    for (int state = blockIdx.z; state < p.n_states; state += gridDim.z) {   // few states are pending: a short z grid
+    const int n_pend = *p.n_pend;
+    for (int pi = blockIdx.z; pi < n_pend; pi += gridDim.z) {   // few states are pending (usually none): a short z grid
+    const int state = p.pend[pi];
     const AcqSearchState st = p.states[state];
     if (!st.pending || (which == 1 && st.best_is_exact)) continue;           // uniform across the workgroup
     const int K = p.k, N = p.n_per_ms, r = blockIdx.x % K, ms = blockIdx.x / K;
@@ -2761,9 +2766,11 @@ __global__ __launch_bounds__(1024) void acq_exact_profile_kernel(ExactParams p) 
 __global__ __launch_bounds__(256) void acq_exact_decide_kernel(ExactParams p) {
     __shared__ double s_max[4], s_sum[4];
     __shared__ int s_arg[4], s_cnt[4];
-    const int state = blockIdx.x;
+    const int n_pend = *p.n_pend;
+    for (int pi = blockIdx.x; pi < n_pend; pi += gridDim.x) {   // (uniform)
+    const int state = p.pend[pi];
     AcqSearchState st = p.states[state];
-    if (!st.pending) return;
+    if (!st.pending) continue;
     const int N = p.n_per_ms;
     double strength[2] = {0.0, st.best_strength};
     int argmax[2] = {0, st.best_index};
@@ -2811,6 +2818,8 @@ __global__ __launch_bounds__(256) void acq_exact_decide_kernel(ExactParams p) {
     // clears the scratch once, not per level (each thread re-visits exactly the elements it read)
     double* rows = p.profiles + (int64_t)state * 2 * N;
     for (int i = threadIdx.x; i < 2 * N; i += 256) rows[i] = 0.0;
+    __syncthreads();
+    }
 }
 
 // One coherent cell per (stream, satellite) at the winning Doppler, tapped at the winning code phase (:122-136).
