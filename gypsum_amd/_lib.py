@@ -35,7 +35,7 @@ PARAMS = np.dtype([(k, "<f8") for k in (
     "acq_initial_spread_hz", "acq_min_spread_hz", "acq_bins_per_spread", "dll_gain", "dll_phase_modulus",
     "pll_bandwidth_locked_hz", "pll_bandwidth_unlocked_hz", "lock_error_variance_max", "lock_i_variance_max",
     "lock_rotation_max_deg", "watchdog_period_s", "watchdog_drop_below", "watchdog_nudge_below", "watchdog_nudge_hz",
-    "spec_confidence_kappa")], align=True)
+    "spec_confidence_kappa", "acq_reuse_level_records")], align=True)
 TRACK_REC = np.dtype([("peak_re", "<f4"), ("peak_im", "<f4"), ("strength", "<f4"), ("discriminator", "<f4"),
                       ("doppler_hz", "<f8"), ("carrier_phase", "<f8"), ("error", "<f8"), ("code_phase", "<i4"),
                       ("peak_offset", "<i4"), ("pseudosymbol", "i1"), ("locked", "i1"), ("status", "i1"),

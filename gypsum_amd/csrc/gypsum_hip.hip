@@ -249,6 +249,7 @@ void gyp_params_default(gyp_params* p) {
     p->lock_error_variance_max = 900.0; p->lock_i_variance_max = 2.0; p->lock_rotation_max_deg = 6.0;
     p->watchdog_period_s = 6.0; p->watchdog_drop_below = 0.2; p->watchdog_nudge_below = 0.93; p->watchdog_nudge_hz = 5.0;
     p->spec_confidence_kappa = 20.0;
+    p->acq_reuse_level_records = 0.0;
 }
 
 int gyp_set_params(gyp_ctx* ctx, const gyp_params* p) {
@@ -256,7 +257,8 @@ int gyp_set_params(gyp_ctx* ctx, const gyp_params* p) {
     if (!(p->acq_initial_spread_hz > 0) || !(p->acq_min_spread_hz > 0) || !(p->acq_bins_per_spread >= 1) || !(p->dll_phase_modulus > 0) ||
         !(p->pll_bandwidth_locked_hz > 0) || !(p->pll_bandwidth_unlocked_hz > 0) || !(p->lock_error_variance_max > 0) ||
         !(p->lock_i_variance_max > 0) || !(p->lock_rotation_max_deg > 0 && p->lock_rotation_max_deg < 90) || !(p->watchdog_period_s > 0) ||
-        !(p->spec_confidence_kappa >= 0) || !std::isfinite(p->dll_gain))
+        !(p->spec_confidence_kappa >= 0) || !std::isfinite(p->dll_gain) ||
+        !(p->acq_reuse_level_records == 0.0 || p->acq_reuse_level_records == 1.0))
         return fail(ctx, GYP_E_BAD_ARG, "gyp_set_params: value out of range");
     for (double s = p->acq_initial_spread_hz; s >= p->acq_min_spread_hz; s /= 2.0) {   // every level must fit the cell table
         const int step = (int)(s / p->acq_bins_per_spread);
@@ -797,7 +799,8 @@ static int acquire_search(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, 
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `init` is a local
     const int tpb = 64, nblk = (n_states + tpb - 1) / tpb;
     for (double spread = spread0; single_level ? spread == spread0 : spread >= ctx->params.acq_min_spread_hz; spread /= 2.0) {  // acquisition.py:81,89
-        hipLaunchKernelGGL(acq_plan_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_cells, d_reuse, ctx->params.acq_bins_per_spread);
+        hipLaunchKernelGGL(acq_plan_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_cells, d_reuse, ctx->params.acq_bins_per_spread,
+                           ctx->params.acq_reuse_level_records != 0.0 ? 1 : 0);
         hipLaunchKernelGGL(acq_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const gyp_cell_desc*)d_cells, (int)n_cells, d_order, d_n_active, d_n_cand);
         rc = correlate_cells_listed(ctx, iq_dev, stream_stride_samples, n_ms, d_cells, (int32_t)n_cells, GYP_NON_COHERENT, d_out, nullptr,
                                     d_order, d_n_active);

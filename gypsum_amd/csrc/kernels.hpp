@@ -31,7 +31,7 @@ constexpr int kLockRefresh = 1024;  // exact two-pass recomputation of the slidi
 constexpr int kTablesBytes = 1024 * 8;  // tw1024 (tw2048 stays in global memory / L1)
 constexpr int kRedBytes = 1536;
 // gyp_cell_desc::reserved of a cell the acquisition search already holds the record of (same satellite and Doppler bin in
-// the previous level): the correlation kernels leave its output slot alone, acq_reuse_kernel fills it.
+// the previous level, gyp_params::acq_reuse_level_records): the correlation kernels leave its slot alone, acq_reuse_kernel fills it.
 constexpr int kCellSkip = 0x5eed;
 // K = samples per chip.  A workgroup has W wavefronts, W = the largest divisor of K that is <= 8 (corr_core.hpp); K > 8 is
 // processed in R = K / W rounds of W polyphase branches (branch r = rho*W + wavefront).
@@ -2479,16 +2479,19 @@ struct AcqSearchState {
     int32_t best_doppler, best_index;
     double best_strength;
     int32_t bins_lo, bins_step, n_bins, pad;
-    int32_t prev_lo, prev_step, prev_n, pad1;   // the previous level's bins (their records are kept: acquisition.py:203's cache)
+    int32_t prev_lo, prev_step, prev_n, pad1;   // the previous level's bins (gyp_params::acq_reuse_level_records)
     // cross-level near-ties (see acq_exact_*): a level winner whose strength is within kStrengthBand of the incumbent's
     int32_t pending, cand_doppler, best_is_exact, pad2;
 };
 
 // Fill the descriptors of the current level: range(int(c-s), int(c+s), int(s/10)), padded to kMaxBins.
-// A bin the previous level already evaluated (every other bin of levels 2 and 3 with the reference's spreads: the grid is
-// refined by exactly 2) is not correlated again -- the reference returns it from its cache (acquisition.py:200-219), here
-// `reuse` says which of the previous level's records acq_reuse_kernel copies into the slot.
-__global__ void acq_plan_kernel(AcqSearchState* states, int n_states, gyp_cell_desc* cells, int32_t* reuse, double bins_per_spread) {
+// With gyp_params::acq_reuse_level_records a bin the previous level already evaluated (every other bin of levels 2, 3, 8
+// and 10 with the reference's spreads) is not correlated again: `reuse` says which of the previous level's records
+// acq_reuse_kernel copies into the slot.  The reference keeps a cache for exactly this (acquisition.py:200-219) but has its
+// lookup switched off and recomputes -- the default here too; the records are pure functions of (data, satellite, bin), so
+// the reuse changes nothing but the time.
+__global__ void acq_plan_kernel(AcqSearchState* states, int n_states, gyp_cell_desc* cells, int32_t* reuse, double bins_per_spread,
+                                int reuse_records) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_states) return;
     AcqSearchState s = states[i];
@@ -2504,7 +2507,7 @@ __global__ void acq_plan_kernel(AcqSearchState* states, int n_states, gyp_cell_d
         d.tap_index = -1;
         d.reserved = 0;
         int from = -1;
-        if (b < nb && s.level > 0 && s.bins_step > 0) {
+        if (reuse_records && b < nb && s.level > 0 && s.bins_step > 0) {
             const int off = lo + b * step - s.bins_lo;
             if (off >= 0 && off % s.bins_step == 0 && off / s.bins_step < s.n_bins) from = off / s.bins_step;
         }

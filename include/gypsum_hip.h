@@ -87,6 +87,12 @@ typedef struct gyp_params {
     /* this library's speculative tracker: a millisecond advances on its window maximum if peak^2 >= kappa * (energy of the
      * millisecond's samples); results do not depend on it (every such millisecond is verified), only speed does */
     double spec_confidence_kappa;      /* 20 */
+    /* acquisition.py:200-219: the reference keeps a cache of integrated profiles keyed by (data, Doppler, PRN) but has its
+     * lookup switched off (`if False and key in ...`), so it correlates a bin again when a finer level lands on it (every
+     * other bin of levels 2, 3, 8 and 10 with its spreads).  0 (default): do as the reference does.  1: reuse the previous
+     * level's record of such a bin -- the records are pure functions of (data, satellite, bin), results are bit-identical,
+     * about a fifth of the cells of a search are not evaluated twice. */
+    double acq_reuse_level_records;    /* 0 */
 } gyp_params;
 void gyp_params_default(gyp_params* out);
 /* Takes effect for calls made afterwards (banks included).  GYP_E_BAD_ARG for values the kernels cannot represent

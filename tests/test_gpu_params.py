@@ -223,3 +223,29 @@ def test_code_phase_beyond_int32(engine_factory):
     assert float(rec[0, 0]["discriminator"]) == pytest.approx(r.discriminator, rel=1e-5)
     assert abs(int(rec[0, 0]["code_phase"])) < n and np.sign(int(rec[0, 0]["code_phase"])) in (0, np.sign(r.code_phase_after))
     assert np.all(rec[0]["status"] == 0) and np.all(np.abs(rec[0]["code_phase"]) < 2 ** 31)
+
+
+@pytest.mark.parametrize("fs", [2_046_000, 8_184_000])
+def test_reusing_level_records_changes_nothing_but_the_time(engine_factory, fs):
+    """gyp_params::acq_reuse_level_records: a bin the previous level already evaluated is not correlated again (the reference
+    has a cache for this, acquisition.py:200-219, with its lookup switched off).  The acquisition results must be
+    identical either way -- all 32 satellites of a scene, noise-only ones included."""
+    n = fs // 1000
+    eng = engine_factory(fs, n)
+    scene = synth.random_scene(fs, 10, 6, 31337, with_nav_bits=False, max_code_phase=(2046 if n > 2046 else None))
+    iq = synth.render(scene)
+    ids = list(range(1, 33))
+    assert eng.get_params()["acq_reuse_level_records"] == 0.0
+    a = eng.acquire(iq, 1, 10, ids)
+    eng.set_params(acq_reuse_level_records=1.0)
+    try:
+        b = eng.acquire(iq, 1, 10, ids)
+    finally:
+        eng.set_params(acq_reuse_level_records=0.0)
+    for k in ("sat_id", "doppler_hz", "code_phase", "carrier_phase"):
+        assert np.array_equal(a[k], b[k]), k
+    # strength: to the last bit or two (the float64 profiles behind the rare cross-level near-ties are summed with atomics,
+    # whose order differs between any two runs, reuse or not)
+    np.testing.assert_allclose(a["strength"], b["strength"], rtol=1e-14, atol=0.0)
+    with pytest.raises(_lib.GypsumHipError):
+        eng.set_params(acq_reuse_level_records=0.5)
