@@ -787,9 +787,7 @@ static int acquire_search(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, 
     const void* profiles_before = ctx->scratch[7];
     if ((rc = ensure_scratch(ctx, 7, profile_bytes))) return rc;
     double* d_profiles = (double*)ctx->scratch[7];
-    // float64 profile rows of the (rare) cross-level near-ties: cleared when the buffer is (re)allocated, and again by
-    // acq_exact_decide_kernel for the rows it consumed -- not 54 MB of memset per level
-    if (ctx->scratch[7] != profiles_before) HIP_TRY(ctx, hipMemsetAsync(d_profiles, 0, ctx->scratch_cap[7], ctx->stream));
+    (void)profiles_before;   // float64 profile rows of the (rare) cross-level near-ties: written whole by acq_exact_profile_kernel
     double* d_refined = (double*)ctx->scratch[3];
     AcqSearchState* d_states = (AcqSearchState*)ctx->scratch[4];
     gyp_cell_desc* d_cells = (gyp_cell_desc*)ctx->scratch[1];
@@ -830,7 +828,7 @@ static int acquire_search(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, 
         ep.states = d_states; ep.ones = ctx->d_ones; ep.inv_fs = rp.inv_fs; ep.profiles = d_profiles;
         ep.pend = d_pend; ep.n_pend = d_n_pend;
         // (pending pairs are rare -- about one acquisition in a hundred: a short z grid whose blocks walk the states)
-        hipLaunchKernelGGL(acq_exact_profile_kernel, dim3((unsigned)(ctx->k * n_ms), 2, (unsigned)std::min(n_states, 4)), dim3(1024), 0, ctx->stream, ep);
+        hipLaunchKernelGGL(acq_exact_profile_kernel, dim3((unsigned)ctx->k, 2, (unsigned)std::min(n_states, 32)), dim3(1024), 0, ctx->stream, ep);
         hipLaunchKernelGGL(acq_exact_decide_kernel, dim3((unsigned)std::min(n_states, 32)), dim3(256), 0, ctx->stream, ep);
     }
     if (single_level) {

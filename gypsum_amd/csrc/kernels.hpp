@@ -2698,7 +2698,7 @@ __global__ void acq_reduce_kernel(AcqSearchState* states, int n_states, const gy
 // profile resolves (about 1 % of visible-satellite acquisitions flipped by 1 Hz).  For those pairs the whole
 // non-coherent profile is recomputed in float64 straight from the definition (polyphase form, no FFT):
 //     profile[K*q + r] = sum_ms | sum_m chip[m] * y_r[(m + q) mod 1023] |,   y_r[m] = sum_{j<K} xw[(K*m + r + j) mod N]
-// one workgroup per (state, candidate, ms, branch); magnitudes accumulate with float64 atomics.
+// one workgroup per (state, candidate, branch), the milliseconds in order inside it.
 struct ExactParams {
     const cf* iq;
     int64_t stream_stride;
@@ -2711,8 +2711,10 @@ struct ExactParams {
     const int32_t* n_pend;
 };
 
-// grid: (K * n_ms, 2, min(n_states, 32)); block 1024
 __global__ __launch_bounds__(1024) void acq_exact_profile_kernel(ExactParams p) {
+    // grid (K, 2, z): one block per (polyphase branch, candidate / incumbent), the milliseconds walked INSIDE the block so
+    // that each lag's magnitudes are summed in millisecond order -- the order the reference integrates in (utils.py:98-108)
+    // -- and plainly stored: no atomics, the same bits on every run
     __shared__ double2 y[1024];
     __shared__ uint16_t ones[512];
     __shared__ double tot_re[16], tot_im[16];
@@ -2722,46 +2724,50 @@ __global__ __launch_bounds__(1024) void acq_exact_profile_kernel(ExactParams p) 
     const int state = p.pend[pi];
     const AcqSearchState st = p.states[state];
     if (!st.pending || (which == 1 && st.best_is_exact)) continue;           // uniform across the workgroup
-    const int K = p.k, N = p.n_per_ms, r = blockIdx.x % K, ms = blockIdx.x / K;
+    const int K = p.k, N = p.n_per_ms, r = blockIdx.x;
     const double f = (double)(which == 0 ? st.cand_doppler : st.best_doppler);
-    const cf* block = p.iq + (int64_t)st.stream * p.stream_stride + (int64_t)ms * N;
     const int m = threadIdx.x;
     if (m < 512) ones[m] = p.ones[(st.sat_id - 1) * 512 + m];
-    double re = 0.0, im = 0.0;
-    if (m < kChips) {
-        for (int j = 0; j < K; ++j) {
-            int nn = K * m + r + j;
-            nn = nn >= N ? nn - N : nn;
-            const double u = f * (((double)((int64_t)ms * N) + (double)nn) * p.inv_fs);   // utils.py:92-96
-            double sn, cs;
-            sincospi(2.0 * (u - rint(u)), &sn, &cs);                                      // exp(-2*pi*i*u) = (cs, -sn)
-            const cf x = block[nn];
-            re += (double)x.x * cs + (double)x.y * sn;
-            im += (double)x.y * cs - (double)x.x * sn;
+    double total = 0.0;
+    for (int ms = 0; ms < p.n_ms; ++ms) {
+        const cf* block = p.iq + (int64_t)st.stream * p.stream_stride + (int64_t)ms * N;
+        double re = 0.0, im = 0.0;
+        if (m < kChips) {
+            for (int j = 0; j < K; ++j) {
+                int nn = K * m + r + j;
+                nn = nn >= N ? nn - N : nn;
+                const double u = f * (((double)((int64_t)ms * N) + (double)nn) * p.inv_fs);   // utils.py:92-96
+                double sn, cs;
+                sincospi(2.0 * (u - rint(u)), &sn, &cs);                                      // exp(-2*pi*i*u) = (cs, -sn)
+                const cf x = block[nn];
+                re += (double)x.x * cs + (double)x.y * sn;
+                im += (double)x.y * cs - (double)x.x * sn;
+            }
+            y[m] = make_double2(re, im);
         }
-        y[m] = make_double2(re, im);
-    }
-    // T = sum_m y[m]; with the code in {-1, +1}: sum_m chip[m]*y[m+q] = 2 * sum_{ones} y[m+q] - T  (512 terms, not 1023)
-    const double w_re = wave_sum(re), w_im = wave_sum(im);
-    if ((m & 63) == 0) { tot_re[m >> 6] = w_re; tot_im[m >> 6] = w_im; }
-    __syncthreads();
-    if (m < kChips) {
-        double t_re = 0.0, t_im = 0.0;
+        // T = sum_m y[m]; with the code in {-1, +1}: sum_m chip[m]*y[m+q] = 2 * sum_{ones} y[m+q] - T  (512 terms, not 1023)
+        const double w_re = wave_sum(re), w_im = wave_sum(im);
+        if ((m & 63) == 0) { tot_re[m >> 6] = w_re; tot_im[m >> 6] = w_im; }
+        __syncthreads();
+        if (m < kChips) {
+            double t_re = 0.0, t_im = 0.0;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) { t_re += tot_re[w]; t_im += tot_im[w]; }
-        double s_re = 0.0, s_im = 0.0;
+            for (int w = 0; w < 16; ++w) { t_re += tot_re[w]; t_im += tot_im[w]; }
+            double s_re = 0.0, s_im = 0.0;
 #pragma unroll 8
-        for (int i = 0; i < 512; ++i) {
-            int idx = (int)ones[i] + m;          // (position + q) mod 1023 with q = m
-            idx = idx >= kChips ? idx - kChips : idx;
-            const double2 v = y[idx];
-            s_re += v.x;
-            s_im += v.y;
+            for (int i = 0; i < 512; ++i) {
+                int idx = (int)ones[i] + m;          // (position + q) mod 1023 with q = m
+                idx = idx >= kChips ? idx - kChips : idx;
+                const double2 v = y[idx];
+                s_re += v.x;
+                s_im += v.y;
+            }
+            const double c_re = 2.0 * s_re - t_re, c_im = 2.0 * s_im - t_im;
+            total += sqrt(c_re * c_re + c_im * c_im);
         }
-        const double c_re = 2.0 * s_re - t_re, c_im = 2.0 * s_im - t_im;
-        atomicAdd(p.profiles + ((int64_t)state * 2 + which) * N + K * m + r, sqrt(c_re * c_re + c_im * c_im));
+        __syncthreads();   // the shared row is rebuilt for the next millisecond
     }
-    __syncthreads();   // the shared row is rebuilt for the next pending state
+    if (m < kChips) p.profiles[((int64_t)state * 2 + which) * N + K * m + r] = total;
     }
 }
 
@@ -2817,10 +2823,6 @@ __global__ __launch_bounds__(256) void acq_exact_decide_kernel(ExactParams p) {
         st.pending = 0;
         p.states[state] = st;
     }
-    // the rows go back to zero for the next pending pair (acq_exact_profile_kernel accumulates with atomics): the host
-    // clears the scratch once, not per level (each thread re-visits exactly the elements it read)
-    double* rows = p.profiles + (int64_t)state * 2 * N;
-    for (int i = threadIdx.x; i < 2 * N; i += 256) rows[i] = 0.0;
     __syncthreads();
     }
 }

@@ -229,7 +229,7 @@ def test_code_phase_beyond_int32(engine_factory):
 def test_reusing_level_records_changes_nothing_but_the_time(engine_factory, fs):
     """gyp_params::acq_reuse_level_records: a bin the previous level already evaluated is not correlated again (the reference
     has a cache for this, acquisition.py:200-219, with its lookup switched off).  The acquisition results must be
-    identical either way -- all 32 satellites of a scene, noise-only ones included."""
+    bit-identical either way -- all 32 satellites of a scene, noise-only ones included."""
     n = fs // 1000
     eng = engine_factory(fs, n)
     scene = synth.random_scene(fs, 10, 6, 31337, with_nav_bits=False, max_code_phase=(2046 if n > 2046 else None))
@@ -242,10 +242,7 @@ def test_reusing_level_records_changes_nothing_but_the_time(engine_factory, fs):
         b = eng.acquire(iq, 1, 10, ids)
     finally:
         eng.set_params(acq_reuse_level_records=0.0)
-    for k in ("sat_id", "doppler_hz", "code_phase", "carrier_phase"):
-        assert np.array_equal(a[k], b[k]), k
-    # strength: to the last bit or two (the float64 profiles behind the rare cross-level near-ties are summed with atomics,
-    # whose order differs between any two runs, reuse or not)
-    np.testing.assert_allclose(a["strength"], b["strength"], rtol=1e-14, atol=0.0)
+    assert a.tobytes() == b.tobytes()          # bit for bit, strength included
+    assert eng.acquire(iq, 1, 10, ids).tobytes() == a.tobytes()   # and the same bits on every run (no atomics on the path)
     with pytest.raises(_lib.GypsumHipError):
         eng.set_params(acq_reuse_level_records=0.5)
