@@ -828,7 +828,7 @@ static int acquire_search(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, 
         ep.states = d_states; ep.ones = ctx->d_ones; ep.inv_fs = rp.inv_fs; ep.profiles = d_profiles;
         ep.pend = d_pend; ep.n_pend = d_n_pend;
         // (pending pairs are rare -- about one acquisition in a hundred: a short z grid whose blocks walk the states)
-        hipLaunchKernelGGL(acq_exact_profile_kernel, dim3((unsigned)ctx->k, 2, (unsigned)std::min(n_states, 32)), dim3(1024), 0, ctx->stream, ep);
+        hipLaunchKernelGGL(acq_exact_profile_kernel, dim3((unsigned)(ctx->k * kExactSplit), 2, (unsigned)std::min(n_states, 32)), dim3(1024), 0, ctx->stream, ep);
         hipLaunchKernelGGL(acq_exact_decide_kernel, dim3((unsigned)std::min(n_states, 32)), dim3(256), 0, ctx->stream, ep);
     }
     if (single_level) {

@@ -2711,10 +2711,13 @@ struct ExactParams {
     const int32_t* n_pend;
 };
 
+constexpr int kExactSplit = 4;   // blocks per polyphase branch: each forms a quarter of the branch's 1023 lags
 __global__ __launch_bounds__(1024) void acq_exact_profile_kernel(ExactParams p) {
-    // grid (K, 2, z): one block per (polyphase branch, candidate / incumbent), the milliseconds walked INSIDE the block so
-    // that each lag's magnitudes are summed in millisecond order -- the order the reference integrates in (utils.py:98-108)
-    // -- and plainly stored: no atomics, the same bits on every run
+    // grid (K * kExactSplit, 2, z): one block per (polyphase branch, quarter of its lags, candidate / incumbent), the
+    // milliseconds walked INSIDE the block so that each lag's magnitudes are summed in millisecond order -- the order the
+    // reference integrates in (utils.py:98-108) -- and plainly stored: no atomics, the same bits on every run.  Every
+    // block forms the whole decimated row y (cheap); the 512-term sum of a lag is split over four neighbouring threads
+    // (the LDS traffic of those sums is what the pass costs) and combined in a fixed order.
     __shared__ double2 y[1024];
     __shared__ uint16_t ones[512];
     __shared__ double tot_re[16], tot_im[16];
@@ -2724,9 +2727,10 @@ __global__ __launch_bounds__(1024) void acq_exact_profile_kernel(ExactParams p) 
     const int state = p.pend[pi];
     const AcqSearchState st = p.states[state];
     if (!st.pending || (which == 1 && st.best_is_exact)) continue;           // uniform across the workgroup
-    const int K = p.k, N = p.n_per_ms, r = blockIdx.x;
+    const int K = p.k, N = p.n_per_ms, r = blockIdx.x / kExactSplit, sub = blockIdx.x % kExactSplit;
     const double f = (double)(which == 0 ? st.cand_doppler : st.best_doppler);
     const int m = threadIdx.x;
+    const int q = sub * 256 + (m >> 2), part = m & 3;        // this thread's lag and its quarter of the ones
     if (m < 512) ones[m] = p.ones[(st.sat_id - 1) * 512 + m];
     double total = 0.0;
     for (int ms = 0; ms < p.n_ms; ++ms) {
@@ -2749,25 +2753,28 @@ __global__ __launch_bounds__(1024) void acq_exact_profile_kernel(ExactParams p) 
         const double w_re = wave_sum(re), w_im = wave_sum(im);
         if ((m & 63) == 0) { tot_re[m >> 6] = w_re; tot_im[m >> 6] = w_im; }
         __syncthreads();
-        if (m < kChips) {
-            double t_re = 0.0, t_im = 0.0;
+        double t_re = 0.0, t_im = 0.0;
 #pragma unroll
-            for (int w = 0; w < 16; ++w) { t_re += tot_re[w]; t_im += tot_im[w]; }
-            double s_re = 0.0, s_im = 0.0;
+        for (int w = 0; w < 16; ++w) { t_re += tot_re[w]; t_im += tot_im[w]; }
+        double s_re = 0.0, s_im = 0.0;
+        if (q < kChips) {
 #pragma unroll 8
-            for (int i = 0; i < 512; ++i) {
-                int idx = (int)ones[i] + m;          // (position + q) mod 1023 with q = m
+            for (int i = 128 * part; i < 128 * part + 128; ++i) {
+                int idx = (int)ones[i] + q;          // (position + q) mod 1023
                 idx = idx >= kChips ? idx - kChips : idx;
                 const double2 v = y[idx];
                 s_re += v.x;
                 s_im += v.y;
             }
-            const double c_re = 2.0 * s_re - t_re, c_im = 2.0 * s_im - t_im;
-            total += sqrt(c_re * c_re + c_im * c_im);
         }
+        // the four quarters of a lag sit in four neighbouring lanes: (part 0 + part 1) + (part 2 + part 3)
+        s_re += dpp_d<kDppXor1>(s_re); s_im += dpp_d<kDppXor1>(s_im);
+        s_re += dpp_d<kDppXor2>(s_re); s_im += dpp_d<kDppXor2>(s_im);
+        const double c_re = 2.0 * s_re - t_re, c_im = 2.0 * s_im - t_im;
+        total += sqrt(c_re * c_re + c_im * c_im);
         __syncthreads();   // the shared row is rebuilt for the next millisecond
     }
-    if (m < kChips) p.profiles[((int64_t)state * 2 + which) * N + K * m + r] = total;
+    if (part == 0 && q < kChips) p.profiles[((int64_t)state * 2 + which) * N + K * q + r] = total;
     }
 }
 
