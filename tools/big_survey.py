@@ -1,6 +1,6 @@
 """Not a test: the closed-loop survey of tests/test_gpu_track_survey.py at a larger scale, to put a number on how often
 int(self.phase) comes out one sample different from the float64 oracle for a millisecond.
-    python tools/big_survey.py <n_scenes> [GYP_NO_SPEC|-] [fs]"""
+    python tools/big_survey.py <n_scenes> [GYP_NO_SPEC|-] [fs] [first_seed]"""
 import os
 import sys
 from pathlib import Path
@@ -16,9 +16,10 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     env = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "-" else None
     fs = int(sys.argv[3]) if len(sys.argv) > 3 else ts.FS
+    seed0 = int(sys.argv[4]) if len(sys.argv) > 4 else 500000
     if env:
         os.environ[env] = "1"
     eng = GypsumEngine(0)
     eng.set_stream_format(fs, fs // 1000)
-    t = ts._survey(eng, list(range(500000, 500000 + n)), 1009, 12, (env or "speculative") + f" {fs / 1e6:.3f} Msps", fs, fs // 1000)
+    t = ts._survey(eng, list(range(seed0, seed0 + n)), 1009, 12, (env or "speculative") + f" {fs / 1e6:.3f} Msps", fs, fs // 1000)
     print({k: v for k, v in t.items() if k != "first"})
