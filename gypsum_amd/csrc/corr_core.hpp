@@ -730,6 +730,27 @@ __device__ __forceinline__ double wave_sum_last(double v) {   // valid in lane 6
     v += dpp_d_masked(v, 1);
     return v;
 }
+// wave_sum_last of four floats and one double at once (each value goes through exactly the steps of its own
+// wave_sum_last, so the results are the same bits): written step by step over all five so that the five dependent DPP
+// chains interleave instead of running one after the other -- the latency-bound tracking loop has issue slots to spare,
+// not cycles.  Valid in lane 63 only.
+__device__ __forceinline__ void wave_sum_last_4f1d(float& a, float& b, float& c, float& d, double& e) {
+#define GYP_STEP(CTRL) do { a += dpp_f<CTRL>(a); b += dpp_f<CTRL>(b); c += dpp_f<CTRL>(c); d += dpp_f<CTRL>(d); e += dpp_d<CTRL>(e); } while (0)
+    GYP_STEP(kDppXor1);
+    GYP_STEP(kDppXor2);
+    GYP_STEP(kDppHalfMirror);
+    GYP_STEP(kDppMirror);
+#undef GYP_STEP
+#define GYP_BCAST(CTRL, MASK, WHICH) do { \
+        a += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(a), CTRL, MASK, 0xF, false)); \
+        b += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(b), CTRL, MASK, 0xF, false)); \
+        c += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(c), CTRL, MASK, 0xF, false)); \
+        d += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(d), CTRL, MASK, 0xF, false)); \
+        e += dpp_d_masked(e, WHICH); } while (0)
+    GYP_BCAST(0x142, 0xA, 0);
+    GYP_BCAST(0x143, 0xC, 1);
+#undef GYP_BCAST
+}
 // Best of 16 values replicated in every 16-lane row (lane & 15 indexes the value): result uniform across the wavefront.
 __device__ __forceinline__ Best row16_best(Best b) {
     b = best_step<kDppXor1>(b);

@@ -1023,16 +1023,8 @@ __device__ __forceinline__ void sum_partials64(const double* part, double* fin, 
         if (lane == 0) fin[v] = a;
     }
 }
-// The speculative kernel's form (K == 8, 512 threads): all eight wavefronts take part -- wavefront w sums half
-// (w >> 2) of value (w & 3), four partials per lane requested together, and leaves the result in fin[2*(w & 3) + (w >> 2)].
-__device__ __forceinline__ void sum_partials64_spec(const double* part, double* fin, int tid) {
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int v = wave & 3, half = wave >> 2;
-    const double* src = part + v * 512 + 256 * half + lane;
-    const double a0 = src[0], a1 = src[64], a2 = src[128], a3 = src[192];
-    const double a = wave_sum_last((a0 + a1) + (a2 + a3));
-    if (lane == 63) fin[2 * v + half] = a;
-}
+// (The speculative kernel sums its partials at the end of spec_window: wavefront w sums half (w >> 2) of value (w & 3), four
+// partials per lane requested together, and leaves the result in fin[2*(w & 3) + (w >> 2)].)
 // tracker.py:297: ((E.re^2 + E.im^2) - (L.re^2 + L.im^2)) / 2 from the prompt value and the boundary sums.
 __device__ __forceinline__ double dll_discriminator(double p_re, double p_im, const double* d) {
     const double er = p_re - d[0], ei = p_im - d[1], lr = p_re + d[2], li = p_im + d[3];
@@ -1979,6 +1971,8 @@ struct WinCache {
 };
 template <int K>
 __device__ __forceinline__ void spec_window(const Smem& sm, const SpecLds& sl, int centre, int sN, int tid, WinCache& wc) {
+    // (ends with this wavefront's share of the float64 boundary-sum partials: on the wavefronts that also form a prompt quarter the five
+    // reductions -- window lag re/im, prompt re/im, one float64 boundary sum -- run interleaved, see wave_sum_last_4f1d)
     static_assert(kSpecRate<K>, "one window lag per wavefront of the 512-thread workgroup");
     constexpr int N = K * kChips;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -2009,9 +2003,26 @@ __device__ __forceinline__ void spec_window(const Smem& sm, const SpecLds& sl, i
         for (int k = 0; k < 16; ++k) { ar = fmaf(wc.c[k], y[k].x, ar); ai = fmaf(wc.c[k], y[k].y, ai); }
         ar = fmaf(wc.ch, hv.x, ar); ai = fmaf(wc.ch, hv.y, ai);
     }
-    ar = wave_sum_last(ar); ai = wave_sum_last(ai);
-    if (lane == 63) sl.win[wave] = make_float2(ar, ai);
-    if (wave >= 2 && wave < 6) {   // a quarter of the prompt lag each: chips j = lane + 64*(4*pq + k); quarter 0 adds the halo terms
+    // this wavefront's float64 partials: requested now, consumed by the reduction below
+    const int pv = wave & 3, phalf = wave >> 2;
+    const double* psrc = sl.part + pv * 512 + 256 * phalf + lane;
+    const double pa0 = psrc[0], pa1 = psrc[64], pa2 = psrc[128], pa3 = psrc[192];
+    double pacc = (pa0 + pa1) + (pa2 + pa3);
+    if (wave < 2) {
+        ar = wave_sum_last(ar); ai = wave_sum_last(ai);
+        if (lane == 63) sl.win[wave] = make_float2(ar, ai);
+        pacc = wave_sum_last(pacc);
+        if (lane == 63) sl.fin[2 * pv + phalf] = pacc;
+    } else if (wave >= 6) {   // the sample energy, half per wavefront, in the same interleaved reduction
+        const float* src = sl.ein_part + 256 * (wave - 6) + lane;
+        float en = (src[0] + src[64]) + (src[128] + src[192]), zero = 0.f;
+        wave_sum_last_4f1d(ar, ai, en, zero, pacc);
+        if (lane == 63) {
+            sl.win[wave] = make_float2(ar, ai);
+            sl.fin[2 * pv + phalf] = pacc;
+            reinterpret_cast<float*>(sl.fin + 8)[wave - 6] = en;
+        }
+    } else {   // a quarter of the prompt lag each: chips j = lane + 64*(4*pq + k); quarter 0 adds the halo terms
         const int pq = wave - 2;     // (wavefronts 0 and 1 prepare the loop updates meanwhile, 6 and 7 sum the sample energy)
         const int ss = __builtin_amdgcn_readfirstlane(sN);
         const int rs = ss % K, qs = ss / K;
@@ -2031,8 +2042,12 @@ __device__ __forceinline__ void spec_window(const Smem& sm, const SpecLds& sl, i
         }
         const cf hv = sm.halo[hrow + rs];
         pr = fmaf(wc.ph, hv.x, pr); pi = fmaf(wc.ph, hv.y, pi);
-        pr = wave_sum_last(pr); pi = wave_sum_last(pi);
-        if (lane == 63) sl.win[2 * kSpecHalf + pq] = make_float2(pr, pi);
+        wave_sum_last_4f1d(ar, ai, pr, pi, pacc);
+        if (lane == 63) {
+            sl.win[wave] = make_float2(ar, ai);
+            sl.win[2 * kSpecHalf + pq] = make_float2(pr, pi);
+            sl.fin[2 * pv + phalf] = pacc;
+        }
     }
 }
 
@@ -2255,13 +2270,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
                 if (ms + 1 < p.ms_end) stage_fetch_own<K>(stream + (int64_t)(ms + 1) * N, smp, launder(threadIdx.x));
                 if (prof) t_b = (long long)__builtin_readcyclecounter();
                 const int centre = sm.red->istate[2];
-                spec_window<K>(sm, sl, centre, sN, tid, wcache);
-                sum_partials64_spec(sl.part, sl.fin, tid);
-                if (wave >= 6) {   // the sample energy, half per wavefront
-                    const float* src = sl.ein_part + 256 * (wave - 6) + lane;
-                    const float a = wave_sum_last((src[0] + src[64]) + (src[128] + src[192]));
-                    if (lane == 63) reinterpret_cast<float*>(sl.fin + 8)[wave - 6] = a;
-                }
+                spec_window<K>(sm, sl, centre, sN, tid, wcache);   // (incl. this wavefront's share of the float64 boundary sums)
                 asm volatile("; MARK_WINDOW_END");
                 GYP_STAMP(5);
                 lds_barrier();
