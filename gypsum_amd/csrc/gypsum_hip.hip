@@ -1077,7 +1077,9 @@ static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
     v.iq = p.iq; v.stream_stride = p.stream_stride; v.n_ms = p.n_ms; v.start_time = p.start_time;
     v.states = bank->d_states; v.n_chan = bank->n_chan; v.spec = bank->d_spec; v.rec_out = p.rec_out; v.bad = bank->d_bad;
     v.replica_table = ctx->d_replicas; v.tw_tables = ctx->d_tw; v.inv_fs = p.inv_fs; v.tie_tol = 4e-6f;
-    const int n_sub = p.n_ms >= 256 ? 4 : 1;
+    // the last sub-block's verification trails the tracking (1.9 ms for 2500 ms x 12 channels): more, shorter sub-blocks
+    // for long blocks (each launch re-reads the channel state and the tables: ~20 us)
+    const int n_sub = p.n_ms >= 4096 ? 16 : (p.n_ms >= 256 ? 4 : 1);
     const int sub = (p.n_ms + n_sub - 1) / n_sub;
     int rc;
     for (int b0 = 0; b0 < p.n_ms; b0 += sub) {
