@@ -15,7 +15,12 @@
 //                       and the rolled-PRN argmax of tracker.py:284-313.
 //   track_block_kernel  persistent per-channel loop over many milliseconds with the DLL / Costas / lock-detector
 //                       / circularity-watchdog state on the device (tracker.py:157-203, 246-262, 297-305, 331-389).
-//   acq_* kernels       the level-to-level bookkeeping of acquisition.py:70-152 on the device.
+//                       MODE 0: throughput form.  MODE 2 (K = 8, 2; banks of at most one channel per CU): speculative
+//                       form -- window correlations around the last peak lag on the serial chain, only the lock verdict
+//                       between a peak and the next wipe-off, track_verify_kernel proving every such millisecond's
+//                       arg-max from the full profile in parallel.
+//   acq_* kernels       the level-to-level bookkeeping of acquisition.py:70-152 on the device: plan, work list, record
+//                       reuse (optional), float64 tie-breaks within a level (refine) and across levels (exact).
 #pragma once
 #include "corr_core.hpp"
 #include "../../include/gypsum_hip.h"

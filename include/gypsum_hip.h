@@ -467,7 +467,7 @@ int gyp_ingest_times(const gyp_ingest* ing, int64_t first_ms, int32_t n_ms, doub
  * stamp-to-stamp cycles (state read, sample requests, staging, boundary sums, barrier, window, barrier, decision,
  * transform path if taken, loop update). */
 int gyp_debug_track_profile(gyp_ctx* ctx, int enable, long long* out16);
-/* Debug (speculative block tracker, 8.184 Msps banks of at most one channel per CU): with GYP_SPEC_DEBUG set in the
+/* Debug (speculative block tracker: 8.184 / 2.046 Msps banks of at most one channel per CU): with GYP_SPEC_DEBUG set in the
  * environment the last gyp_track_block(_dev) call leaves, per (channel, ms), 20 floats: |c0|^2 at the 8 window lags
  * (previous peak lag - 4 .. + 3), 8 zeros, the sample-energy estimate, code_phase mod N, the window centre, 0.  bad_out (may be NULL): per
  * channel, 1 if the verify pass sent the channel back through the transform kernel.  Synchronises the stream. */
