@@ -82,7 +82,8 @@ def make_scene(rng, n_streams: int, n_visible: int, fs: int, amplitude: float):
 # collective is the library's own ncclAllGather (gyp_allgather_dev)
 # ---------------------------------------------------------------------------------------------------------------
 class Comm:
-    def __init__(self, eng: GypsumEngine, rank: int, world: int, force: bool) -> None:
+    def __init__(self, eng, rank: int, world: int, force: bool, allow_host_gather: bool = False) -> None:
+        """eng is None in --rendezvous-only runs (the CPU test of the launch path): gloo rendezvous, no RCCL."""
         self.rank, self.world, self.dist, self.eng = rank, world, None, eng
         self.fallback = None          # why the library's own collective is not in use, if it is not
         if world > 1 or force:
@@ -91,6 +92,8 @@ class Comm:
             import torch.distributed as dist
             dist.init_process_group("gloo", rank=rank, world_size=world)
             self.dist = dist
+            if eng is None:
+                return
             # every rank first checks that it can load librccl at all (creating an id is local), and all ranks take the
             # same decision: a rank that cannot join would leave the others waiting inside ncclCommInitRank
             err, my_id = None, None
@@ -109,14 +112,20 @@ class Comm:
                     err = repr(e)
                 dist.all_gather_object(flags, err)
             bad = [f for f in flags if f]
-            if bad:   # measured anyway, and said so in the JSON line: records cross through host memory over gloo
-                self.fallback = f"RCCL communicator not available ({bad[0]}); records gathered through the host over gloo"
+            if bad:
+                # A multi-GPU figure whose records crossed through host memory is not the path north_star describes: fail
+                # loudly (every rank takes this branch together) unless the caller asked for the host gather by name.
+                if not allow_host_gather:
+                    dist.destroy_process_group()
+                    raise SystemExit(f"bench.py: the RCCL communicator did not come up on {len(bad)} of {world} ranks ({bad[0]}); "
+                                     f"refusing to measure a host-gathered figure (pass --allow-host-gather to do that on purpose)")
+                self.fallback = f"RCCL communicator not available ({bad[0]}); records gathered through the host over gloo (--allow-host-gather)"
                 try:
                     eng.comm_destroy()           # a rank whose own communicator did come up
                 except Exception:
                     pass
                 eng.comm_init(0, 1, None)
-        else:
+        elif eng is not None:
             eng.comm_init(0, 1, None)
 
     def allgather(self, send, recv, nbytes: int) -> None:
@@ -369,18 +378,18 @@ def run_cfg3(eng, comm, args, rng) -> dict:
         trk_ms += eng.timer_stop()
     trk_ms /= reps
     acq_ms /= reps
-    # the same scans with gyp_params::acq_reuse_level_records = 1 (bit-identical results, see include/gypsum_hip.h): reported,
-    # not what `value` is measured with -- the reference recomputes a bin a finer level lands on again, and so does the default
-    eng.set_params(acq_reuse_level_records=1.0)
-    acq_reuse_ms = 0.0
+    # the same scans with gyp_params::acq_reuse_level_records = 0 (every bin of every level correlated again, as the reference does
+    # with its cache lookup switched off, acquisition.py:204): bit-identical results, reported beside the default
+    eng.set_params(acq_reuse_level_records=0.0)
+    acq_noreuse_ms = 0.0
     for i in range(reps + 1):
         eng.timer_start()
         eng.acquire_dev(su.iq.ptr.value, A, su.stride, 10, ALL_IDS, acq_recv.ptr.value)
         t = eng.timer_stop()
-        acq_reuse_ms += t if i else 0.0
-    acq_reuse_ms /= reps
+        acq_noreuse_ms += t if i else 0.0
+    acq_noreuse_ms /= reps
     same = bool(np.array_equal(acq_send.download(np.uint8, acq_bytes), acq_recv.download(np.uint8, acq_bytes)))   # bit for bit
-    eng.set_params(acq_reuse_level_records=0.0)
+    eng.set_params(acq_reuse_level_records=1.0)
     sym_ok = None
     state = su.bank.state()
     if su.rec_dev is not None:
@@ -400,7 +409,7 @@ def run_cfg3(eng, comm, args, rng) -> dict:
         "dominant": {"kernel": "track_block_kernel<8>", "ms": trk_ms, "flops": f_trk * B * T, "bytes": (8 * n + 64 * C_) * B * T},
         "extra": {"acquire_ms_per_step": round(acq_ms, 3), "track_ms_per_step": round(trk_ms, 3),
                   "acquire_ms_per_stream_32sat": round(acq_ms / A, 3),
-                  "acquire_ms_per_step_with_level_record_reuse": round(acq_reuse_ms, 3),
+                  "acquire_ms_per_step_without_level_record_reuse": round(acq_noreuse_ms, 3),
                   "level_record_reuse_gives_identical_results": same,
                   "acquisition_seed_hits": f"{su.acq_ok}/{B * C_}", "channels_lost": int(state["lost"].sum()),
                   "symbol_agreement_ok_fraction": sym_ok,
@@ -671,12 +680,56 @@ def measured_traffic(workload: str):
         return None
 
 
+def spawn_ranks(n: int, argv: list) -> int:
+    """Launch n copies of this script, one per GPU of this node, with the environment torch.distributed.run would give them
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT); rank 0 inherits stdout (the one JSON line).  Returns the
+    first non-zero exit code; a rank that dies takes the others down instead of leaving them in a rendezvous."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:            # a free port on the loopback interface (the container hostname may not resolve)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env,
+                                      stdout=result_stdout() if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for q in pending:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+_RESULT_FD = None
+
+
+def result_stdout():
+    """The launcher's original stdout (main() points fd 1 at stderr before anything else runs)."""
+    return _RESULT_FD if _RESULT_FD is not None else None
+
+
 def main() -> None:
     # stdout carries exactly one line, the JSON result of rank 0: RCCL / HIP print banners to the C-level stdout (and
     # flush them at exit, i.e. after anything Python printed), so file descriptor 1 is pointed at stderr for the whole
     # run and the JSON goes to a private duplicate of the original stdout.
     sys.stdout.flush()
     result_fd = os.dup(1)
+    global _RESULT_FD
+    _RESULT_FD = result_fd
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -689,21 +742,40 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-records", action="store_true", help="do not write per-ms tracking records")
     ap.add_argument("--no-extras", action="store_true", help="skip single_stream / h2d_inclusive / other_configs")
+    ap.add_argument("--allow-host-gather", action="store_true",
+                    help="N > 1 only: if the RCCL communicator cannot be created, gather the records through the host over gloo "
+                         "instead of failing (the figure is then flagged collective.fallback)")
+    ap.add_argument("--rendezvous-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` is the whole command: this process becomes the launcher of N ranks (one per GPU)
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus N` (self-spawning) or "
+                         f"`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     force_dist = bool(os.environ.get("GYP_BENCH_FORCE_DIST"))   # the env switch exercises RCCL on a 1-GPU box
+    if args.rendezvous_only:
+        # CPU-runnable proof of the launch path (tests/test_bench_launch.py): spawn -> env -> gloo rendezvous -> max over ranks ->
+        # one JSON line from rank 0.  No engine, no GPU.
+        comm = Comm(None, rank, world, False)
+        comm.barrier()
+        top = comm.max(float(rank))
+        if rank == 0:
+            os.write(result_fd, (json.dumps({"rendezvous_only": True, "n_gpus": world, "max_rank_seen": int(top),
+                                             "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}) + "\n").encode())
+        comm.close()
+        return
     if world > 1 or force_dist:
         # torch (gloo rendezvous only) brings its own copies of the HIP / HSA / RCCL libraries: load them BEFORE
         # libgypsum_hip so that the process holds ONE ROCm stack.  The other order leaves RCCL talking to a second,
-        # uninitialised HSA runtime (ncclCommInitRank: "no ROCm-capable device is detected").
+        # uninitialised HSA runtime (ncclCommInitRank: "no ROCm-capable device is detected").  INTEGRATION.md section 6.
         import torch  # noqa: F401
     eng = GypsumEngine(local_rank)
-    comm = Comm(eng, rank, world, force_dist)
+    comm = Comm(eng, rank, world, force_dist, args.allow_host_gather)
     rng = np.random.default_rng(20260925 + 7919 * rank)
 
     if args.workload == "cfg3":
@@ -769,7 +841,7 @@ def main() -> None:
                               "achieved": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12, 3), "peak": VALU_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 5),
                               "kernel_ms_per_launch": round(dom["ms"], 4)},
-            "collective": {**eng.comm_info(), **({"fallback": comm.fallback} if comm.fallback else {})},
+            "collective": {**eng.comm_info(), "ranks_launched": world, **({"fallback": comm.fallback} if comm.fallback else {})},
             **result["extra"], **extras,
         }
         for k in ("cpu_baseline", "cpu_baseline_all_cores"):

@@ -51,8 +51,14 @@ BITS_STATE = np.dtype([("determined_bit_phase", "<i4"), ("previous_bit_phase_dec
                        ("last_emitted_bits_len", "<i4"), ("last_emitted_bits", "i1", (52,))], align=True)
 GYP_BIT_ZERO, GYP_BIT_ONE, GYP_BIT_UNKNOWN = 0, 1, 2
 GYP_COMM_ID_BYTES = 128
-RECORD_SIZES = {"gyp_bit_event": 24, "gyp_bits_state": 112, "gyp_synth_sat": 32, "gyp_cell_desc": 24, "gyp_cell": 32, "gyp_acq_result": 32, "gyp_chan_in": 32, "gyp_chan_out": 80, "gyp_best_bin": 24, "gyp_params": 120,
-                "gyp_track_rec": 56}
+# sizeof() of every record the header declares, derived from the mirrors above (tests/test_abi_and_host.py compiles the
+# header with gcc and checks sizes and offsets against them)
+RECORD_SIZES = {"gyp_bit_event": BIT_EVENT.itemsize, "gyp_bits_state": BITS_STATE.itemsize, "gyp_synth_sat": SYNTH_SAT.itemsize,
+                "gyp_cell_desc": CELL_DESC.itemsize, "gyp_cell": CELL.itemsize, "gyp_acq_result": ACQ_RESULT.itemsize,
+                "gyp_chan_in": CHAN_IN.itemsize, "gyp_chan_out": CHAN_OUT.itemsize, "gyp_best_bin": BEST_BIN.itemsize,
+                "gyp_params": PARAMS.itemsize, "gyp_track_rec": TRACK_REC.itemsize}
+# include/gypsum_hip.h GYP_VERSION these mirrors were written against: load() refuses any other library
+GYP_VERSION = 200
 
 EXPORTS = (
     "gyp_version gyp_create gyp_destroy gyp_last_error gyp_device_name gyp_set_stream gyp_sync gyp_timer_start "
@@ -86,6 +92,10 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python -m gypsum_amd.build` (hipcc --offload-arch=gfx950). "
             "gypsum_amd has no CPU or PyTorch fallback.")
     lib = C.CDLL(str(LIB_PATH))
+    lib.gyp_version.restype = C.c_int
+    if lib.gyp_version() != GYP_VERSION:
+        raise ImportError(f"{LIB_PATH} reports ABI version {lib.gyp_version()}, this binding is written against {GYP_VERSION}: "
+                          "rebuild it with `python -m gypsum_amd.build --force`")
     vp, i32, i64, u64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
     sig = {
         "gyp_version": (C.c_int, []),

@@ -136,6 +136,8 @@ struct gyp_ctx {
     int comm_rank = 0, comm_world = 1;
     gyp_params params;
     bool no_spec = false;        // GYP_NO_SPEC=1: A/B switch: lightly loaded banks use the throughput kernel too
+    bool spec_debug = false;     // GYP_SPEC_DEBUG=1: per-ms window dump of the speculative tracker (gyp_debug_spec_read)
+    // (the GYP_* environment switches are read ONCE, in gyp_create: no getenv on a hot entry point)
     long long* d_prof = nullptr; // debug: per-phase cycle counters of track_block workgroup 0
     // growable scratch for the host-buffer entry points and the acquisition driver
     static constexpr int kScratchSlots = 10;
@@ -183,7 +185,16 @@ bool rccl_load() {
     // stacks (PyTorch ships its own libamdhip64 / libhsa-runtime64 / librccl): an RCCL from the other stack talks to an
     // HSA runtime nobody initialised (ncclCommInitRank: "no ROCm-capable device is detected").
     Dl_info info;
-    if (dladdr(reinterpret_cast<void*>(&hipStreamSynchronize), &info) && info.dli_fname) {
+    // GYP_RCCL_LIB=<path or soname>: use exactly this library (a deployment with its own RCCL build); nothing else is tried
+    const char* forced = std::getenv("GYP_RCCL_LIB");
+    if (forced && *forced) {
+        h = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) {
+            const char* why = dlerror();
+            g_rccl.err = std::string("librccl not found: GYP_RCCL_LIB=") + forced + ": " + (why ? why : "no loader message");
+            return false;
+        }
+    } else if (dladdr(reinterpret_cast<void*>(&hipStreamSynchronize), &info) && info.dli_fname) {
         std::string dir(info.dli_fname);
         const size_t slash = dir.rfind('/');
         if (slash != std::string::npos) {
@@ -193,7 +204,11 @@ bool rccl_load() {
     }
     for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // else a copy already in the process, if any
     for (const char* n : {"librccl.so.1", "librccl.so"}) if (!h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (!h) { g_rccl.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return false; }
+    if (!h) {
+        const char* why = dlerror();   // (one call: dlerror() clears the message it returns)
+        g_rccl.err = std::string("librccl not found: ") + (why ? why : "no loader message");
+        return false;
+    }
     g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
     g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(h, "ncclAllGather"));
@@ -249,7 +264,7 @@ void gyp_params_default(gyp_params* p) {
     p->lock_error_variance_max = 900.0; p->lock_i_variance_max = 2.0; p->lock_rotation_max_deg = 6.0;
     p->watchdog_period_s = 6.0; p->watchdog_drop_below = 0.2; p->watchdog_nudge_below = 0.93; p->watchdog_nudge_hz = 5.0;
     p->spec_confidence_kappa = 20.0;
-    p->acq_reuse_level_records = 0.0;
+    p->acq_reuse_level_records = 1.0;
 }
 
 int gyp_set_params(gyp_ctx* ctx, const gyp_params* p) {
@@ -298,6 +313,7 @@ int gyp_create(int device_ordinal, gyp_ctx** out) {
     ctx->n_cus = prop.multiProcessorCount;
     ctx->no_pipe = std::getenv("GYP_NO_PIPE") != nullptr;
     ctx->no_spec = std::getenv("GYP_NO_SPEC") != nullptr;
+    ctx->spec_debug = std::getenv("GYP_SPEC_DEBUG") != nullptr;
     gyp_params_default(&ctx->params);
     if (const char* kv = std::getenv("GYP_SPEC_KAPPA")) ctx->params.spec_confidence_kappa = std::atof(kv);
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -1065,7 +1081,7 @@ static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
     HIP_TRY(ctx, hipMemsetAsync(bank->d_bad, 0, (size_t)bank->n_chan * sizeof(int32_t), ctx->stream));
     p.spec_out = bank->d_spec;
     p.spec_kappa = (float)ctx->params.spec_confidence_kappa;
-    if (std::getenv("GYP_SPEC_DEBUG")) {
+    if (ctx->spec_debug) {
         if (bank->dbg_cap < n_rec * 20) {
             if (bank->d_dbg) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(bank->d_dbg)); }
             HIP_TRY(ctx, hipMalloc((void**)&bank->d_dbg, n_rec * 20 * sizeof(float)));

@@ -402,7 +402,8 @@ __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void 
     for (int v = blockIdx.x; v < n_work; v += gridDim.x) {
         const int cell = cells_pick(p, v, n_work);
         const gyp_cell_desc d = p.cells[cell];
-        if (d.sat_id < 1 || d.sat_id > 32 || d.reserved == kCellSkip) continue;  // padding / cached cell (uniform across the workgroup)
+        // padding cell, or (acquisition driver's work list only: gyp_cell_desc::reserved is the caller's otherwise) a cached one
+        if (d.sat_id < 1 || d.sat_id > 32 || (p.order && d.reserved == kCellSkip)) continue;   // uniform across the workgroup
         const cf* rep = replica_of(p.replica_table, d.sat_id - 1);
         const double du = d.doppler_hz * p.inv_fs;
         const CarrierSteps cs = carrier_steps<K>(du);
@@ -504,7 +505,8 @@ __global__ __launch_bounds__(Geom<K>::kThreads, 2) void corr_cells_pipe_kernel(C
     for (int v = blockIdx.x; v < n_work; v += gridDim.x) {
         const int cell = cells_pick(p, v, n_work);
         const gyp_cell_desc d = p.cells[cell];
-        if (d.sat_id < 1 || d.sat_id > 32 || d.reserved == kCellSkip) continue;  // padding / cached cell (uniform across the workgroup)
+        // padding cell, or (acquisition driver's work list only: gyp_cell_desc::reserved is the caller's otherwise) a cached one
+        if (d.sat_id < 1 || d.sat_id > 32 || (p.order && d.reserved == kCellSkip)) continue;   // uniform across the workgroup
         const cf* rep = replica_of(p.replica_table, d.sat_id - 1);
         const double du = d.doppler_hz * p.inv_fs;
         const CarrierSteps cs = carrier_steps<K>(du);

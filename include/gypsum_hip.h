@@ -28,7 +28,9 @@
 extern "C" {
 #endif
 
-#define GYP_VERSION 100 /* 0.1.0 */
+/* 200: gyp_chan_out carries the float64 early/late pair (80 bytes), gyp_track_rec::path_info, gyp_debug_track_profile writes
+ * 16 values, gyp_params grew; a binding written against another value must not load the library (gypsum_amd/_lib.py checks). */
+#define GYP_VERSION 200 /* 0.2.0 */
 
 enum {
     GYP_OK = 0,
@@ -85,14 +87,21 @@ typedef struct gyp_params {
     double watchdog_nudge_below;       /* 0.93 */
     double watchdog_nudge_hz;          /* 5 (the phase nudge is pi/2 as upstream) */
     /* this library's speculative tracker: a millisecond advances on its window maximum if peak^2 >= kappa * (energy of the
-     * millisecond's samples); results do not depend on it (every such millisecond is verified), only speed does */
+     * millisecond's samples).  Speed only in this sense: every such millisecond is verified against its full profile, so
+     * the arg-max, pseudosymbols, lock flags and code phase are the same for every kappa.  The float32 VALUES are not
+     * bit-identical across kappa: a fast-path millisecond feeds the loop filters the window's direct sum at the peak lag,
+     * a transform-path millisecond (and the throughput kernel) the FFT's value -- the two agree to float32 rounding
+     * (~1e-7 relative), and so do peak_re/peak_im/error/doppler_hz/carrier_phase downstream.  Two lags whose |c|^2 the
+     * float32 transform cannot order (within 4e-6 relative) count as agreement with the window's choice. */
     double spec_confidence_kappa;      /* 20 */
     /* acquisition.py:200-219: the reference keeps a cache of integrated profiles keyed by (data, Doppler, PRN) but has its
-     * lookup switched off (`if False and key in ...`), so it correlates a bin again when a finer level lands on it (every
-     * other bin of levels 2, 3, 8 and 10 with its spreads).  0 (default): do as the reference does.  1: reuse the previous
-     * level's record of such a bin -- the records are pure functions of (data, satellite, bin), results are bit-identical,
-     * about a fifth of the cells of a search are not evaluated twice. */
-    double acq_reuse_level_records;    /* 0 */
+     * lookup switched off (`if False and key in ...`, "to rule it out as a confounding factor"), so it correlates a bin
+     * again when a finer level lands on it (every other bin of levels 2, 3, 8 and 10 with its spreads).  The records are
+     * pure functions of (data, satellite, bin): re-evaluating them is redundant work, not part of the result contract.
+     * 1 (default): reuse the previous level's record of such a bin -- bit-identical results (tests/test_gpu_params.py),
+     * about a fifth of the cells of a search are not evaluated twice.  0: correlate every bin of every level again, as the
+     * reference does. */
+    double acq_reuse_level_records;    /* 1 */
 } gyp_params;
 void gyp_params_default(gyp_params* out);
 /* Takes effect for calls made afterwards (banks included).  GYP_E_BAD_ARG for values the kernels cannot represent

@@ -175,3 +175,22 @@ def test_block_scheduler_finds_the_watchdog_millisecond_with_the_providers_clock
             for i in (0, 5990, 6000, 6001, 13020, 47998, 60000):
                 want = next(j for j in range(i, i + 70000) if clock(j) - last >= 6.0)
                 assert first_step_at_least(clock, i, last, 6.0) == want, (fs, last, i)
+
+
+def test_comm_entry_points_report_a_missing_librccl_instead_of_crashing(tmp_path):
+    """with librccl nowhere to be found gyp_comm_unique_id must return GYP_E_COMM with a message (it used to
+    add a NULL dlerror() to a std::string).  Run in a child that is pointed (GYP_RCCL_LIB) at a library that does not exist."""
+    import os
+    code = (
+        "import ctypes as C, sys\n"
+        f"lib = C.CDLL({str(_lib.LIB_PATH)!r})\n"
+        "lib.gyp_last_error.restype = C.c_char_p\n"
+        "buf = C.create_string_buffer(128)\n"
+        "rc = lib.gyp_comm_unique_id(buf)\n"
+        "msg = lib.gyp_last_error(None)\n"
+        "print(rc, msg.decode())\n")
+    env = dict(os.environ, GYP_RCCL_LIB="librccl_that_does_not_exist.so")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rc, msg = r.stdout.strip().split(" ", 1)
+    assert int(rc) == -8 and msg.startswith("librccl not found"), r.stdout

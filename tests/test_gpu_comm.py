@@ -63,3 +63,39 @@ def test_pinned_upload_and_widen(dtype, fmt):
     assert np.array_equal(got, words.astype(np.float32) * np.float32(0.25))
     eng.host_free(pinned)
     eng.close()
+
+
+@pytest.mark.parametrize("order", ["torch_first", "gypsum_first"])
+def test_rccl_communicator_comes_up_in_either_import_order(order):
+    """A process that also imports PyTorch holds two ROCm stacks (torch ships its own libamdhip64 / libhsa-runtime64 /
+    librccl).  rccl_load() takes the librccl that sits next to the HIP runtime libgypsum_hip is bound to, so the communicator
+    must come up whichever of the two was loaded first."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    repo = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(repo / "tools" / "comm_order_probe.py"), order], cwd=str(repo), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert f"{order} comm ok" in r.stdout and "'uses_rccl': 1" in r.stdout, r.stdout[-2000:]
+
+
+def test_bench_line_through_rccl_on_one_rank():
+    """bench.py with the distributed plumbing forced on (gloo rendezvous of one rank + a real RCCL communicator): the step's
+    all-gather is ncclAllGather issued by the library, and the line says so."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    repo = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, GYP_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, str(repo / "bench.py"), "--steps", "1", "--warmup", "1", "--streams", "16", "--track-ms", "100",
+                        "--no-cpu-baseline", "--no-extras"], cwd=str(repo), capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert line["collective"]["uses_rccl"] == 1 and "fallback" not in line["collective"]
+    assert line["value"] > 0

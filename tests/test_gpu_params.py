@@ -235,13 +235,13 @@ def test_reusing_level_records_changes_nothing_but_the_time(engine_factory, fs):
     scene = synth.random_scene(fs, 10, 6, 31337, with_nav_bits=False, max_code_phase=(2046 if n > 2046 else None))
     iq = synth.render(scene)
     ids = list(range(1, 33))
-    assert eng.get_params()["acq_reuse_level_records"] == 0.0
-    a = eng.acquire(iq, 1, 10, ids)
-    eng.set_params(acq_reuse_level_records=1.0)
+    assert eng.get_params()["acq_reuse_level_records"] == 1.0      # the default since r03: redundant work is not part of the contract
+    b = eng.acquire(iq, 1, 10, ids)
+    eng.set_params(acq_reuse_level_records=0.0)                    # every bin of every level correlated again, as the reference does
     try:
-        b = eng.acquire(iq, 1, 10, ids)
+        a = eng.acquire(iq, 1, 10, ids)
     finally:
-        eng.set_params(acq_reuse_level_records=0.0)
+        eng.set_params(acq_reuse_level_records=1.0)
     assert a.tobytes() == b.tobytes()          # bit for bit, strength included
     assert eng.acquire(iq, 1, 10, ids).tobytes() == a.tobytes()   # and the same bits on every run (no atomics on the path)
     with pytest.raises(_lib.GypsumHipError):
