@@ -137,6 +137,8 @@ struct gyp_ctx {
     gyp_params params;
     bool no_spec = false;        // GYP_NO_SPEC=1: A/B switch: lightly loaded banks use the throughput kernel too
     bool spec_debug = false;     // GYP_SPEC_DEBUG=1: per-ms window dump of the speculative tracker (gyp_debug_spec_read)
+    double dll_prov_bias = 0.0;  // GYP_DLL_PROV_BIAS=x (test hook): added to the speculative kernel's PROVISIONAL discriminator, so
+                                 // that dll_scan_kernel's repair path runs; results must not depend on it
     // (the GYP_* environment switches are read ONCE, in gyp_create: no getenv on a hot entry point)
     long long* d_prof = nullptr; // debug: per-phase cycle counters of track_block workgroup 0
     // growable scratch for the host-buffer entry points and the acquisition driver
@@ -155,6 +157,8 @@ struct gyp_bank {
     // speculative block tracking: state checkpoint, per-(channel, ms) hand-over records, failed-verification flags
     ChanState* d_ckpt = nullptr;
     SpecIn* d_spec = nullptr;
+    double* d_disc = nullptr;    // [n_chan][n_ms] exact discriminators from the verify pass (dll_scan_kernel's input)
+    DllExact* d_dllx = nullptr;  // [n_chan] the exactly re-integrated code loop between sub-blocks
     size_t spec_cap = 0;         // in records
     int32_t* d_bad = nullptr;
     float* d_dbg = nullptr;      // GYP_SPEC_DEBUG: per-ms window dump of the last block
@@ -314,6 +318,7 @@ int gyp_create(int device_ordinal, gyp_ctx** out) {
     ctx->no_pipe = std::getenv("GYP_NO_PIPE") != nullptr;
     ctx->no_spec = std::getenv("GYP_NO_SPEC") != nullptr;
     ctx->spec_debug = std::getenv("GYP_SPEC_DEBUG") != nullptr;
+    if (const char* b = std::getenv("GYP_DLL_PROV_BIAS")) ctx->dll_prov_bias = std::atof(b);
     gyp_params_default(&ctx->params);
     if (const char* kv = std::getenv("GYP_SPEC_KAPPA")) ctx->params.spec_confidence_kappa = std::atof(kv);
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -1011,6 +1016,8 @@ void gyp_bank_destroy(gyp_bank* bank) {
     if (bank->d_states) (void)hipFree(bank->d_states);
     if (bank->d_ckpt) (void)hipFree(bank->d_ckpt);
     if (bank->d_spec) (void)hipFree(bank->d_spec);
+    if (bank->d_disc) (void)hipFree(bank->d_disc);
+    if (bank->d_dllx) (void)hipFree(bank->d_dllx);
     if (bank->d_bad) (void)hipFree(bank->d_bad);
     if (bank->d_dbg) (void)hipFree(bank->d_dbg);
     if (bank->verify_stream) { (void)hipStreamSynchronize(bank->verify_stream); (void)hipStreamDestroy(bank->verify_stream); }
@@ -1062,6 +1069,7 @@ static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
     if (!bank->d_ckpt) {
         HIP_TRY(ctx, hipMalloc((void**)&bank->d_ckpt, (size_t)bank->n_chan * sizeof(ChanState)));
         HIP_TRY(ctx, hipMalloc((void**)&bank->d_bad, (size_t)bank->n_chan * sizeof(int32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&bank->d_dllx, (size_t)bank->n_chan * sizeof(DllExact)));
         HIP_TRY(ctx, hipStreamCreateWithFlags(&bank->verify_stream, hipStreamNonBlocking));
         HIP_TRY(ctx, hipEventCreateWithFlags(&bank->ev_spec, hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&bank->ev_verify, hipEventDisableTiming));
@@ -1071,10 +1079,13 @@ static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(bank->verify_stream));
             HIP_TRY(ctx, hipFree(bank->d_spec));
+            HIP_TRY(ctx, hipFree(bank->d_disc));
             bank->d_spec = nullptr;
+            bank->d_disc = nullptr;
             bank->spec_cap = 0;
         }
         HIP_TRY(ctx, hipMalloc((void**)&bank->d_spec, n_rec * sizeof(SpecIn)));
+        HIP_TRY(ctx, hipMalloc((void**)&bank->d_disc, n_rec * sizeof(double)));
         bank->spec_cap = n_rec;
     }
     HIP_TRY(ctx, hipMemcpyAsync(bank->d_ckpt, bank->d_states, (size_t)bank->n_chan * sizeof(ChanState), hipMemcpyDeviceToDevice, ctx->stream));
@@ -1092,7 +1103,13 @@ static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
     TrackVerifyParams v;
     v.iq = p.iq; v.stream_stride = p.stream_stride; v.n_ms = p.n_ms; v.start_time = p.start_time;
     v.states = bank->d_states; v.n_chan = bank->n_chan; v.spec = bank->d_spec; v.rec_out = p.rec_out; v.bad = bank->d_bad;
-    v.replica_table = ctx->d_replicas; v.tw_tables = ctx->d_tw; v.inv_fs = p.inv_fs; v.tie_tol = 4e-6f;
+    v.disc_out = bank->d_disc;
+    v.replica_table = ctx->d_replicas; v.tw_tables = ctx->d_tw; v.chipf = ctx->d_chipf; v.inv_fs = p.inv_fs; v.tie_tol = 4e-6f;
+    DllScanParams d;
+    d.iq = p.iq; d.stream_stride = p.stream_stride; d.n_ms = p.n_ms; d.start_time = p.start_time;
+    d.states = bank->d_states; d.ckpt = bank->d_ckpt; d.n_chan = bank->n_chan; d.spec = bank->d_spec; d.disc = bank->d_disc;
+    d.rec_out = p.rec_out; d.exact = bank->d_dllx; d.bad = bank->d_bad; d.chipf = ctx->d_chipf;
+    d.inv_fs = p.inv_fs; d.dll_gain = p.lp.dll_gain; d.dll_modulus = p.lp.dll_modulus; d.n_samples = p.lp.n_samples;
     // the last sub-block's verification trails the tracking (1.9 ms for 2500 ms x 12 channels): more, shorter sub-blocks
     // for long blocks (each launch re-reads the channel state and the tables: ~20 us)
     const int n_sub = p.n_ms >= 4096 ? 16 : (p.n_ms >= 256 ? 4 : 1);
@@ -1107,6 +1124,11 @@ static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
         v.ms_begin = p.ms_begin;
         v.ms_end = p.ms_end;
         if ((rc = launch_track_verify(ctx, v, bank->verify_stream))) return rc;
+        // the code loop, re-integrated from the verify pass's float64 discriminators (behind it on the same stream)
+        d.ms_begin = p.ms_begin; d.ms_end = p.ms_end; d.first = b0 == 0 ? 1 : 0; d.final = p.ms_end == p.n_ms ? 1 : 0;
+        if (ctx->k == 2) hipLaunchKernelGGL(dll_scan_kernel<2>, dim3((unsigned)bank->n_chan), dim3(kScanThreads), 0, bank->verify_stream, d);
+        else hipLaunchKernelGGL(dll_scan_kernel<8>, dim3((unsigned)bank->n_chan), dim3(kScanThreads), 0, bank->verify_stream, d);
+        HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipEventRecord(bank->ev_verify, bank->verify_stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, bank->ev_verify, 0));
@@ -1157,6 +1179,7 @@ int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stri
     }
     p.spec_out = nullptr;
     p.spec_kappa = (float)ctx->params.spec_confidence_kappa;
+    p.prov_bias = ctx->dll_prov_bias;
     p.only_if = nullptr;
     p.restore_from = nullptr;
     p.dbg = nullptr;
@@ -1279,6 +1302,18 @@ int gyp_debug_spec_read(gyp_bank* bank, float* out, int32_t n_floats, int32_t* b
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (out && bank->d_dbg) HIP_TRY(ctx, hipMemcpy(out, bank->d_dbg, std::min((size_t)n_floats, bank->dbg_cap) * sizeof(float), hipMemcpyDeviceToHost));
     if (bad_out && bank->d_bad) HIP_TRY(ctx, hipMemcpy(bad_out, bank->d_bad, (size_t)bank->n_chan * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return GYP_OK;
+}
+
+int gyp_debug_dll_read(gyp_bank* bank, int32_t* repairs_out) {
+    if (!bank || !repairs_out) return GYP_E_BAD_ARG;
+    gyp_ctx* ctx = bank->ctx;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<DllExact> x((size_t)bank->n_chan);
+    for (int i = 0; i < bank->n_chan; ++i) repairs_out[i] = 0;
+    if (!bank->d_dllx) return GYP_OK;          // the bank never took the speculative path
+    HIP_TRY(ctx, hipMemcpy(x.data(), bank->d_dllx, x.size() * sizeof(DllExact), hipMemcpyDeviceToHost));
+    for (int i = 0; i < bank->n_chan; ++i) repairs_out[i] = x[i].repairs;
     return GYP_OK;
 }
 

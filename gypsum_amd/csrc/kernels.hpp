@@ -34,7 +34,7 @@ constexpr int kLockWindow = 250;    // config.py:23
 constexpr int kPeakHistory = 1000;  // tracker.py:146 (deque maxlen)
 constexpr int kLockRefresh = 1024;  // exact two-pass recomputation of the sliding sums every this many ms
 constexpr int kTablesBytes = 1024 * 8;  // tw1024 (tw2048 stays in global memory / L1)
-constexpr int kRedBytes = 1536;
+constexpr int kRedBytes = 2048;
 // gyp_cell_desc::reserved of a cell the acquisition search already holds the record of (same satellite and Doppler bin in
 // the previous level, gyp_params::acq_reuse_level_records): the correlation kernels leave its slot alone, acq_reuse_kernel fills it.
 constexpr int kCellSkip = 0x5eed;
@@ -111,8 +111,10 @@ struct LoopConst {
 struct RedScratch {
     WaveCand cand[16];
     float taps[6];      // early re/im, late re/im, probe re/im (the value at one more lag of the caller's choice)
-    double eldelta[4];  // float64 boundary sums c0[s] - c0[s-1] and c0[s+1] - c0[s] (re, im each), see el_delta_partial
-    double elpart[8][4];// the same per wavefront, summed by epl_finish* after its barrier
+    // float64 prompt value and boundary sums of the code loop, per wavefront (ExactOwn / exact_epl_generic), summed by
+    // epl_finish* after its barrier: {P re, im; c0[s] - c0[s-1] re, im; c0[s+1] - c0[s] re, im}
+    double expart[8][6];
+    double2 xc[9];      // constants of those sums for the wipe-off in force, see exact_consts: exp(-2 pi i du i), i < K <= 8; chip stride
     double dstate[4];   // new doppler, new carrier phase
     int istate[4];      // new code phase, lost flag
     CarrierSteps steps; // rotation constants of the next millisecond's wipe-off
@@ -129,7 +131,6 @@ struct RedScratch {
     double t0_next;        // start time of the next millisecond's chunk, fetched by an idle wavefront during the loop updates
     LoopConst kc;
     struct CostasCand { double nf, nphi; cf rot1; cf step; double pscale; } cc[3];   // step: the carrier over 4096 samples (second chip of a thread)
-    double pscale;         // throughput kernels: prompt_scale of the wipe-off in force (see prompt_scale)
     int cand_sel, rec_sel, pad2[2];
 };
 static_assert(sizeof(RedScratch) <= kRedBytes, "reduction scratch too large");
@@ -181,12 +182,12 @@ __device__ __forceinline__ void transform_staged(const Smem& sm, const cf* __res
 }
 
 // One millisecond block, round rho: stage (all wavefronts) -> barrier -> per-wavefront correlation.
-// Halo-free staging only: `wiped(c, w)` sees each chip's K wiped samples, `staged(tid)` runs once the rows are written
-// (the tracking kernels take their early/late boundary sums there); neither is called on the other staging paths.
-template <int K, typename Wiped, typename Staged>
+// Halo-free staging only: `raw(smp, tid)` sees the thread's raw samples between the fetch and the wipe-off (the tracking
+// kernels form the code loop's float64 sums there); it is not called on the other staging paths.
+template <int K, typename Raw>
 __device__ __forceinline__ void correlate_round(const cf* __restrict__ block, int rho, double u0, double du,
                                                 const CarrierSteps& cs, const Smem& sm,
-                                                const cf* __restrict__ rep_table_sat, cf (&c)[16], Wiped&& wiped, Staged&& staged) {
+                                                const cf* __restrict__ rep_table_sat, cf (&c)[16], Raw&& raw) {
     constexpr int W = Geom<K>::W;
     const int tid = launder(threadIdx.x);
     if constexpr (kOwnStaging<K>) {
@@ -196,8 +197,8 @@ __device__ __forceinline__ void correlate_round(const cf* __restrict__ block, in
             for (int r = 0; r < K; ++r) y_all[r] = sm.xch + r * kXchWave;
             OwnSamples<K> smp;
             stage_fetch_own<K>(block, smp, tid);
-            stage_emit_own<K>(smp, u0, du, cs, y_all, sm.halo, tid, wiped);
-            staged(tid);
+            stage_emit_own<K>(smp, u0, du, cs, y_all, sm.halo, tid);
+            raw(smp, tid);
         }
         transform_staged<K, true>(sm, rep_table_sat, c, tid, rho * W, rho == 0);
     } else {
@@ -213,7 +214,7 @@ template <int K>
 __device__ __forceinline__ void correlate_round(const cf* __restrict__ block, int rho, double u0, double du,
                                                 const CarrierSteps& cs, const Smem& sm,
                                                 const cf* __restrict__ rep_table_sat, cf (&c)[16]) {
-    correlate_round<K>(block, rho, u0, du, cs, sm, rep_table_sat, c, [](int, const cf (&)[K]) {}, [](int) {});
+    correlate_round<K>(block, rho, u0, du, cs, sm, rep_table_sat, c, [](const OwnSamples<kOwnStaging<K> ? K : 1>&, int) {});
 }
 
 // Coherent integration of n_blocks millisecond blocks, round rho, with ONE transform (pre-folded inputs).
@@ -932,15 +933,27 @@ __device__ __forceinline__ int mod_n(int v, int n) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// float64 early / late taps.  The reference's DLL (tracker.py:293-301) integrates (|E|^2 - |L|^2)/2 * 0.002 and
-// takes int() of the accumulator, so an error of ~1e-6 in the taps lands int(self.phase) on the other side of an
-// integer once per ~1e6 channel-ms.  E and L are single lags either side of the prompt lag s, and neighbouring lags
-// differ only where the replica changes sign inside the sample window:
+// The code loop's inputs in float64.  The reference's DLL (tracker.py:293-301) integrates
+//     disc = (|E|^2 - |L|^2) / 2,   E = np.correlate(xw, roll(prn, s-1)),  L = np.correlate(xw, roll(prn, s+1))
+// (complex128 single-lag dot products) and takes int() of the accumulator, every millisecond, for ever.  The
+// accumulator dithers across integer boundaries, so ANY error that accumulates shows up as a different
+// int(self.phase) sooner or later: float32 taps (~2e-6 per ms) once per ~1e6 channel-ms (r01), float64 boundary sums
+// beside a float32 prompt value (r02) once per ~2e6.  The only version that follows the reference for good carries the
+// three lags in float64 end to end: raw float32 samples x a float64 carrier, float64 sums.
+//
+// The code loop is a side chain: the prompt PROFILE is roll(c0, -s), so its arg-max value, the Costas loop, the lock
+// detector and the watchdog never see s (only the record's peak_offset = arg-max lag - s does).  What the DLL needs of a
+// millisecond is c0 at the three lags s-1, s, s+1, and neighbouring lags differ only where the replica changes sign
+// inside the sample window:
 //     c0[L+1] - c0[L] = sum_m (chip[m-1] - chip[m]) * xw[(L + K*m) mod N]        (chips as +-1, m mod 1023)
-// -- one sample per chip TRANSITION (~512 of the 1023 chips of a C/A code).  Those two boundary sums are formed in
-// float64 from the raw samples with a float64 carrier; E = P - (c0[s] - c0[s-1]), L = P + (c0[s+1] - c0[s]) with the
-// prompt value P = c0[s].  An error dP in P enters the discriminator only through Re(dP * conj(L - E)), i.e. scaled by
-// the (small) difference of the taps, not by their magnitude.
+// -- one sample per chip TRANSITION.  So:  P = c0[s] over all N samples,  d_e = c0[s] - c0[s-1],  d_l = c0[s+1] - c0[s]
+// over the transition samples,  E = P - d_e,  L = P + d_l.
+//
+// With s = K*q + r, sample i of chip m (n = K*m + i) meets replica chip j = (m - q) mod 1023 if i >= r, chip j-1 if not:
+//     P   = sum_m A_m * ( chip[j] * sum_{i>=r} x_i rho^i  +  chip[j-1] * sum_{i<r} x_i rho^i )
+//     d_l = sum_m A_m * (chip[j-1] - chip[j]) * x_r rho^r
+//     d_e = sum_m A_m * (chip[j-1] - chip[j]) * x_{r-1} rho^{r-1}          (r == 0: (chip[j] - chip[j+1]) * x_{K-1} rho^{K-1})
+// with A_m = exp(-2 pi i (u0 + du K m)) the carrier at the chip's first sample and rho = exp(-2 pi i du).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kMaxTrans = 1024;
 struct CodeTables {
@@ -949,33 +962,12 @@ struct CodeTables {
     const float* chipf;       // [32][2048]: +-1.0f, chipf[i] = chip[i mod 1023]
 };
 
-// Per-thread partial sums over the transitions e = tid, tid + T, ...:
-//   acc[0..1] = c0[s] - c0[s-1] (re, im),  acc[2..3] = c0[s+1] - c0[s].
-// Split in two so that a latency-bound caller can request the samples (el_fetch) long before it consumes them
-// (el_accumulate); a thread handles at most kElMax transitions (1023 <= kElMax * T for every workgroup size used: the
-// smallest is one wavefront, K == 1, which loops instead -- see el_delta_partial).
+// (speculative kernel's provisional code loop: boundary samples gathered through the transition table)
 struct ElSample {
     cf xl, xe;      // raw samples at (s + K*m) mod N and one before
     int nl;         // (s + K*m) mod N, or -1: nothing to do
     float g;        // chip[m-1] - chip[m]: +-2
 };
-template <int K>
-__device__ __forceinline__ ElSample el_fetch(const cf* __restrict__ block, int sN, const uint16_t* trans, int nt, int e) {
-    constexpr int N = K * kChips;
-    ElSample s;
-    s.nl = -1; s.g = 0.f; s.xl = s.xe = make_float2(0.f, 0.f);
-    if (e < nt) {
-        const unsigned t = trans[e];
-        const int m = (int)(t & 0x3ffu);
-        s.g = (t & 0x8000u) ? -2.0f : 2.0f;
-        int nl = sN + K * m;
-        nl = nl >= N ? nl - N : nl;
-        s.nl = nl;
-        s.xl = block[nl];
-        s.xe = block[nl == 0 ? N - 1 : nl - 1];
-    }
-    return s;
-}
 // The same for a thread whose transition is fixed (sample offset K*m, or < 0: none).
 template <int K>
 __device__ __forceinline__ ElSample el_fetch_const(const cf* __restrict__ block, int sN, int off, float g) {
@@ -1004,120 +996,177 @@ __device__ __forceinline__ void el_accumulate(const ElSample& s, double u0, doub
     acc[0] = fma(g, pe.x, acc[0]); acc[1] = fma(g, pe.y, acc[1]);
     acc[2] = fma(g, pl.x, acc[2]); acc[3] = fma(g, pl.y, acc[3]);
 }
-template <int K>
-__device__ __forceinline__ void el_delta_partial(const cf* __restrict__ block, double u0, double du, int sN,
-                                                 const uint16_t* __restrict__ trans, int nt, int tid, double (&acc)[4]) {
-    constexpr int T = Geom<K>::kThreads;
-    acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
-    for (int e = tid; e < nt; e += T) {
-        const ElSample s = el_fetch<K>(block, sN, trans, nt, e);
-        el_accumulate<K>(s, u0, du, acc);
-    }
-}
-// Sum NV values whose per-thread partials sit at part[v*T + tid], in a fixed order (the result does not depend on
-// timing): value v is summed by wavefront (first_wave + v) mod W; fin[v] is valid after the caller's next barrier.
-template <int K, int NV>
-__device__ __forceinline__ void sum_partials64(const double* part, double* fin, int first_wave, int tid) {
-    constexpr int T = Geom<K>::kThreads, W = Geom<K>::W;
-    const int wave = tid >> 6, lane = tid & 63;
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        if ((first_wave + v) % W != wave) continue;   // wave-uniform
-        double a = 0.0;
-#pragma unroll
-        for (int k = 0; k < W; ++k) a += part[v * T + lane + 64 * k];
-        a = wave_sum(a);
-        if (lane == 0) fin[v] = a;
-    }
-}
-// (The speculative kernel sums its partials at the end of spec_window: wavefront w sums half (w >> 2) of value (w & 3), four
-// partials per lane requested together, and leaves the result in fin[2*(w & 3) + (w >> 2)].)
-// tracker.py:297: ((E.re^2 + E.im^2) - (L.re^2 + L.im^2)) / 2 from the prompt value and the boundary sums.
+// tracker.py:297 from float32 prompt value + float64 boundary sums: the speculative kernel's PROVISIONAL discriminator
+// (dll_scan_kernel re-integrates the code loop from the exact sums the verify pass forms).
 __device__ __forceinline__ double dll_discriminator(double p_re, double p_im, const double* d) {
     const double er = p_re - d[0], ei = p_im - d[1], lr = p_re + d[2], li = p_im + d[3];
     return ((er * er + ei * ei) - (lr * lr + li * li)) / 2.0;
 }
-// One wavefront's share of the boundary sums, left in red->elpart[wave] for epl_finish* to add up after its barrier
-// (no barrier of its own).  `job.trans == nullptr`: nothing to do (callers that only want the profile).
-struct ElJob {
-    const cf* block;
-    double u0, du;
-    int sN;
-    const uint16_t* trans;
-    int nt;
-    const float* chipf;   // this satellite's +-1 code, twice over (own-sample form)
-};
+// tracker.py:297, in the reference's association, from the exact sums ex = {P, d_e, d_l} (re, im each); no contraction
+// into FMAs: Python rounds every product.
+__device__ __forceinline__ double dll_discriminator_exact(const double (&ex)[6]) {
+    const double er = ex[0] - ex[2], ei = ex[1] - ex[3], lr = ex[0] + ex[4], li = ex[1] + ex[5];
+    const double e2 = __dadd_rn(__dmul_rn(er, er), __dmul_rn(ei, ei)), l2 = __dadd_rn(__dmul_rn(lr, lr), __dmul_rn(li, li));
+    return __dsub_rn(e2, l2) / 2.0;
+}
+
+// Which staging a rate's exact sums ride on: the halo-free staging with the raw samples in registers (K = 2, 8: the
+// rates of the reference's own recordings that the tuned kernels serve) or a pass of its own over the block (every other rate).
 template <int K>
-__device__ __forceinline__ void el_wave_partials(const ElJob& job, RedScratch* red, int tid) {
-    if (!job.trans) return;
-    double acc[4];
-    el_delta_partial<K>(job.block, job.u0, job.du, job.sN, job.trans, job.nt, tid, acc);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) acc[v] = wave_sum_last(acc[v]);
-    if ((tid & 63) == 63) {
-        double* o = red->elpart[tid >> 6];
-        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+constexpr bool kExactOwn = (K == 2 || K == 8);
+
+// Constants of ExactOwn for the wipe-off in force, by ONE wavefront (all lanes), into RedScratch::xc:
+//   xc[i] = exp(-2 pi i du i), i < K;   xc[K] = exp(-2 pi i du K T): a thread's chip c -> its chip c+1.
+// A workgroup barrier must separate this from the staging that uses them.
+template <int K>
+__device__ __forceinline__ void exact_consts(RedScratch* red, double du, int lane) {
+    if constexpr (kExactOwn<K>) {
+        constexpr int T = OwnSamples<K>::T;
+        const double2 v = carrier64(du * (double)(lane < K ? lane : K * T));
+        if (lane <= K) red->xc[lane] = v;
     }
 }
-// The throughput kernel's form, from the WIPED float32 samples the halo-free staging forms anyway (chips j = tid + c*T,
-// K samples each): sample (s + K*m) of transition m is offset r = s mod K of chip j = (s / K + m) mod 1023, so the
-// thread that owns chip j applies the coefficient chip[j-q-1] - chip[j-q] (0 where the code does not change sign) to its
-// own sample r, and to its sample r-1 for the early side (r == 0: its sample K-1 with the next transition's
-// coefficient).  No gather from memory (two 8-byte loads per transition at a 64-byte stride cost the throughput kernel
-// as much as its transforms) and no second carrier: the ~512 float32 products carry ~1e-8 each, the sums are
-// accumulated in float64 -- the same accuracy class as the float32 prompt value they are combined with.
-template <int K>
-struct ElOwn {
-    int q, r, re;
-    const float* chipf;
-    double acc[4];
-    __device__ __forceinline__ void init(const ElJob& job) {
-        q = __builtin_amdgcn_readfirstlane(job.sN / K); r = __builtin_amdgcn_readfirstlane(job.sN % K);
-        re = r ? r - 1 : K - 1;
-        chipf = job.chipf;
-        acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
-    }
-    __device__ __forceinline__ void chip(int c, const cf (&w)[K], int tid) {
-        const int j = tid + c * OwnSamples<K>::T;
-        cf xl = w[0], xe = w[0];
+
+// One wavefront's share of the three sums -> red->expart[wave]; epl_finish* adds the wavefronts up after its barrier.
+__device__ __forceinline__ void exact_publish(double (&acc)[6], RedScratch* red, int tid) {
 #pragma unroll
-        for (int o = 1; o < K; ++o) {        // r, re are wave-uniform: scalar selects
-            xl = o == r ? w[o] : xl;
-            xe = o == re ? w[o] : xe;
+    for (int v = 0; v < 6; ++v) acc[v] = wave_sum_last(acc[v]);
+    if ((tid & 63) == 63) {
+        double* o = red->expart[tid >> 6];
+#pragma unroll
+        for (int v = 0; v < 6; ++v) o[v] = acc[v];
+    }
+}
+template <int W>
+__device__ __forceinline__ void exact_collect(const RedScratch* red, double (&ex)[6]) {
+#pragma unroll
+    for (int v = 0; v < 6; ++v) {
+        double a = red->expart[0][v];
+#pragma unroll
+        for (int w = 1; w < W; ++w) a += red->expart[w][v];
+        ex[v] = a;
+    }
+}
+
+// ExactOwn: the sums from the raw samples the halo-free staging has just fetched (thread t owns chips m = t + c*T, K
+// samples each, still in registers).  The offset r = s mod K is uniform, so the split of a chip's samples between replica
+// chips j-1 and j is compiled in (one straight-line body per r behind a scalar switch: no per-sample selects).
+// acc * w + x  (complex, x a float32 sample): one Horner step of sum_i x_i w^i
+__device__ __forceinline__ double2 horner64(double2 acc, double2 w, cf x) {
+    return make_double2(fma(acc.x, w.x, fma(-acc.y, w.y, (double)x.x)), fma(acc.x, w.y, fma(acc.y, w.x, (double)x.y)));
+}
+template <int K, int R>
+__device__ __forceinline__ void exact_own_body(const OwnSamples<K>& smp, const RedScratch* red, const float* __restrict__ chipf, int q,
+                                               double u0, double du, int tid, double (&acc)[6]) {
+    constexpr int T = OwnSamples<K>::T, CH = OwnSamples<K>::CH;
+    constexpr int RE = R ? R - 1 : K - 1;   // offset of the early-side boundary sample
+    // Per chip, Horner in rho over the two runs of samples (i >= R meets replica chip j, i < R chip j-1):
+    //   sum_{i>=R} x_i rho^i = rho^R * h,  h = x_R + rho (x_{R+1} + rho (...)),     sum_{i<R} x_i rho^i = g likewise
+    // -- three wave-uniform constants live (rho, rho^R, rho^RE) instead of a table of K powers.  Chips are folded last chip
+    // first with the chip-stride rotation xc[K] (Horner again), and the thread's anchor carrier is applied once at the end.
+    const double2 rho = red->xc[1 < K ? 1 : 0], rho_r = red->xc[R], rho_e = red->xc[RE], step = red->xc[K];
+    double2 sp = make_double2(0.0, 0.0), se = sp, sl = sp;
+#pragma unroll
+    for (int c = CH - 1; c >= 0; --c) {
+        const int m = tid + c * T;
+        int j = m - q;
+        j = j < 0 ? j + kChips : j;               // (m - q) mod 1023
+        const float* cp = chipf + j + kChips;
+        const float z = m < kChips ? 1.f : 0.f;   // the padding chip m == 1023 (its registers hold a copy of chip 1022): no weight
+        const float cm1 = cp[-1] * z, c0 = cp[0] * z, cp1 = cp[1] * z;
+        const double dj = (double)c0, djm1 = (double)cm1, gl = (double)(cm1 - c0), ge = (double)(R ? cm1 - c0 : c0 - cp1);
+        const cf (&x)[K] = smp.w[c];
+        double2 h = make_double2((double)x[K - 1].x, (double)x[K - 1].y);
+#pragma unroll
+        for (int i = K - 2; i >= R; --i) h = horner64(h, rho, x[i]);
+        h = cmul64(h, rho_r);
+        double2 pc = make_double2(dj * h.x, dj * h.y);
+        if (R > 0) {
+            double2 g = make_double2((double)x[R - 1].x, (double)x[R - 1].y);
+#pragma unroll
+            for (int i = R - 2; i >= 0; --i) g = horner64(g, rho, x[i]);
+            pc.x = fma(djm1, g.x, pc.x); pc.y = fma(djm1, g.y, pc.y);
         }
-        int m = j - q;
-        m = m < 0 ? m + kChips : m;          // (j - q) mod 1023, j < 1023 (the padding chip j == 1023 carries zeros)
-        const float* cp = chipf + m + kChips;
-        const float c0 = cp[-1], c1 = cp[0], c2 = cp[1];
-        const float gl = c0 - c1;                             // chip[m-1] - chip[m]
-        const float ge = r ? gl : c1 - c2;                    // r == 0: transition m + 1
-        acc[0] += (double)(ge * xe.x); acc[1] += (double)(ge * xe.y);     // +-2 * x: exact
-        acc[2] += (double)(gl * xl.x); acc[3] += (double)(gl * xl.y);
-    }
-    __device__ __forceinline__ void finish(RedScratch* red, int tid) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) acc[v] = wave_sum_last(acc[v]);
-        if ((tid & 63) == 63) {
-            double* o = red->elpart[tid >> 6];
-            o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+        const double2 tl = cmul64(make_double2((double)x[R].x, (double)x[R].y), rho_r);
+        const double2 te = cmul64(make_double2((double)x[RE].x, (double)x[RE].y), rho_e);
+        const double2 lc = make_double2(gl * tl.x, gl * tl.y), ec = make_double2(ge * te.x, ge * te.y);
+        if (c == CH - 1) { sp = pc; se = ec; sl = lc; }
+        else {
+            const double2 a = cmul64(sp, step), b = cmul64(se, step), d = cmul64(sl, step);
+            sp = make_double2(a.x + pc.x, a.y + pc.y);
+            se = make_double2(b.x + ec.x, b.y + ec.y);
+            sl = make_double2(d.x + lc.x, d.y + lc.y);
         }
     }
-};
+    const double2 anchor = carrier64(u0 + du * (double)(K * tid));
+    const double2 p = cmul64(sp, anchor), e = cmul64(se, anchor), l = cmul64(sl, anchor);
+    acc[0] = p.x; acc[1] = p.y; acc[2] = e.x; acc[3] = e.y; acc[4] = l.x; acc[5] = l.y;
+}
 template <int K>
-__device__ __forceinline__ void el_collect(const RedScratch* red, double (&eld)[4]) {
+__device__ __forceinline__ void exact_own(const OwnSamples<K>& smp, RedScratch* red, const float* __restrict__ chipf, int sN, double u0, double du,
+                                          int tid) {
+    static_assert(kExactOwn<K>, "rates whose tuned kernels keep the raw samples in registers");
+    const int q = __builtin_amdgcn_readfirstlane(sN / K), r = __builtin_amdgcn_readfirstlane(sN % K);
+    double acc[6];
+    if constexpr (K == 2) {
+        if (r == 0) exact_own_body<K, 0>(smp, red, chipf, q, u0, du, tid, acc);
+        else exact_own_body<K, 1>(smp, red, chipf, q, u0, du, tid, acc);
+    } else {
+        switch (r) {   // scalar
+            case 0: exact_own_body<K, 0>(smp, red, chipf, q, u0, du, tid, acc); break;
+            case 1: exact_own_body<K, 1>(smp, red, chipf, q, u0, du, tid, acc); break;
+            case 2: exact_own_body<K, 2>(smp, red, chipf, q, u0, du, tid, acc); break;
+            case 3: exact_own_body<K, 3>(smp, red, chipf, q, u0, du, tid, acc); break;
+            case 4: exact_own_body<K, 4>(smp, red, chipf, q, u0, du, tid, acc); break;
+            case 5: exact_own_body<K, 5>(smp, red, chipf, q, u0, du, tid, acc); break;
+            case 6: exact_own_body<K, 6>(smp, red, chipf, q, u0, du, tid, acc); break;
+            default: exact_own_body<K, 7>(smp, red, chipf, q, u0, du, tid, acc); break;
+        }
+    }
+    exact_publish(acc, red, tid);
+}
+
+// The same three sums for any rate and any workgroup size, straight from the block in memory: thread t walks samples
+// [t*L, (t+1)*L) with a float64 carrier recurrence (anchor per thread, one rotation per sample).  Used by the rates without
+// ExactOwn and by dll_scan_kernel's repair steps.  acc: this thread's partial sums.
+template <int K, int T>
+__device__ __forceinline__ void exact_epl_generic(const cf* __restrict__ block, double u0, double du, int sN, const float* __restrict__ chipf,
+                                                  int tid, double (&acc)[6]) {
+    constexpr int N = K * kChips;
+    constexpr int L = (N + T - 1) / T;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        double a = red->elpart[0][v];
-#pragma unroll
-        for (int w = 1; w < Geom<K>::W; ++w) a += red->elpart[w][v];
-        eld[v] = a;
+    for (int v = 0; v < 6; ++v) acc[v] = 0.0;
+    const int n0 = tid * L;
+    if (n0 >= N) return;
+    const int n1 = n0 + L < N ? n0 + L : N;
+    double2 car = carrier64(u0 + du * (double)n0);
+    const double2 rot = carrier64(du);            // (|du| up to 5e-3 cycles at the lowest rates: the full-range form)
+    int k = n0 - sN;                              // (n - s) mod N: replica chip k / K, offset k % K
+    k = k < 0 ? k + N : k;
+    int c = k / K, ph = k - c * K;
+    for (int n = n0; n < n1; ++n) {
+        const cf x = block[n];
+        const double2 w = cmul64(make_double2((double)x.x, (double)x.y), car);
+        const float cc = chipf[c];
+        const double d = (double)cc;
+        acc[0] = fma(d, w.x, acc[0]); acc[1] = fma(d, w.y, acc[1]);
+        if (ph == K - 1) {                        // lag s-1 sees the next replica chip here
+            const double g = (double)(cc - chipf[c + 1]);
+            acc[2] = fma(g, w.x, acc[2]); acc[3] = fma(g, w.y, acc[3]);
+        }
+        if (ph == 0) {                            // lag s+1 sees the previous one
+            const double g = (double)(chipf[c + kChips - 1] - cc);
+            acc[4] = fma(g, w.x, acc[4]); acc[5] = fma(g, w.y, acc[5]);
+        }
+        car = cmul64(car, rot);
+        if (++ph == K) { ph = 0; if (++c == kChips) c = 0; }
     }
 }
 
 // E/P/L of one millisecond given the un-rolled correlation c0:
 //   early = c0[(s-1) mod N], late = c0[(s+1) mod N], prompt profile[k] = c0[(s+k) mod N].
 struct EplResult {
-    double eld[4];   // float64 boundary sums c0[s] - c0[s-1], c0[s+1] - c0[s] (el_wave_partials), if requested
+    double ex[6];    // float64 {P, c0[s] - c0[s-1], c0[s+1] - c0[s]} (re, im each) of the code loop's lag s, if requested
     cf early, late, peak, probe;
     Best best;   // best.key = peak offset in the rolled profile, best.v = |peak|
     double sum;
@@ -1218,7 +1267,7 @@ __device__ __forceinline__ EplResult epl_finish_wave(RedScratch* red) {
     r.early = make_float2(red->taps[0], red->taps[1]);
     r.late = make_float2(red->taps[2], red->taps[3]);
     r.probe = make_float2(red->taps[4], red->taps[5]);
-    el_collect<K>(red, r.eld);
+    exact_collect<Geom<K>::W>(red, r.ex);
     r.peak = make_float2(g.re, g.im);
     r.best = Best{__builtin_amdgcn_sqrtf(g.v), g.key};
     r.sum = sum;
@@ -1233,7 +1282,7 @@ __device__ __forceinline__ EplResult epl_finish(const LaneStats& ls, RedScratch*
     r.early = make_float2(red->taps[0], red->taps[1]);
     r.late = make_float2(red->taps[2], red->taps[3]);
     r.probe = make_float2(red->taps[4], red->taps[5]);
-    el_collect<K>(red, r.eld);
+    exact_collect<Geom<K>::W>(red, r.ex);
     r.peak = st.peak;
     r.best = st.best;
     r.sum = st.sum;
@@ -1243,47 +1292,50 @@ __device__ __forceinline__ EplResult epl_finish(const LaneStats& ls, RedScratch*
 
 // One tracking millisecond of one channel: all rounds, then the reductions.
 // `probe`: one more lag (0 <= probe < N) whose complex value is returned in EplResult::probe.
-// WANT_EL: also form the float64 early/late boundary sums (EplResult::eld) -- from the staging's own wiped samples
-// where the halo-free staging is used (chipf), by gathering the transition samples otherwise (trans / nt).
-template <int K, bool WANT_EL = false>
+// WANT_EX: also form the code loop's float64 sums (EplResult::ex): from the raw samples of the halo-free staging where
+// kExactOwn (RedScratch::xc must hold exact_consts of this du -- PREP_CONSTS forms them here, at the price of a barrier; the
+// persistent block kernel keeps them current in its loop update), by a pass of their own over the block otherwise.
+template <int K, bool WANT_EX = false, bool PREP_CONSTS = true>
 __device__ __forceinline__ EplResult track_ms(const cf* __restrict__ block, double u0, double du, const CarrierSteps& cs,
                                               int code_phase, int probe, const Smem& sm, const cf* __restrict__ rep, float* profile_row,
-                                              const uint16_t* trans = nullptr, int nt = 0, const float* chipf = nullptr) {
+                                              const float* chipf = nullptr) {
     constexpr int N = K * kChips;
     const int s = mod_n(code_phase, N);
-    const ElJob job{block, u0, du, s, trans, nt, chipf};
+    if constexpr (WANT_EX && kExactOwn<K> && kOwnStaging<K>) {
+        if constexpr (PREP_CONSTS) {
+            if ((threadIdx.x >> 6) == 0) exact_consts<K>(sm.red, du, threadIdx.x & 63);
+            __syncthreads();
+        }
+    }
+    auto raw_hook = [&](const OwnSamples<kOwnStaging<K> ? K : 1>& smp, int tid) {
+        if constexpr (WANT_EX && kExactOwn<K> && kOwnStaging<K>) exact_own<K>(smp, sm.red, chipf, s, u0, du, tid);
+    };
+    auto generic_ex = [&]() {   // rates without ExactOwn: the workgroup walks the block once more (L1/L2-resident by now)
+        if constexpr (WANT_EX && !(kExactOwn<K> && kOwnStaging<K>)) {
+            double acc[6];
+            const int tid = launder(threadIdx.x);
+            exact_epl_generic<K, Geom<K>::kThreads>(block, u0, du, s, chipf, tid, acc);
+            exact_publish(acc, sm.red, tid);
+        }
+    };
     if constexpr (Geom<K>::R == 1) {
         cf c[16];
-        if constexpr (kOwnStaging<K> && K >= 8 && WANT_EL) {   // (K = 2, 4: few transitions per thread, float64 gather kept)
-            // the boundary sums come from the samples the staging holds anyway (reduced per wavefront at once: nothing
-            // stays live across the transforms)
-            ElOwn<K> el;
-            el.init(job);
-            const int tid0 = launder(threadIdx.x);
-            correlate_round<K>(block, 0, u0, du, cs, sm, rep, c, [&](int ci, const cf (&w)[K]) { el.chip(ci, w, tid0); },
-                               [&](int tid) { el.finish(sm.red, tid); });
-            epl_round_wave<K>(c, s, probe, sm.red, profile_row, launder(threadIdx.x));
-        } else {
-            correlate_round<K>(block, 0, u0, du, cs, sm, rep, c);
-            epl_round_wave<K>(c, s, probe, sm.red, profile_row, launder(threadIdx.x));
-            if constexpr (WANT_EL) el_wave_partials<K>(job, sm.red, launder(threadIdx.x));
-        }
+        correlate_round<K>(block, 0, u0, du, cs, sm, rep, c, raw_hook);
+        epl_round_wave<K>(c, s, probe, sm.red, profile_row, launder(threadIdx.x));
+        generic_ex();
         return epl_finish_wave<K>(sm.red);
     }
     LaneStats ls = lane_stats_init();
     if constexpr (kOwnStaging<K>) {
         // all K rows resident: one staging pass (round 0), no barrier between the rounds; epl_finish's barrier is the one
         // that precedes the next millisecond's staging
-        ElOwn<K> el;
-        el.init(job);
-        const int tid0 = launder(threadIdx.x);
 #pragma unroll 1
         for (int rho = 0; rho < Geom<K>::R; ++rho) {
             cf c[16];
-            correlate_round<K>(block, rho, u0, du, cs, sm, rep, c, [&](int ci, const cf (&w)[K]) { if (WANT_EL) el.chip(ci, w, tid0); },
-                               [&](int tid) { if (WANT_EL) el.finish(sm.red, tid); });
+            correlate_round<K>(block, rho, u0, du, cs, sm, rep, c, raw_hook);
             epl_round<K>(c, rho, s, probe, ls, sm.red, profile_row, launder(threadIdx.x));
         }
+        generic_ex();
         return epl_finish<K>(ls, sm.red, launder(threadIdx.x));
     }
 #pragma unroll 1
@@ -1293,7 +1345,7 @@ __device__ __forceinline__ EplResult track_ms(const cf* __restrict__ block, doub
         epl_round<K>(c, rho, s, probe, ls, sm.red, profile_row, launder(threadIdx.x));
         if (Geom<K>::R > 1) __syncthreads();   // tiles are re-staged by the next round
     }
-    if constexpr (WANT_EL) el_wave_partials<K>(job, sm.red, launder(threadIdx.x));
+    generic_ex();
     return epl_finish<K>(ls, sm.red, launder(threadIdx.x));
 }
 
@@ -1312,15 +1364,14 @@ __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void 
         const double u0 = in.doppler_hz * p.start_time[in.stream] + in.carrier_phase * 0.15915494309189533577;
         const cf* block = p.iq + (int64_t)in.stream * p.stream_stride;
         const EplResult r = track_ms<K, true>(block, u0, du, carrier_steps<K>(du), in.code_phase, mod_n(in.code_phase, N),
-                                        sm, rep, p.profile_out ? p.profile_out + (int64_t)ch * N : nullptr,
-                                        p.trans + (in.sat_id - 1) * kMaxTrans, p.n_trans[in.sat_id - 1], p.chipf + (in.sat_id - 1) * 2048);
+                                        sm, rep, p.profile_out ? p.profile_out + (int64_t)ch * N : nullptr, p.chipf + (in.sat_id - 1) * 2048);
         if (threadIdx.x == 0) {
             gyp_chan_out o;
             o.early_re = r.early.x; o.early_im = r.early.y;
             o.late_re = r.late.x; o.late_im = r.late.y;
-            const double* d = r.eld;
-            o.early64_re = (double)r.probe.x - d[0]; o.early64_im = (double)r.probe.y - d[1];
-            o.late64_re = (double)r.probe.x + d[2]; o.late64_im = (double)r.probe.y + d[3];
+            const double* x = r.ex;     // E = P - (c0[s] - c0[s-1]), L = P + (c0[s+1] - c0[s]), all float64
+            o.early64_re = x[0] - x[2]; o.early64_im = x[1] - x[3];
+            o.late64_re = x[0] + x[4]; o.late64_im = x[1] + x[5];
             o.peak_re = r.peak.x; o.peak_im = r.peak.y;
             o.peak_mag = r.best.v;
             o.peak_offset = r.best.key;
@@ -1508,9 +1559,11 @@ __device__ __attribute__((noinline)) void constellation_stats_wave(const ChanSta
 struct SpecIn {
     double doppler, carrier_phase;   // loop state the millisecond was processed with
     int32_t code_phase;
-    int32_t key;                     // window arg-max as an index into the rolled profile; < 0: the millisecond took the
-                                     // full-transform path inside the tracking kernel (its record is already complete)
+    int32_t key;                     // window arg-max as an index into the rolled profile; -1: the millisecond took the
+                                     // full-transform path inside the tracking kernel (its record is already complete);
+                                     // -2: the channel was lost, the millisecond was not processed
 };
+constexpr int kSpecKeyTransform = -1, kSpecKeyLost = -2;
 
 struct TrackBlockParams {
     const cf* iq;
@@ -1531,6 +1584,7 @@ struct TrackBlockParams {
     // speculative mode (MODE 2)
     SpecIn* spec_out;          // [n_chan][n_ms]
     float spec_kappa;          // window peak^2 must reach spec_kappa * (energy of the millisecond's samples)
+    double prov_bias;          // test hook: added to the provisional discriminator (see dll_scan_kernel)
     // re-run mode: only channels with only_if[ch] != 0 run, after restoring their state from restore_from[ch]
     const int32_t* only_if;
     const ChanState* restore_from;
@@ -1694,13 +1748,13 @@ __device__ __forceinline__ void costas_update(const LoopConst& kc, ChanState* st
             }
         }
     }
+    exact_consts<K>(red, nf * kc.inv_fs, lane);   // (all lanes) the code loop's float64 constants for the next wipe-off
     if (lane == 0) {
         red->loop.last_watchdog = last_watchdog; red->loop.n_steps = n + 1; red->loop.sums = sums;
         red->loop.pos_e = pos_e; red->loop.pos_p = pos_p; red->loop.pos_refresh = pos_refresh;
         red->dstate[0] = nf; red->dstate[1] = nphi;
         red->istate[1] = lost;
         red->steps = tracking_steps<K>(nf * kc.inv_fs);
-        red->pscale = kOwnStaging<K> ? prompt_scale<K>(red->steps.rot1, make_float2(1.f, 0.f)) : 1.0;
         gyp_track_rec& o = red->rec;
         o.peak_re = r.peak.x; o.peak_im = r.peak.y;
         if (r.strength_pending) {
@@ -2126,9 +2180,10 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
         __threadfence();
         __syncthreads();
     }
-    const int sat_index = st->sat_id - 1;
+    // (wave-uniform values out of vector loads: as scalars, so that the pointers derived from them live in scalar registers)
+    const int sat_index = __builtin_amdgcn_readfirstlane(st->sat_id) - 1;
     const cf* rep = replica_of(p.replica_table, sat_index);
-    const cf* stream = p.iq + (int64_t)st->stream * p.stream_stride;
+    const cf* stream = p.iq + (int64_t)__builtin_amdgcn_readfirstlane(st->stream) * p.stream_stride;
     const uint16_t* trans = p.codes.trans + sat_index * kMaxTrans;
     const int nt = p.codes.n_trans[sat_index];
     if (SPEC) {
@@ -2154,11 +2209,11 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
         sm.red->cc[0].rot1 = sm.red->steps.rot1;
         sm.red->cc[0].step = carrier_from_cycles_fast(st->doppler * p.inv_fs * (double)(K * kSpecThreads));
         sm.red->cc[0].pscale = prompt_scale<K>(sm.red->cc[0].rot1, sm.red->cc[0].step);
-        sm.red->pscale = kOwnStaging<K> ? prompt_scale<K>(sm.red->steps.rot1, make_float2(1.f, 0.f)) : 1.0;
         sm.red->cand_sel = 0; sm.red->rec_sel = 0;
         sm.red->defer = 0;
         if (SPEC && p.ms_begin < p.ms_end) sm.red->t0_next = p.start_time[p.ms_begin];
     }
+    if (!SPEC && wave == 0) exact_consts<K>(sm.red, st->doppler * p.inv_fs, lane);   // as costas_update leaves them
     __syncthreads();
     const bool prof = PROF && p.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
     long long tp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -2198,7 +2253,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
                     z.carrier_phase = SPEC ? sm.red->cc[sm.red->cand_sel].nphi : sm.red->dstate[1];
                     *rec = z;
                 }
-                if (SPEC) p.spec_out[(int64_t)ch * p.n_ms + ms].key = -1;
+                if (SPEC) p.spec_out[(int64_t)ch * p.n_ms + ms].key = kSpecKeyLost;
             }
             continue;
         }
@@ -2218,7 +2273,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
             pscale = cand.pscale;
         } else {
             f = sm.red->dstate[0]; phi = sm.red->dstate[1]; cs = sm.red->steps;
-            pscale = sm.red->pscale;
+            pscale = 1.0;
         }
         {
             const int code_phase = sm.red->istate[0];
@@ -2324,7 +2379,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
                 if (wave == 1) {   // the code loop runs beside the Costas loop (wavefront 0)
                     const cf p0 = sl.win[2 * kSpecHalf], p1 = sl.win[2 * kSpecHalf + 1], p2 = sl.win[2 * kSpecHalf + 2], p3 = sl.win[2 * kSpecHalf + 3];
                     const double d[4] = {sl.fin[0] + sl.fin[1], sl.fin[2] + sl.fin[3], sl.fin[4] + sl.fin[5], sl.fin[6] + sl.fin[7]};
-                    m.disc = dll_discriminator((double)((p0.x + p1.x) + (p2.x + p3.x)) * pscale, (double)((p0.y + p1.y) + (p2.y + p3.y)) * pscale, d);
+                    m.disc = dll_discriminator((double)((p0.x + p1.x) + (p2.x + p3.x)) * pscale, (double)((p0.y + p1.y) + (p2.y + p3.y)) * pscale, d) + p.prov_bias;   // PROVISIONAL: dll_scan_kernel re-integrates the loop exactly
                 }
                 if (wave == 3 && lane == 0) {
                     SpecIn si;
@@ -2333,13 +2388,13 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
                     sm.red->istate[2] = next_centre;
                 }
             } else {
-                const EplResult r = track_ms<K, true>(block, u0, du, cs, code_phase, mod_n(code_phase, N), sm, rep, nullptr, trans, nt,
-                                                      p.codes.chipf + sat_index * 2048);
+                const EplResult r = track_ms<K, true, false>(block, u0, du, cs, code_phase, mod_n(code_phase, N), sm, rep, nullptr,
+                                                             p.codes.chipf + sat_index * 2048);
                 if (prof) t_b = (long long)__builtin_readcyclecounter();
                 m.peak = r.peak; m.peak_mag = r.best.v; m.key = r.best.key; m.sum = r.sum; m.n_max = r.n_max;
                 m.strength_pending = false;
                 m.path_info = 0;
-                m.disc = dll_discriminator((double)r.probe.x * pscale, (double)r.probe.y * pscale, r.eld);
+                m.disc = dll_discriminator_exact(r.ex);   // float64 end to end: int(self.phase) follows tracker.py:297-301
                 if (prof) t_c = (long long)__builtin_readcyclecounter();
             }
         }
@@ -2408,8 +2463,10 @@ struct TrackVerifyParams {
     const SpecIn* spec;
     gyp_track_rec* rec_out;
     int32_t* bad;
+    double* disc_out;          // [n_chan][n_ms]: tracker.py:297 in float64 at the lag the tracking kernel used (dll_scan_kernel's input)
     const cf* replica_table;
     const cf* tw_tables;
+    const float* chipf;        // CodeTables::chipf
     double inv_fs;
     float tie_tol;
 };
@@ -2425,26 +2482,137 @@ __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void 
         const int u = xcd_contiguous(v, n_units);
         const int ms = p.ms_begin + u / p.n_chan, ch = u % p.n_chan;   // the channels of a millisecond are neighbours: shared IQ
         const SpecIn in = p.spec[(int64_t)ch * p.n_ms + ms];
-        if (in.key < 0) continue;                                 // uniform
+        if (in.key == kSpecKeyLost) continue;                     // uniform
         const ChanState* st = p.states + ch;
         const cf* rep = replica_of(p.replica_table, st->sat_id - 1);
         const cf* block = p.iq + (int64_t)st->stream * p.stream_stride + (int64_t)ms * N;
         const double du = in.doppler * p.inv_fs;
         const double u0 = in.doppler * p.start_time[ms] + in.carrier_phase * 0.15915494309189533577;
-        int probe = mod_n(in.code_phase, N) + in.key;
+        const int sN = mod_n(in.code_phase, N);
+        int probe = sN + (in.key >= 0 ? in.key : 0);
         probe = probe >= N ? probe - N : probe;
-        const EplResult r = track_ms<K>(block, u0, du, carrier_steps<K>(du), in.code_phase, probe, sm, rep, nullptr);
+        const EplResult r = track_ms<K, true>(block, u0, du, carrier_steps<K>(du), in.code_phase, probe, sm, rep, nullptr,
+                                              p.chipf + (st->sat_id - 1) * 2048);
         if (threadIdx.x == 0) {
-            if (r.best.key != in.key) {
-                const float vp = fmaf(r.probe.x, r.probe.x, r.probe.y * r.probe.y), vm = r.best.v * r.best.v;
-                if (!(vp >= vm * (1.0f - p.tie_tol))) p.bad[ch] = 1;
-            }
-            if (p.rec_out) {
-                const float mean_excl = (float)((r.sum - (double)r.n_max * (double)r.best.v) / (double)(N - r.n_max));
-                p.rec_out[(int64_t)ch * p.n_ms + ms].strength = r.best.v / mean_excl;
+            p.disc_out[(int64_t)ch * p.n_ms + ms] = dll_discriminator_exact(r.ex);
+            if (in.key >= 0) {   // a millisecond that advanced on its window maximum
+                if (r.best.key != in.key) {
+                    const float vp = fmaf(r.probe.x, r.probe.x, r.probe.y * r.probe.y), vm = r.best.v * r.best.v;
+                    if (!(vp >= vm * (1.0f - p.tie_tol))) p.bad[ch] = 1;
+                }
+                if (p.rec_out) {
+                    const float mean_excl = (float)((r.sum - (double)r.n_max * (double)r.best.v) / (double)(N - r.n_max));
+                    p.rec_out[(int64_t)ch * p.n_ms + ms].strength = r.best.v / mean_excl;
+                }
             }
         }
         __syncthreads();
+    }
+}
+
+// The code loop of the speculative path, re-integrated exactly.  track_block_kernel MODE 2 advances its code phase on a
+// PROVISIONAL discriminator (float32 prompt value); the code loop is a side chain (nothing else of the tracker reads it), so
+// its exact trajectory can be formed afterwards: track_verify_kernel has evaluated tracker.py:297 in float64 for every
+// millisecond at the lag the tracking kernel used, and this kernel -- one workgroup per channel, the milliseconds in order --
+// integrates tracker.py:298-303 from those values.  Where its int(self.phase) differs from the provisional one (the two
+// accumulators straddle an integer: about once per 1e6 channel-ms, for a few milliseconds each time) the millisecond's sums
+// are formed on the spot for the right lag (exact_epl_generic over the block: a "repair" step) and the record's
+// code phase / peak offset are corrected.  The exact state travels from sub-block to sub-block in DllExact and is written
+// back into the channel state by the last one, so the next call starts from it.
+struct DllExact {
+    double dll;            // self.phase
+    int32_t code_phase;    // current_prn_code_phase_shift
+    int32_t repairs;       // repair steps so far in this call (telemetry)
+};
+struct DllScanParams {
+    const cf* iq;
+    int64_t stream_stride;
+    int32_t n_ms, ms_begin, ms_end;
+    const double* start_time;
+    ChanState* states;
+    const ChanState* ckpt;     // the states before the call
+    int32_t n_chan;
+    const SpecIn* spec;
+    const double* disc;
+    gyp_track_rec* rec_out;
+    DllExact* exact;
+    const int32_t* bad;
+    const float* chipf;
+    double inv_fs, dll_gain, dll_modulus, n_samples;
+    int32_t first, final;
+};
+constexpr int kScanThreads = 512;
+template <int K>
+__global__ __launch_bounds__(kScanThreads) void dll_scan_kernel(DllScanParams p) {
+    constexpr int N = K * kChips;
+    __shared__ double part[kScanThreads / 64][6];
+    const int ch = blockIdx.x, tid = threadIdx.x;
+    if (ch >= p.n_chan || p.bad[ch]) return;   // (a channel sent back through the transform kernel gets everything from there)
+    const ChanState* st = p.states + ch;
+    double a;
+    int s, repairs;
+    if (p.first) { a = p.ckpt[ch].dll_phase; s = p.ckpt[ch].code_phase; repairs = 0; }
+    else { const DllExact x = p.exact[ch]; a = x.dll; s = x.code_phase; repairs = x.repairs; }
+    const float* chipf = p.chipf + (st->sat_id - 1) * 2048;
+    const cf* stream = p.iq + (int64_t)st->stream * p.stream_stride;
+    // (the hand-over records do not depend on the chain: the next millisecond's are requested one iteration early, so the
+    // serial loop never waits for memory)
+    SpecIn in_next = p.spec[(int64_t)ch * p.n_ms + p.ms_begin];
+    double d_next = p.disc[(int64_t)ch * p.n_ms + p.ms_begin];
+    for (int ms = p.ms_begin; ms < p.ms_end; ++ms) {
+        const int64_t at = (int64_t)ch * p.n_ms + ms;
+        const SpecIn in = in_next;
+        double d = d_next;
+        if (ms + 1 < p.ms_end) { in_next = p.spec[at + 1]; d_next = p.disc[at + 1]; }
+        gyp_track_rec* rec = p.rec_out ? p.rec_out + at : nullptr;
+        if (in.key == kSpecKeyLost) {          // not processed: the loop state stands (the status-2 record carries it)
+            if (rec && tid == 0) rec->code_phase = s;
+            continue;
+        }
+        if (s != in.code_phase) {              // uniform
+            double acc[6];
+            const double du = in.doppler * p.inv_fs;
+            const double u0 = in.doppler * p.start_time[ms] + in.carrier_phase * 0.15915494309189533577;
+            exact_epl_generic<K, kScanThreads>(stream + (int64_t)ms * N, u0, du, mod_n(s, N), chipf, tid, acc);
+#pragma unroll
+            for (int v = 0; v < 6; ++v) acc[v] = wave_sum_last(acc[v]);
+            __syncthreads();                   // the previous repair's readers are done with `part`
+            if ((tid & 63) == 63) {
+#pragma unroll
+                for (int v = 0; v < 6; ++v) part[tid >> 6][v] = acc[v];
+            }
+            __syncthreads();
+            double ex[6];
+#pragma unroll
+            for (int v = 0; v < 6; ++v) {
+                double t = part[0][v];
+#pragma unroll
+                for (int w = 1; w < kScanThreads / 64; ++w) t += part[w][v];
+                ex[v] = t;
+            }
+            d = dll_discriminator_exact(ex);
+            ++repairs;
+            if (rec && tid == 0) {             // the arg-max LAG stands; its index in the profile of the PRN rolled by s moves
+                int lag = rec->peak_offset + mod_n(in.code_phase, N);
+                lag = lag >= N ? lag - N : lag;
+                int key = lag - mod_n(s, N);
+                rec->peak_offset = key < 0 ? key + N : key;
+            }
+        }
+        // tracker.py:298-303, as dll_update
+        double dll = a + d * p.dll_gain;
+        const double whole = trunc(dll);
+        const int s_next = uniform(fabs(whole) < 2147483648.0) ? (int)whole : code_phase_beyond_int32(whole, p.n_samples);
+        dll = pymod_uniform(dll, p.dll_modulus);
+        dll += dll < 0.0 ? p.dll_modulus : 0.0;
+        a = dll;
+        s = s_next;
+        if (rec && tid == 0) { rec->discriminator = (float)d; rec->code_phase = s_next; }
+    }
+    if (tid == 0) {
+        DllExact x; x.dll = a; x.code_phase = s; x.repairs = repairs;
+        p.exact[ch] = x;
+        if (p.final) { p.states[ch].dll_phase = a; p.states[ch].code_phase = s; }
     }
 }
 

@@ -326,6 +326,13 @@ class ChannelBank:
         self.engine._check(self.engine.lib.gyp_bank_get_state(self.handle, ptr(f), ptr(phi), ptr(cp), ptr(lost)))
         return {"doppler_hz": f, "carrier_phase": phi, "code_phase": cp, "lost": lost}
 
+    def dll_repairs(self) -> np.ndarray:
+        """Per channel: milliseconds of the last block in which the exactly re-integrated code loop differed from the
+        speculative kernel's provisional one and repaired it (gyp_debug_dll_read); zeros on the throughput kernel."""
+        out = np.zeros(self.n_chan, dtype=np.int32)
+        self.engine._check(self.engine.lib.gyp_debug_dll_read(self.handle, _lib.ptr(out)))
+        return out
+
     def close(self) -> None:
         if getattr(self, "handle", None) is not None and self.handle.value:
             self.engine.lib.gyp_bank_destroy(self.handle)

@@ -1,0 +1,202 @@
+"""The code loop in float64 end to end.
+
+tracker.py:293-301 integrates (|E|^2 - |L|^2)/2 * 0.002 from complex128 single-lag correlations and takes int() of the
+accumulator every millisecond; any error that accumulates eventually lands int(self.phase) on the other side of an
+integer.  Since r03 the three lags the DLL reads are formed from the raw samples with a float64 carrier:
+  * gyp_track_step: early64 / late64 agree with np.correlate to ~1e-12 (here: every instantiated rate, every sample
+    offset s mod K, the wrap lags, a late start time);
+  * throughput kernel: the sums are formed in line;
+  * speculative tracker: the serial kernel runs on a provisional discriminator, the verify pass forms the exact one per
+    millisecond and dll_scan_kernel re-integrates the loop, repairing the milliseconds where the two disagree.  The repair
+    path is FORCED here with a bias on the provisional discriminator (GYP_DLL_PROV_BIAS): records and final state must still
+    equal the transform kernel's and the oracle's.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import pytest
+
+from gypsum_amd import _lib, synth
+from gypsum_amd._lib import CHAN_IN
+from oracle import gypsum_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+RATES = [1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 48]
+
+
+@pytest.mark.parametrize("k", RATES)
+def test_early_late_are_float64_exact_at_every_rate(engine_factory, k):
+    fs, n = 1_023_000 * k, 1023 * k
+    eng = engine_factory(fs, n)
+    scene = synth.random_scene(fs, 3, 3, 4100 + k, max_doppler=4800.0, with_nav_bits=False)
+    iq = synth.render(scene)
+    chips = orc.generate_ca_codes()
+    sat = scene.sats[0]
+    prn = orc.prn_as_complex(chips[sat.sat_id - 1], n)
+    # every offset inside a chip, the wrap lags, a lag beyond N (np.roll semantics), negative
+    lags = sorted({0, 1, n - 1, n - 2, n, n + 3, -1, -5, sat.code_phase} | {37 * k + r for r in range(min(k, 9))} |
+                  {sat.code_phase + d for d in (-2, -1, 1, 2, 7)})
+    worst = 0.0
+    for ms, t_add in ((1, 0.0), (2, 40.0)):          # a late start time: 2 pi f t ~ 1e6 rad
+        t0 = orc.chunk_times(ms * n, n, fs)[0] + t_add
+        ch = np.zeros(len(lags), dtype=CHAN_IN)
+        for i, s in enumerate(lags):
+            ch[i] = (0, sat.sat_id, sat.doppler_hz + 0.37, 0.8, s, 0)
+        out, _ = eng.track_step(iq[ms * n:(ms + 1) * n], 1, [t0], ch)
+        t = np.arange(n) / fs + t0
+        xw = iq[ms * n:(ms + 1) * n] * np.exp(-1j * ((2 * np.pi * (sat.doppler_hz + 0.37) * t) + 0.8))
+        scale = float(np.sqrt(np.sum(np.abs(xw) ** 2) * n))      # |sum| <= ||xw|| * ||prn||
+        for i, s in enumerate(lags):
+            e = np.correlate(xw, np.roll(prn, s - 1))[0]
+            l = np.correlate(xw, np.roll(prn, s + 1))[0]
+            ge = complex(out["early64_re"][i], out["early64_im"][i])
+            gl = complex(out["late64_re"][i], out["late64_im"][i])
+            worst = max(worst, abs(ge - e) / scale, abs(gl - l) / scale)
+    # float64 sums of 1023 K terms: ~1e-16 sqrt(N) of the norm; the late start time adds the rounding of the reference's own
+    # 2 pi f t (+-1e-10 rad per sample at t = 40 s), which no restatement reproduces term for term
+    assert worst < 2e-12, worst
+
+
+def _bank_run(eng, iq, inits, n, fs, n_ms, first_ms=9):
+    t0 = [orc.chunk_times(ms * n, n, fs)[0] for ms in range(first_ms, n_ms)]
+    bank = eng.create_bank(inits)
+    rec = bank.track_block(iq[first_ms * n:], 1, n_ms - first_ms, t0)
+    state = bank.state()
+    repairs = bank.dll_repairs()
+    bad = np.zeros(len(inits), dtype=np.int32)
+    eng._check(eng.lib.gyp_debug_spec_read(bank.handle, None, 0, _lib.ptr(bad)))
+    bank.close()
+    return rec, state, repairs, bad
+
+
+def _engine_with_env(fs, n, **env):
+    from gypsum_amd.engine import GypsumEngine
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        eng = GypsumEngine(0)            # GYP_* switches are read when the context is created
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    eng.set_stream_format(fs, n)
+    return eng
+
+
+def _scene_and_inits(fs, n, n_ms, n_sats, seed):
+    scene = synth.random_scene(fs, n_ms, n_sats, seed, max_code_phase=(2046 if n > 2046 else None))
+    iq = synth.render(scene)
+    rng = np.random.default_rng(seed ^ 0x5EED)
+    inits = np.zeros(n_sats, dtype=_lib.CHAN_INIT)
+    for i, s in enumerate(scene.sats):
+        inits[i] = (0, s.sat_id, float(int(round(s.doppler_hz)) + int(rng.integers(-2, 3))),
+                    float(np.angle(np.exp(1j * (s.carrier_phase + rng.uniform(-0.2, 0.2))))), s.code_phase, 0)
+    return iq, inits
+
+
+def _oracle_rows(iq, inits, fs, n, n_ms):
+    chips = orc.generate_ca_codes()
+    out = []
+    for rec in inits:
+        trk = orc.Tracker(orc.TrackingState(float(rec["doppler_hz"]), float(rec["carrier_phase"]), int(rec["code_phase"])),
+                          orc.prn_as_complex(chips[int(rec["sat_id"]) - 1], n), fs, n)
+        rows = []
+        for ms in range(9, n_ms):
+            st, en = orc.chunk_times(ms * n, n, fs)
+            r = trk.process_samples(iq[ms * n:(ms + 1) * n], st, en)
+            rows.append((r.code_phase_after, r.peak_offset, r.pseudosymbol, r.discriminator, trk.phase))
+        out.append(rows)
+    return out
+
+
+@pytest.mark.parametrize("fs", [8_184_000, 2_046_000])
+def test_forced_repairs_leave_records_and_state_exact(fs):
+    """A bias of 20 on the PROVISIONAL discriminator (~0.04 samples per ms on the serial kernel's accumulator) makes its
+    int(self.phase) disagree with the exact one every few milliseconds: the scan must repair each of them."""
+    n = fs // 1000
+    n_ms, n_sats = 409, 4
+    iq, inits = _scene_and_inits(fs, n, n_ms, n_sats, 880 + n)
+    ref = _oracle_rows(iq, inits, fs, n, n_ms)
+    eng_t = _engine_with_env(fs, n, GYP_NO_SPEC=1)
+    rec_t, st_t, rep_t, _ = _bank_run(eng_t, iq, inits, n, fs, n_ms)
+    eng_t.close()
+    assert not rep_t.any()                                  # the throughput kernel's loop is exact in line: nothing to repair
+    for label, env in (("unbiased", {}), ("biased", {"GYP_DLL_PROV_BIAS": 20.0})):
+        eng_s = _engine_with_env(fs, n, **env)
+        rec_s, st_s, rep_s, bad = _bank_run(eng_s, iq, inits, n, fs, n_ms)
+        eng_s.close()
+        assert not bad.any()
+        assert np.mean((rec_s["path_info"] & 3) == 1) > 0.5, label        # it really was the speculative path
+        if env:
+            assert rep_s.sum() > 20, rep_s                                # and the repair path really ran
+        for i in range(n_sats):
+            want = ref[i]
+            assert [int(v) for v in rec_s[i]["code_phase"]] == [w[0] for w in want], (label, i)
+            assert [int(v) for v in rec_s[i]["peak_offset"]] == [w[1] for w in want], (label, i)
+            assert [int(v) for v in rec_s[i]["pseudosymbol"]] == [w[2] for w in want], (label, i)
+            np.testing.assert_allclose(rec_s[i]["discriminator"], [w[3] for w in want], rtol=2e-6, atol=1e-6)
+            assert np.array_equal(rec_s[i]["code_phase"], rec_t[i]["code_phase"])
+            assert np.array_equal(rec_s[i]["peak_offset"], rec_t[i]["peak_offset"])
+        assert np.array_equal(st_s["code_phase"], st_t["code_phase"])
+        # the accumulator itself: the state the next block starts from equals the oracle's self.phase to float64 rounding
+        for i in range(n_sats):
+            assert int(st_s["code_phase"][i]) == ref[i][-1][0]
+
+
+def test_block_cuts_do_not_change_the_exact_code_loop(engine_factory):
+    """The exact accumulator travels from call to call in the channel state: one 400-ms block == 7 ragged ones."""
+    fs, n = 8_184_000, 8184
+    eng = engine_factory(fs, n)
+    n_ms = 409
+    iq, inits = _scene_and_inits(fs, n, n_ms, 3, 4242)
+    t0 = [orc.chunk_times(ms * n, n, fs)[0] for ms in range(9, n_ms)]
+    bank = eng.create_bank(inits)
+    whole = bank.track_block(iq[9 * n:], 1, n_ms - 9, t0)
+    bank.close()
+    bank = eng.create_bank(inits)
+    parts, at = [], 0
+    for cut in (1, 37, 64, 3, 120, 100, 75):
+        parts.append(bank.track_block(iq[(9 + at) * n:(9 + at + cut) * n], 1, cut, t0[at:at + cut]))
+        at += cut
+    bank.close()
+    cat = np.concatenate(parts, axis=1)
+    for f in ("code_phase", "peak_offset", "pseudosymbol", "locked", "discriminator", "doppler_hz"):
+        assert np.array_equal(cat[f], whole[f]), f
+
+
+def test_failed_speculation_is_recovered_bit_for_bit():
+    """the recovery chain of the speculative tracker (verify sets bad -> state restored from the checkpoint ->
+    the transform kernel re-runs the block) had never run in a test.  With kappa = 0 every interior window maximum is
+    trusted; on noise-only channels (satellites that are not in the scene) the global arg-max is almost never inside the
+    8-lag window, so verification must fail -- and the re-run must give exactly what the transform kernel gives alone."""
+    fs, n = 8_184_000, 8184
+    n_ms = 209
+    scene = synth.random_scene(fs, n_ms, 4, 9911, max_code_phase=2046)
+    iq = synth.render(scene)
+    present = {s.sat_id for s in scene.sats}
+    absent = [sv for sv in range(1, 33) if sv not in present][:3]
+    inits = np.zeros(len(scene.sats) + len(absent), dtype=_lib.CHAN_INIT)
+    for i, s in enumerate(scene.sats):
+        inits[i] = (0, s.sat_id, float(round(s.doppler_hz)), s.carrier_phase, s.code_phase, 0)
+    for j, sv in enumerate(absent):
+        inits[len(scene.sats) + j] = (0, sv, 1000.0 * (j - 1), 0.5, 100 + 700 * j, 0)
+    eng_t = _engine_with_env(fs, n, GYP_NO_SPEC=1)
+    rec_t, st_t, _, _ = _bank_run(eng_t, iq, inits, n, fs, n_ms)
+    eng_t.close()
+    eng_s = _engine_with_env(fs, n, GYP_SPEC_KAPPA=0)
+    rec_s, st_s, _, bad = _bank_run(eng_s, iq, inits, n, fs, n_ms)
+    eng_s.close()
+    assert bad[len(scene.sats):].all(), bad                  # the noise-only channels failed verification ...
+    for i in np.nonzero(bad)[0]:                             # ... and every channel that did is the transform kernel's, bit for bit
+        assert rec_s[i].tobytes() == rec_t[i].tobytes(), i
+        assert np.all((rec_s[i]["path_info"] & 3) == 0)
+    for key in ("doppler_hz", "carrier_phase", "code_phase", "lost"):
+        assert np.array_equal(st_s[key][bad != 0], st_t[key][bad != 0]), key
+    for i in np.nonzero(bad == 0)[0]:                        # the others stayed on the speculative path and agree on every integer
+        for f in ("code_phase", "peak_offset", "pseudosymbol", "locked"):
+            assert np.array_equal(rec_s[i][f], rec_t[i][f]), (i, f)

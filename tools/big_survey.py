@@ -16,7 +16,7 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     env = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "-" else None
     fs = int(sys.argv[3]) if len(sys.argv) > 3 else ts.FS
-    seed0 = int(sys.argv[4]) if len(sys.argv) > 4 else 500000
+    seed0 = int(sys.argv[4]) if len(sys.argv) > 4 else 800000
     if env:
         os.environ[env] = "1"
     eng = GypsumEngine(0)

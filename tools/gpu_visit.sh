@@ -1,0 +1,49 @@
+#!/bin/bash
+# One GPU visit (through gpurun), steps chosen by name:
+#   gpurun --timeout 1500 -- 'bash tools/gpu_visit.sh <tag> step [step ...]'
+# steps: probe64  quick  tests  bench  benchfast  kt  pmc  surveys  single
+set -u
+TAG=$1; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+cd $R
+for step in "$@"; do
+  t0=$(date +%s)
+  case $step in
+    probe64)
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/valu_rate_probe64.hip -o /tmp/valu_probe64 2>/dev/null && timeout 120 /tmp/valu_probe64 > $O/valu_probe64.txt 2>&1
+      cat $O/valu_probe64.txt ;;
+    quick)
+      timeout 900 python -m pytest tests/test_gpu_dll_exact.py tests/test_gpu_parity.py tests/test_gpu_params.py -x -q -m gpu > $O/pytest_quick.log 2>&1
+      echo "pytest rc=$?" >> $O/pytest_quick.log; tail -25 $O/pytest_quick.log ;;
+    tests)
+      timeout 1500 python -m pytest tests -m gpu -x -q -s > $O/pytest_gpu.log 2>&1
+      echo "pytest rc=$?" >> $O/pytest_gpu.log; grep -v "^$" $O/pytest_gpu.log | tail -40 ;;
+    bench)
+      timeout 900 python bench.py > $O/bench_cfg3.json 2> $O/bench_cfg3.err; echo "bench rc=$?"; head -c 7000 $O/bench_cfg3.json; echo ;;
+    benchfast)
+      timeout 600 python bench.py --no-cpu-baseline --no-extras > $O/bench_fast.json 2> $O/bench_fast.err; echo "benchfast rc=$?"; head -c 4000 $O/bench_fast.json; echo ;;
+    kt)
+      timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_cfg3 -o bench -- python bench.py --no-cpu-baseline --no-extras > $O/kt_cfg3.log 2>&1
+      rm -f $O/kt_cfg3/*/bench_kernel_trace.csv $O/kt_cfg3/*/bench_agent_info.csv
+      head -12 $O/kt_cfg3/*/bench_kernel_stats.csv | cut -c1-200 ;;
+    pmc)
+      B="python bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1"
+      for c in FETCH_SIZE WRITE_SIZE; do
+        timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${c} -o bench -- $B > $O/pmc_${c}.log 2>&1
+      done
+      timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --output-format csv -d $O/pmc_sq1 -o bench -- $B > $O/pmc_sq1.log 2>&1
+      timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES --output-format csv -d $O/pmc_sq2 -o bench -- $B > $O/pmc_sq2.log 2>&1
+      rm -f $O/pmc_*/*/bench_agent_info.csv
+      ls $O ;;
+    surveys)
+      timeout 1500 python tools/big_survey.py ${SURVEY_SCENES:-500} - 8184000 800000 > $O/survey_spec.txt 2>&1; tail -4 $O/survey_spec.txt
+      timeout 1500 python tools/big_survey.py ${SURVEY_SCENES:-500} GYP_NO_SPEC 8184000 900000 > $O/survey_nospec.txt 2>&1; tail -4 $O/survey_nospec.txt ;;
+    single)
+      timeout 600 python tools/single_stream_probe.py > $O/single_stream.txt 2>&1; tail -5 $O/single_stream.txt ;;
+    *) echo "unknown step $step" ;;
+  esac
+  echo "[$step: $(( $(date +%s) - t0 )) s]"
+done

@@ -6,7 +6,7 @@ import sys
 
 txt = open(sys.argv[1]).read()
 want = sys.argv[2:] or ["corr_cells_kernelILi8ELb0E", "track_block_kernelILi8ELb0E", "grid_cells_wave_kernelILi2"]
-for m in re.finditer(r"^(_ZN3gyp\w+):[^\n]*\n(.*?)^\s*s_endpgm", txt, flags=re.S | re.M):
+for m in re.finditer(r"^(_ZN3gyp\w+):[^\n]*\n(.*?)^\.Lfunc_end", txt, flags=re.S | re.M):
     name, body = m.group(1), m.group(2)
     if not any(w in name for w in want):
         continue

@@ -7,7 +7,7 @@ import sys
 txt = open(sys.argv[1]).read()
 name = sys.argv[2]
 which = int(sys.argv[3]) if len(sys.argv) > 3 else -1
-m = re.search(r"^(_ZN3gyp\w*" + name + r"\w*):[^\n]*\n(.*?)^\s*s_endpgm", txt, flags=re.S | re.M)
+m = re.search(r"^(_ZN3gyp\w*" + name + r"\w*):[^\n]*\n(.*?)^\.Lfunc_end", txt, flags=re.S | re.M)
 lines = [l.strip() for l in m.group(2).split("\n") if l.strip() and not l.strip().startswith(";")]
 label_at = {re.match(r"(\.LBB\d+_\d+):", l).group(1): i for i, l in enumerate(lines) if re.match(r"(\.LBB\d+_\d+):", l)}
 loops = []
