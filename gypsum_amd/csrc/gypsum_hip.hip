@@ -581,6 +581,39 @@ static int launch_track_verify(gyp_ctx* ctx, const TrackVerifyParams& p, hipStre
     return GYP_OK;
 }
 
+// tracker.py:297 in float64 for every (channel, millisecond) of [ms_begin, ms_end), then the code loop re-integrated from it
+static int launch_dll_exact(gyp_ctx* ctx, const DllExactParams& p, hipStream_t stream) {
+    const int n_units = p.n_chan * (p.ms_end - p.ms_begin);
+    if (n_units <= 0) return GYP_OK;
+    switch (ctx->k) {
+#define X(K)                                                                                                                   \
+    case K:                                                                                                                    \
+        if constexpr (K <= 8) {                                                                                                \
+            const int grid = std::max(1, std::min((n_units + 3) / 4, ctx->n_cus * 8));                                         \
+            hipLaunchKernelGGL(dll_exact_wave_kernel<(K <= 8 ? K : 8)>, dim3(grid), dim3(256), 0, stream, p);                   \
+        } else {                                                                                                               \
+            const int grid = std::max(1, std::min(n_units, ctx->n_cus * 8));                                                   \
+            hipLaunchKernelGGL(dll_exact_block_kernel<K>, dim3(grid), dim3(256), 0, stream, p);                                 \
+        }                                                                                                                      \
+        break;
+        GYP_FOR_EACH_RATE(X)
+#undef X
+        default: return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return GYP_OK;
+}
+static int launch_dll_scan(gyp_ctx* ctx, const DllScanParams& p, hipStream_t stream) {
+    switch (ctx->k) {
+#define X(K) case K: hipLaunchKernelGGL(dll_scan_kernel<K>, dim3((unsigned)p.n_chan), dim3(kScanThreads), 0, stream, p); break;
+        GYP_FOR_EACH_RATE(X)
+#undef X
+        default: return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return GYP_OK;
+}
+
 extern "C" {
 
 // ---------------------------------------------------------------- correlation cells ----------------------
@@ -1059,25 +1092,14 @@ int gyp_bank_drop_channel(gyp_bank* bank, int32_t index) {
     return GYP_OK;
 }
 
-// Speculative block tracking (8.184 Msps, at most one channel per CU): the tracking kernel advances on window maxima
-// (track_block_kernel MODE 2) in sub-blocks; each sub-block's full profiles are verified by track_verify_kernel on a
-// second stream while the next sub-block is being tracked; channels that failed verification are re-run from the
-// checkpoint by the transform kernel.  Everything is enqueued; nothing synchronises with the host.
-static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
+// Buffers of the exact code loop (hand-over records, float64 discriminators, the loop's state), any tracking path.
+static int ensure_dll_buffers(gyp_bank* bank, size_t n_rec) {
     gyp_ctx* ctx = bank->ctx;
-    const size_t n_rec = (size_t)bank->n_chan * p.n_ms;
-    if (!bank->d_ckpt) {
-        HIP_TRY(ctx, hipMalloc((void**)&bank->d_ckpt, (size_t)bank->n_chan * sizeof(ChanState)));
-        HIP_TRY(ctx, hipMalloc((void**)&bank->d_bad, (size_t)bank->n_chan * sizeof(int32_t)));
-        HIP_TRY(ctx, hipMalloc((void**)&bank->d_dllx, (size_t)bank->n_chan * sizeof(DllExact)));
-        HIP_TRY(ctx, hipStreamCreateWithFlags(&bank->verify_stream, hipStreamNonBlocking));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&bank->ev_spec, hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&bank->ev_verify, hipEventDisableTiming));
-    }
+    if (!bank->d_dllx) HIP_TRY(ctx, hipMalloc((void**)&bank->d_dllx, (size_t)bank->n_chan * sizeof(DllExact)));
     if (bank->spec_cap < n_rec) {
         if (bank->d_spec) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(bank->verify_stream));
+            if (bank->verify_stream) HIP_TRY(ctx, hipStreamSynchronize(bank->verify_stream));
             HIP_TRY(ctx, hipFree(bank->d_spec));
             HIP_TRY(ctx, hipFree(bank->d_disc));
             bank->d_spec = nullptr;
@@ -1088,9 +1110,66 @@ static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
         HIP_TRY(ctx, hipMalloc((void**)&bank->d_disc, n_rec * sizeof(double)));
         bank->spec_cap = n_rec;
     }
+    return GYP_OK;
+}
+static DllExactParams dll_exact_params(gyp_bank* bank, const TrackBlockParams& p) {
+    gyp_ctx* ctx = bank->ctx;
+    DllExactParams x;
+    x.iq = p.iq; x.stream_stride = p.stream_stride; x.n_ms = p.n_ms; x.ms_begin = 0; x.ms_end = p.n_ms; x.start_time = p.start_time;
+    x.states = bank->d_states; x.n_chan = bank->n_chan; x.spec = bank->d_spec; x.disc_out = bank->d_disc; x.chipf = ctx->d_chipf;
+    x.inv_fs = p.inv_fs; x.only_if = nullptr;
+    return x;
+}
+static DllScanParams dll_scan_params(gyp_bank* bank, const TrackBlockParams& p) {
+    gyp_ctx* ctx = bank->ctx;
+    DllScanParams d;
+    d.iq = p.iq; d.stream_stride = p.stream_stride; d.n_ms = p.n_ms; d.ms_begin = 0; d.ms_end = p.n_ms; d.start_time = p.start_time;
+    d.states = bank->d_states; d.ckpt = nullptr; d.n_chan = bank->n_chan; d.spec = bank->d_spec; d.disc = bank->d_disc;
+    d.rec_out = p.rec_out; d.exact = bank->d_dllx; d.bad = nullptr; d.only_bad = 0; d.chipf = ctx->d_chipf;
+    d.inv_fs = p.inv_fs; d.dll_gain = p.lp.dll_gain; d.dll_modulus = p.lp.dll_modulus; d.n_samples = p.lp.n_samples;
+    d.first = 1; d.final = 1;
+    return d;
+}
+
+// The throughput tracking kernel with its code loop re-integrated exactly behind it (same stream).  only_if / restore_from: the
+// re-run of channels whose speculation failed verification.
+static int track_block_throughput(gyp_bank* bank, TrackBlockParams p, const int32_t* only_if, const ChanState* restore_from) {
+    gyp_ctx* ctx = bank->ctx;
+    int rc;
+    if ((rc = ensure_dll_buffers(bank, (size_t)bank->n_chan * p.n_ms))) return rc;
+    p.ms_begin = 0; p.ms_end = p.n_ms;
+    p.spec_out = bank->d_spec; p.exact0 = bank->d_dllx; p.dbg = nullptr;
+    p.only_if = only_if; p.restore_from = restore_from;
+    if ((rc = launch_track_block(ctx, p, 0))) return rc;
+    DllExactParams x = dll_exact_params(bank, p);
+    x.only_if = only_if;
+    if ((rc = launch_dll_exact(ctx, x, ctx->stream))) return rc;
+    DllScanParams d = dll_scan_params(bank, p);
+    d.bad = only_if; d.only_bad = only_if ? 1 : 0;
+    return launch_dll_scan(ctx, d, ctx->stream);
+}
+
+// Speculative block tracking (8.184 / 2.046 Msps, at most one channel per CU): the tracking kernel advances on window maxima
+// (track_block_kernel MODE 2) in sub-blocks; each sub-block's full profiles are verified by track_verify_kernel on a second
+// stream while the next sub-block is being tracked, and its code loop is re-integrated there (dll_exact + dll_scan); channels
+// that failed verification are re-run from the checkpoint by the transform kernel.  Everything is enqueued; nothing
+// synchronises with the host.
+static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
+    gyp_ctx* ctx = bank->ctx;
+    const size_t n_rec = (size_t)bank->n_chan * p.n_ms;
+    int rc;
+    if (!bank->d_ckpt) {
+        HIP_TRY(ctx, hipMalloc((void**)&bank->d_ckpt, (size_t)bank->n_chan * sizeof(ChanState)));
+        HIP_TRY(ctx, hipMalloc((void**)&bank->d_bad, (size_t)bank->n_chan * sizeof(int32_t)));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&bank->verify_stream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&bank->ev_spec, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&bank->ev_verify, hipEventDisableTiming));
+    }
+    if ((rc = ensure_dll_buffers(bank, n_rec))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(bank->d_ckpt, bank->d_states, (size_t)bank->n_chan * sizeof(ChanState), hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(bank->d_bad, 0, (size_t)bank->n_chan * sizeof(int32_t), ctx->stream));
     p.spec_out = bank->d_spec;
+    p.exact0 = nullptr;
     p.spec_kappa = (float)ctx->params.spec_confidence_kappa;
     if (ctx->spec_debug) {
         if (bank->dbg_cap < n_rec * 20) {
@@ -1103,18 +1182,14 @@ static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
     TrackVerifyParams v;
     v.iq = p.iq; v.stream_stride = p.stream_stride; v.n_ms = p.n_ms; v.start_time = p.start_time;
     v.states = bank->d_states; v.n_chan = bank->n_chan; v.spec = bank->d_spec; v.rec_out = p.rec_out; v.bad = bank->d_bad;
-    v.disc_out = bank->d_disc;
-    v.replica_table = ctx->d_replicas; v.tw_tables = ctx->d_tw; v.chipf = ctx->d_chipf; v.inv_fs = p.inv_fs; v.tie_tol = 4e-6f;
-    DllScanParams d;
-    d.iq = p.iq; d.stream_stride = p.stream_stride; d.n_ms = p.n_ms; d.start_time = p.start_time;
-    d.states = bank->d_states; d.ckpt = bank->d_ckpt; d.n_chan = bank->n_chan; d.spec = bank->d_spec; d.disc = bank->d_disc;
-    d.rec_out = p.rec_out; d.exact = bank->d_dllx; d.bad = bank->d_bad; d.chipf = ctx->d_chipf;
-    d.inv_fs = p.inv_fs; d.dll_gain = p.lp.dll_gain; d.dll_modulus = p.lp.dll_modulus; d.n_samples = p.lp.n_samples;
+    v.replica_table = ctx->d_replicas; v.tw_tables = ctx->d_tw; v.inv_fs = p.inv_fs; v.tie_tol = 4e-6f;
+    DllExactParams x = dll_exact_params(bank, p);
+    DllScanParams d = dll_scan_params(bank, p);
+    d.ckpt = bank->d_ckpt; d.bad = bank->d_bad; d.only_bad = 0;
     // the last sub-block's verification trails the tracking (1.9 ms for 2500 ms x 12 channels): more, shorter sub-blocks
     // for long blocks (each launch re-reads the channel state and the tables: ~20 us)
     const int n_sub = p.n_ms >= 4096 ? 16 : (p.n_ms >= 256 ? 4 : 1);
     const int sub = (p.n_ms + n_sub - 1) / n_sub;
-    int rc;
     for (int b0 = 0; b0 < p.n_ms; b0 += sub) {
         p.ms_begin = b0;
         p.ms_end = std::min(p.n_ms, b0 + sub);
@@ -1124,22 +1199,17 @@ static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
         v.ms_begin = p.ms_begin;
         v.ms_end = p.ms_end;
         if ((rc = launch_track_verify(ctx, v, bank->verify_stream))) return rc;
-        // the code loop, re-integrated from the verify pass's float64 discriminators (behind it on the same stream)
+        x.ms_begin = p.ms_begin; x.ms_end = p.ms_end;
+        if ((rc = launch_dll_exact(ctx, x, bank->verify_stream))) return rc;
         d.ms_begin = p.ms_begin; d.ms_end = p.ms_end; d.first = b0 == 0 ? 1 : 0; d.final = p.ms_end == p.n_ms ? 1 : 0;
-        if (ctx->k == 2) hipLaunchKernelGGL(dll_scan_kernel<2>, dim3((unsigned)bank->n_chan), dim3(kScanThreads), 0, bank->verify_stream, d);
-        else hipLaunchKernelGGL(dll_scan_kernel<8>, dim3((unsigned)bank->n_chan), dim3(kScanThreads), 0, bank->verify_stream, d);
-        HIP_TRY(ctx, hipGetLastError());
+        if ((rc = launch_dll_scan(ctx, d, bank->verify_stream))) return rc;
     }
     HIP_TRY(ctx, hipEventRecord(bank->ev_verify, bank->verify_stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, bank->ev_verify, 0));
-    // channels whose window maximum was not the global one (never observed on real signals; any count is handled)
-    p.ms_begin = 0;
-    p.ms_end = p.n_ms;
-    p.spec_out = nullptr;
+    // channels whose window maximum was not the global one (never observed on real signals; any count is handled): the whole
+    // block again from the checkpoint through the transform kernel, their code loop re-integrated behind it
     p.dbg = nullptr;
-    p.only_if = bank->d_bad;
-    p.restore_from = bank->d_ckpt;
-    return launch_track_block(ctx, p, 0);
+    return track_block_throughput(bank, p, bank->d_bad, bank->d_ckpt);
 }
 
 int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stride_samples, int32_t n_ms,
@@ -1178,6 +1248,7 @@ int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stri
                           g.watchdog_period_s, g.watchdog_drop_below, g.watchdog_nudge_below, g.watchdog_nudge_hz, (double)ctx->n};
     }
     p.spec_out = nullptr;
+    p.exact0 = nullptr;
     p.spec_kappa = (float)ctx->params.spec_confidence_kappa;
     p.prov_bias = ctx->dll_prov_bias;
     p.only_if = nullptr;
@@ -1185,7 +1256,7 @@ int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stri
     p.dbg = nullptr;
     const bool light = (ctx->k == 8 || ctx->k == 2) && p.n_chan <= ctx->n_cus && !ctx->no_pipe;   // one workgroup per CU anyway
     if (light && !ctx->no_spec) return track_block_speculative(bank, p);
-    return launch_track_block(ctx, p, 0);
+    return track_block_throughput(bank, p, nullptr, nullptr);
 }
 
 int gyp_track_block(gyp_bank* bank, const float* iq_host, int32_t n_streams, int32_t n_ms, const double* start_time_host,

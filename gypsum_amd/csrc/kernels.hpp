@@ -111,10 +111,9 @@ struct LoopConst {
 struct RedScratch {
     WaveCand cand[16];
     float taps[6];      // early re/im, late re/im, probe re/im (the value at one more lag of the caller's choice)
-    // float64 prompt value and boundary sums of the code loop, per wavefront (ExactOwn / exact_epl_generic), summed by
-    // epl_finish* after its barrier: {P re, im; c0[s] - c0[s-1] re, im; c0[s+1] - c0[s] re, im}
+    // float64 prompt value and boundary sums of the code loop's lag, per wavefront (track_step_kernel: exact_epl_generic), summed
+    // by epl_finish* after its barrier: {P re, im; c0[s] - c0[s-1] re, im; c0[s+1] - c0[s] re, im}
     double expart[8][6];
-    double2 xc[9];      // constants of those sums for the wipe-off in force, see exact_consts: exp(-2 pi i du i), i < K <= 8; chip stride
     double dstate[4];   // new doppler, new carrier phase
     int istate[4];      // new code phase, lost flag
     CarrierSteps steps; // rotation constants of the next millisecond's wipe-off
@@ -182,12 +181,10 @@ __device__ __forceinline__ void transform_staged(const Smem& sm, const cf* __res
 }
 
 // One millisecond block, round rho: stage (all wavefronts) -> barrier -> per-wavefront correlation.
-// Halo-free staging only: `raw(smp, tid)` sees the thread's raw samples between the fetch and the wipe-off (the tracking
-// kernels form the code loop's float64 sums there); it is not called on the other staging paths.
-template <int K, typename Raw>
+template <int K>
 __device__ __forceinline__ void correlate_round(const cf* __restrict__ block, int rho, double u0, double du,
                                                 const CarrierSteps& cs, const Smem& sm,
-                                                const cf* __restrict__ rep_table_sat, cf (&c)[16], Raw&& raw) {
+                                                const cf* __restrict__ rep_table_sat, cf (&c)[16]) {
     constexpr int W = Geom<K>::W;
     const int tid = launder(threadIdx.x);
     if constexpr (kOwnStaging<K>) {
@@ -198,7 +195,6 @@ __device__ __forceinline__ void correlate_round(const cf* __restrict__ block, in
             OwnSamples<K> smp;
             stage_fetch_own<K>(block, smp, tid);
             stage_emit_own<K>(smp, u0, du, cs, y_all, sm.halo, tid);
-            raw(smp, tid);
         }
         transform_staged<K, true>(sm, rep_table_sat, c, tid, rho * W, rho == 0);
     } else {
@@ -209,12 +205,6 @@ __device__ __forceinline__ void correlate_round(const cf* __restrict__ block, in
         else stage_general<K, W>(block, 1, rho, u0, 0.0, du, cs, y_rows, tid);
         transform_staged<K>(sm, rep_table_sat, c, tid);
     }
-}
-template <int K>
-__device__ __forceinline__ void correlate_round(const cf* __restrict__ block, int rho, double u0, double du,
-                                                const CarrierSteps& cs, const Smem& sm,
-                                                const cf* __restrict__ rep_table_sat, cf (&c)[16]) {
-    correlate_round<K>(block, rho, u0, du, cs, sm, rep_table_sat, c, [](const OwnSamples<kOwnStaging<K> ? K : 1>&, int) {});
 }
 
 // Coherent integration of n_blocks millisecond blocks, round rho, with ONE transform (pre-folded inputs).
@@ -1010,23 +1000,6 @@ __device__ __forceinline__ double dll_discriminator_exact(const double (&ex)[6])
     return __dsub_rn(e2, l2) / 2.0;
 }
 
-// Which staging a rate's exact sums ride on: the halo-free staging with the raw samples in registers (K = 2, 8: the
-// rates of the reference's own recordings that the tuned kernels serve) or a pass of its own over the block (every other rate).
-template <int K>
-constexpr bool kExactOwn = (K == 2 || K == 8);
-
-// Constants of ExactOwn for the wipe-off in force, by ONE wavefront (all lanes), into RedScratch::xc:
-//   xc[i] = exp(-2 pi i du i), i < K;   xc[K] = exp(-2 pi i du K T): a thread's chip c -> its chip c+1.
-// A workgroup barrier must separate this from the staging that uses them.
-template <int K>
-__device__ __forceinline__ void exact_consts(RedScratch* red, double du, int lane) {
-    if constexpr (kExactOwn<K>) {
-        constexpr int T = OwnSamples<K>::T;
-        const double2 v = carrier64(du * (double)(lane < K ? lane : K * T));
-        if (lane <= K) red->xc[lane] = v;
-    }
-}
-
 // One wavefront's share of the three sums -> red->expart[wave]; epl_finish* adds the wavefronts up after its barrier.
 __device__ __forceinline__ void exact_publish(double (&acc)[6], RedScratch* red, int tid) {
 #pragma unroll
@@ -1048,87 +1021,9 @@ __device__ __forceinline__ void exact_collect(const RedScratch* red, double (&ex
     }
 }
 
-// ExactOwn: the sums from the raw samples the halo-free staging has just fetched (thread t owns chips m = t + c*T, K
-// samples each, still in registers).  The offset r = s mod K is uniform, so the split of a chip's samples between replica
-// chips j-1 and j is compiled in (one straight-line body per r behind a scalar switch: no per-sample selects).
-// acc * w + x  (complex, x a float32 sample): one Horner step of sum_i x_i w^i
-__device__ __forceinline__ double2 horner64(double2 acc, double2 w, cf x) {
-    return make_double2(fma(acc.x, w.x, fma(-acc.y, w.y, (double)x.x)), fma(acc.x, w.y, fma(acc.y, w.x, (double)x.y)));
-}
-template <int K, int R>
-__device__ __forceinline__ void exact_own_body(const OwnSamples<K>& smp, const RedScratch* red, const float* __restrict__ chipf, int q,
-                                               double u0, double du, int tid, double (&acc)[6]) {
-    constexpr int T = OwnSamples<K>::T, CH = OwnSamples<K>::CH;
-    constexpr int RE = R ? R - 1 : K - 1;   // offset of the early-side boundary sample
-    // Per chip, Horner in rho over the two runs of samples (i >= R meets replica chip j, i < R chip j-1):
-    //   sum_{i>=R} x_i rho^i = rho^R * h,  h = x_R + rho (x_{R+1} + rho (...)),     sum_{i<R} x_i rho^i = g likewise
-    // -- three wave-uniform constants live (rho, rho^R, rho^RE) instead of a table of K powers.  Chips are folded last chip
-    // first with the chip-stride rotation xc[K] (Horner again), and the thread's anchor carrier is applied once at the end.
-    const double2 rho = red->xc[1 < K ? 1 : 0], rho_r = red->xc[R], rho_e = red->xc[RE], step = red->xc[K];
-    double2 sp = make_double2(0.0, 0.0), se = sp, sl = sp;
-#pragma unroll
-    for (int c = CH - 1; c >= 0; --c) {
-        const int m = tid + c * T;
-        int j = m - q;
-        j = j < 0 ? j + kChips : j;               // (m - q) mod 1023
-        const float* cp = chipf + j + kChips;
-        const float z = m < kChips ? 1.f : 0.f;   // the padding chip m == 1023 (its registers hold a copy of chip 1022): no weight
-        const float cm1 = cp[-1] * z, c0 = cp[0] * z, cp1 = cp[1] * z;
-        const double dj = (double)c0, djm1 = (double)cm1, gl = (double)(cm1 - c0), ge = (double)(R ? cm1 - c0 : c0 - cp1);
-        const cf (&x)[K] = smp.w[c];
-        double2 h = make_double2((double)x[K - 1].x, (double)x[K - 1].y);
-#pragma unroll
-        for (int i = K - 2; i >= R; --i) h = horner64(h, rho, x[i]);
-        h = cmul64(h, rho_r);
-        double2 pc = make_double2(dj * h.x, dj * h.y);
-        if (R > 0) {
-            double2 g = make_double2((double)x[R - 1].x, (double)x[R - 1].y);
-#pragma unroll
-            for (int i = R - 2; i >= 0; --i) g = horner64(g, rho, x[i]);
-            pc.x = fma(djm1, g.x, pc.x); pc.y = fma(djm1, g.y, pc.y);
-        }
-        const double2 tl = cmul64(make_double2((double)x[R].x, (double)x[R].y), rho_r);
-        const double2 te = cmul64(make_double2((double)x[RE].x, (double)x[RE].y), rho_e);
-        const double2 lc = make_double2(gl * tl.x, gl * tl.y), ec = make_double2(ge * te.x, ge * te.y);
-        if (c == CH - 1) { sp = pc; se = ec; sl = lc; }
-        else {
-            const double2 a = cmul64(sp, step), b = cmul64(se, step), d = cmul64(sl, step);
-            sp = make_double2(a.x + pc.x, a.y + pc.y);
-            se = make_double2(b.x + ec.x, b.y + ec.y);
-            sl = make_double2(d.x + lc.x, d.y + lc.y);
-        }
-    }
-    const double2 anchor = carrier64(u0 + du * (double)(K * tid));
-    const double2 p = cmul64(sp, anchor), e = cmul64(se, anchor), l = cmul64(sl, anchor);
-    acc[0] = p.x; acc[1] = p.y; acc[2] = e.x; acc[3] = e.y; acc[4] = l.x; acc[5] = l.y;
-}
-template <int K>
-__device__ __forceinline__ void exact_own(const OwnSamples<K>& smp, RedScratch* red, const float* __restrict__ chipf, int sN, double u0, double du,
-                                          int tid) {
-    static_assert(kExactOwn<K>, "rates whose tuned kernels keep the raw samples in registers");
-    const int q = __builtin_amdgcn_readfirstlane(sN / K), r = __builtin_amdgcn_readfirstlane(sN % K);
-    double acc[6];
-    if constexpr (K == 2) {
-        if (r == 0) exact_own_body<K, 0>(smp, red, chipf, q, u0, du, tid, acc);
-        else exact_own_body<K, 1>(smp, red, chipf, q, u0, du, tid, acc);
-    } else {
-        switch (r) {   // scalar
-            case 0: exact_own_body<K, 0>(smp, red, chipf, q, u0, du, tid, acc); break;
-            case 1: exact_own_body<K, 1>(smp, red, chipf, q, u0, du, tid, acc); break;
-            case 2: exact_own_body<K, 2>(smp, red, chipf, q, u0, du, tid, acc); break;
-            case 3: exact_own_body<K, 3>(smp, red, chipf, q, u0, du, tid, acc); break;
-            case 4: exact_own_body<K, 4>(smp, red, chipf, q, u0, du, tid, acc); break;
-            case 5: exact_own_body<K, 5>(smp, red, chipf, q, u0, du, tid, acc); break;
-            case 6: exact_own_body<K, 6>(smp, red, chipf, q, u0, du, tid, acc); break;
-            default: exact_own_body<K, 7>(smp, red, chipf, q, u0, du, tid, acc); break;
-        }
-    }
-    exact_publish(acc, red, tid);
-}
-
-// The same three sums for any rate and any workgroup size, straight from the block in memory: thread t walks samples
-// [t*L, (t+1)*L) with a float64 carrier recurrence (anchor per thread, one rotation per sample).  Used by the rates without
-// ExactOwn and by dll_scan_kernel's repair steps.  acc: this thread's partial sums.
+// The three sums for any rate and any workgroup size, straight from the block in memory: thread t walks samples
+// [t*L, (t+1)*L) with a float64 carrier recurrence (anchor per thread, one rotation per sample).  Used by track_step_kernel, by
+// dll_exact_block_kernel (rates above 8 samples per chip) and by dll_scan_kernel's repair steps.  acc: this thread's partial sums.
 template <int K, int T>
 __device__ __forceinline__ void exact_epl_generic(const cf* __restrict__ block, double u0, double du, int sN, const float* __restrict__ chipf,
                                                   int tid, double (&acc)[6]) {
@@ -1248,7 +1143,7 @@ __device__ __forceinline__ void epl_round_wave(const cf (&c)[16], int s, int pro
         red->cand[wave] = wc;
     }
 }
-template <int K>
+template <int K, bool WANT_EX = false>
 __device__ __forceinline__ EplResult epl_finish_wave(RedScratch* red) {
     constexpr int W = Geom<K>::W;
     __syncthreads();   // candidates and taps published
@@ -1267,7 +1162,7 @@ __device__ __forceinline__ EplResult epl_finish_wave(RedScratch* red) {
     r.early = make_float2(red->taps[0], red->taps[1]);
     r.late = make_float2(red->taps[2], red->taps[3]);
     r.probe = make_float2(red->taps[4], red->taps[5]);
-    exact_collect<Geom<K>::W>(red, r.ex);
+    if constexpr (WANT_EX) exact_collect<Geom<K>::W>(red, r.ex);
     r.peak = make_float2(g.re, g.im);
     r.best = Best{__builtin_amdgcn_sqrtf(g.v), g.key};
     r.sum = sum;
@@ -1275,14 +1170,14 @@ __device__ __forceinline__ EplResult epl_finish_wave(RedScratch* red) {
     return r;
 }
 
-template <int K>
+template <int K, bool WANT_EX = false>
 __device__ __forceinline__ EplResult epl_finish(const LaneStats& ls, RedScratch* red, int tid) {
     const ProfileStats st = lane_stats_finish<K, true>(ls, red, tid);   // its barrier also publishes the taps
     EplResult r;
     r.early = make_float2(red->taps[0], red->taps[1]);
     r.late = make_float2(red->taps[2], red->taps[3]);
     r.probe = make_float2(red->taps[4], red->taps[5]);
-    exact_collect<Geom<K>::W>(red, r.ex);
+    if constexpr (WANT_EX) exact_collect<Geom<K>::W>(red, r.ex);
     r.peak = st.peak;
     r.best = st.best;
     r.sum = st.sum;
@@ -1292,26 +1187,16 @@ __device__ __forceinline__ EplResult epl_finish(const LaneStats& ls, RedScratch*
 
 // One tracking millisecond of one channel: all rounds, then the reductions.
 // `probe`: one more lag (0 <= probe < N) whose complex value is returned in EplResult::probe.
-// WANT_EX: also form the code loop's float64 sums (EplResult::ex): from the raw samples of the halo-free staging where
-// kExactOwn (RedScratch::xc must hold exact_consts of this du -- PREP_CONSTS forms them here, at the price of a barrier; the
-// persistent block kernel keeps them current in its loop update), by a pass of their own over the block otherwise.
-template <int K, bool WANT_EX = false, bool PREP_CONSTS = true>
+// WANT_EX (gyp_track_step): also the code loop's three lags in float64 (EplResult::ex), by a pass of the workgroup over the
+// block (exact_epl_generic).  The block kernels do not ask for it: their code loop is re-integrated from dll_exact_*_kernel.
+template <int K, bool WANT_EX = false>
 __device__ __forceinline__ EplResult track_ms(const cf* __restrict__ block, double u0, double du, const CarrierSteps& cs,
                                               int code_phase, int probe, const Smem& sm, const cf* __restrict__ rep, float* profile_row,
                                               const float* chipf = nullptr) {
     constexpr int N = K * kChips;
     const int s = mod_n(code_phase, N);
-    if constexpr (WANT_EX && kExactOwn<K> && kOwnStaging<K>) {
-        if constexpr (PREP_CONSTS) {
-            if ((threadIdx.x >> 6) == 0) exact_consts<K>(sm.red, du, threadIdx.x & 63);
-            __syncthreads();
-        }
-    }
-    auto raw_hook = [&](const OwnSamples<kOwnStaging<K> ? K : 1>& smp, int tid) {
-        if constexpr (WANT_EX && kExactOwn<K> && kOwnStaging<K>) exact_own<K>(smp, sm.red, chipf, s, u0, du, tid);
-    };
-    auto generic_ex = [&]() {   // rates without ExactOwn: the workgroup walks the block once more (L1/L2-resident by now)
-        if constexpr (WANT_EX && !(kExactOwn<K> && kOwnStaging<K>)) {
+    auto generic_ex = [&]() {
+        if constexpr (WANT_EX) {
             double acc[6];
             const int tid = launder(threadIdx.x);
             exact_epl_generic<K, Geom<K>::kThreads>(block, u0, du, s, chipf, tid, acc);
@@ -1320,10 +1205,10 @@ __device__ __forceinline__ EplResult track_ms(const cf* __restrict__ block, doub
     };
     if constexpr (Geom<K>::R == 1) {
         cf c[16];
-        correlate_round<K>(block, 0, u0, du, cs, sm, rep, c, raw_hook);
+        correlate_round<K>(block, 0, u0, du, cs, sm, rep, c);
         epl_round_wave<K>(c, s, probe, sm.red, profile_row, launder(threadIdx.x));
         generic_ex();
-        return epl_finish_wave<K>(sm.red);
+        return epl_finish_wave<K, WANT_EX>(sm.red);
     }
     LaneStats ls = lane_stats_init();
     if constexpr (kOwnStaging<K>) {
@@ -1332,11 +1217,11 @@ __device__ __forceinline__ EplResult track_ms(const cf* __restrict__ block, doub
 #pragma unroll 1
         for (int rho = 0; rho < Geom<K>::R; ++rho) {
             cf c[16];
-            correlate_round<K>(block, rho, u0, du, cs, sm, rep, c, raw_hook);
+            correlate_round<K>(block, rho, u0, du, cs, sm, rep, c);
             epl_round<K>(c, rho, s, probe, ls, sm.red, profile_row, launder(threadIdx.x));
         }
         generic_ex();
-        return epl_finish<K>(ls, sm.red, launder(threadIdx.x));
+        return epl_finish<K, WANT_EX>(ls, sm.red, launder(threadIdx.x));
     }
 #pragma unroll 1
     for (int rho = 0; rho < Geom<K>::R; ++rho) {
@@ -1346,7 +1231,7 @@ __device__ __forceinline__ EplResult track_ms(const cf* __restrict__ block, doub
         if (Geom<K>::R > 1) __syncthreads();   // tiles are re-staged by the next round
     }
     generic_ex();
-    return epl_finish<K>(ls, sm.red, launder(threadIdx.x));
+    return epl_finish<K, WANT_EX>(ls, sm.red, launder(threadIdx.x));
 }
 
 template <int K>
@@ -1564,6 +1449,12 @@ struct SpecIn {
                                      // -2: the channel was lost, the millisecond was not processed
 };
 constexpr int kSpecKeyTransform = -1, kSpecKeyLost = -2;
+// The exactly integrated code loop of a channel (dll_scan_kernel), between sub-blocks of a call.
+struct DllExact {
+    double dll;            // self.phase
+    int32_t code_phase;    // current_prn_code_phase_shift
+    int32_t repairs;       // repair steps so far in this call (telemetry)
+};
 
 struct TrackBlockParams {
     const cf* iq;
@@ -1585,6 +1476,7 @@ struct TrackBlockParams {
     SpecIn* spec_out;          // [n_chan][n_ms]
     float spec_kappa;          // window peak^2 must reach spec_kappa * (energy of the millisecond's samples)
     double prov_bias;          // test hook: added to the provisional discriminator (see dll_scan_kernel)
+    DllExact* exact0;          // throughput path: the code loop's state before this launch is left here for dll_scan_kernel
     // re-run mode: only channels with only_if[ch] != 0 run, after restoring their state from restore_from[ch]
     const int32_t* only_if;
     const ChanState* restore_from;
@@ -1748,7 +1640,6 @@ __device__ __forceinline__ void costas_update(const LoopConst& kc, ChanState* st
             }
         }
     }
-    exact_consts<K>(red, nf * kc.inv_fs, lane);   // (all lanes) the code loop's float64 constants for the next wipe-off
     if (lane == 0) {
         red->loop.last_watchdog = last_watchdog; red->loop.n_steps = n + 1; red->loop.sums = sums;
         red->loop.pos_e = pos_e; red->loop.pos_p = pos_p; red->loop.pos_refresh = pos_refresh;
@@ -2213,8 +2104,11 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
         sm.red->defer = 0;
         if (SPEC && p.ms_begin < p.ms_end) sm.red->t0_next = p.start_time[p.ms_begin];
     }
-    if (!SPEC && wave == 0) exact_consts<K>(sm.red, st->doppler * p.inv_fs, lane);   // as costas_update leaves them
     __syncthreads();
+    if (p.exact0 && threadIdx.x == 0) {
+        DllExact x; x.dll = st->dll_phase; x.code_phase = st->code_phase; x.repairs = 0;
+        p.exact0[ch] = x;
+    }
     const bool prof = PROF && p.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
     long long tp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long t_last = 0;
@@ -2253,7 +2147,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
                     z.carrier_phase = SPEC ? sm.red->cc[sm.red->cand_sel].nphi : sm.red->dstate[1];
                     *rec = z;
                 }
-                if (SPEC) p.spec_out[(int64_t)ch * p.n_ms + ms].key = kSpecKeyLost;
+                if (p.spec_out) p.spec_out[(int64_t)ch * p.n_ms + ms].key = kSpecKeyLost;
             }
             continue;
         }
@@ -2273,7 +2167,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
             pscale = cand.pscale;
         } else {
             f = sm.red->dstate[0]; phi = sm.red->dstate[1]; cs = sm.red->steps;
-            pscale = 1.0;
+            pscale = 1.0;   // (unused here)
         }
         {
             const int code_phase = sm.red->istate[0];
@@ -2388,13 +2282,22 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
                     sm.red->istate[2] = next_centre;
                 }
             } else {
-                const EplResult r = track_ms<K, true, false>(block, u0, du, cs, code_phase, mod_n(code_phase, N), sm, rep, nullptr,
-                                                             p.codes.chipf + sat_index * 2048);
+                // the hand-over record of the exact code loop (dll_exact_*_kernel / dll_scan_kernel): what this millisecond ran with
+                if (p.spec_out && threadIdx.x == 0) {
+                    SpecIn si;
+                    si.doppler = f; si.carrier_phase = phi; si.code_phase = code_phase; si.key = kSpecKeyTransform;
+                    p.spec_out[(int64_t)ch * p.n_ms + ms] = si;
+                }
+                const EplResult r = track_ms<K>(block, u0, du, cs, code_phase, mod_n(code_phase, N), sm, rep, nullptr);
                 if (prof) t_b = (long long)__builtin_readcyclecounter();
                 m.peak = r.peak; m.peak_mag = r.best.v; m.key = r.best.key; m.sum = r.sum; m.n_max = r.n_max;
                 m.strength_pending = false;
                 m.path_info = 0;
-                m.disc = dll_discriminator_exact(r.ex);   // float64 end to end: int(self.phase) follows tracker.py:297-301
+                // PROVISIONAL discriminator from the transform's float32 taps at s -+ 1 (tracker.py:297): it only has to keep
+                // int(self.phase) right for all but about one millisecond in a million -- the loop is re-integrated from
+                // float64 sums afterwards and those milliseconds repaired (dll_scan_kernel)
+                m.disc = (((double)r.early.x * (double)r.early.x + (double)r.early.y * (double)r.early.y) -
+                          ((double)r.late.x * (double)r.late.x + (double)r.late.y * (double)r.late.y)) / 2.0 + p.prov_bias;
                 if (prof) t_c = (long long)__builtin_readcyclecounter();
             }
         }
@@ -2463,10 +2366,8 @@ struct TrackVerifyParams {
     const SpecIn* spec;
     gyp_track_rec* rec_out;
     int32_t* bad;
-    double* disc_out;          // [n_chan][n_ms]: tracker.py:297 in float64 at the lag the tracking kernel used (dll_scan_kernel's input)
     const cf* replica_table;
     const cf* tw_tables;
-    const float* chipf;        // CodeTables::chipf
     double inv_fs;
     float tie_tol;
 };
@@ -2482,61 +2383,204 @@ __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void 
         const int u = xcd_contiguous(v, n_units);
         const int ms = p.ms_begin + u / p.n_chan, ch = u % p.n_chan;   // the channels of a millisecond are neighbours: shared IQ
         const SpecIn in = p.spec[(int64_t)ch * p.n_ms + ms];
-        if (in.key == kSpecKeyLost) continue;                     // uniform
+        if (in.key < 0) continue;                                 // uniform: transform path in the tracking kernel, or not processed
         const ChanState* st = p.states + ch;
         const cf* rep = replica_of(p.replica_table, st->sat_id - 1);
         const cf* block = p.iq + (int64_t)st->stream * p.stream_stride + (int64_t)ms * N;
         const double du = in.doppler * p.inv_fs;
         const double u0 = in.doppler * p.start_time[ms] + in.carrier_phase * 0.15915494309189533577;
-        const int sN = mod_n(in.code_phase, N);
-        int probe = sN + (in.key >= 0 ? in.key : 0);
+        int probe = mod_n(in.code_phase, N) + in.key;
         probe = probe >= N ? probe - N : probe;
-        const EplResult r = track_ms<K, true>(block, u0, du, carrier_steps<K>(du), in.code_phase, probe, sm, rep, nullptr,
-                                              p.chipf + (st->sat_id - 1) * 2048);
+        const EplResult r = track_ms<K>(block, u0, du, carrier_steps<K>(du), in.code_phase, probe, sm, rep, nullptr);
         if (threadIdx.x == 0) {
-            p.disc_out[(int64_t)ch * p.n_ms + ms] = dll_discriminator_exact(r.ex);
-            if (in.key >= 0) {   // a millisecond that advanced on its window maximum
-                if (r.best.key != in.key) {
-                    const float vp = fmaf(r.probe.x, r.probe.x, r.probe.y * r.probe.y), vm = r.best.v * r.best.v;
-                    if (!(vp >= vm * (1.0f - p.tie_tol))) p.bad[ch] = 1;
-                }
-                if (p.rec_out) {
-                    const float mean_excl = (float)((r.sum - (double)r.n_max * (double)r.best.v) / (double)(N - r.n_max));
-                    p.rec_out[(int64_t)ch * p.n_ms + ms].strength = r.best.v / mean_excl;
-                }
+            if (r.best.key != in.key) {
+                const float vp = fmaf(r.probe.x, r.probe.x, r.probe.y * r.probe.y), vm = r.best.v * r.best.v;
+                if (!(vp >= vm * (1.0f - p.tie_tol))) p.bad[ch] = 1;
+            }
+            if (p.rec_out) {
+                const float mean_excl = (float)((r.sum - (double)r.n_max * (double)r.best.v) / (double)(N - r.n_max));
+                p.rec_out[(int64_t)ch * p.n_ms + ms].strength = r.best.v / mean_excl;
             }
         }
         __syncthreads();
     }
 }
 
-// The code loop of the speculative path, re-integrated exactly.  track_block_kernel MODE 2 advances its code phase on a
-// PROVISIONAL discriminator (float32 prompt value); the code loop is a side chain (nothing else of the tracker reads it), so
-// its exact trajectory can be formed afterwards: track_verify_kernel has evaluated tracker.py:297 in float64 for every
-// millisecond at the lag the tracking kernel used, and this kernel -- one workgroup per channel, the milliseconds in order --
-// integrates tracker.py:298-303 from those values.  Where its int(self.phase) differs from the provisional one (the two
-// accumulators straddle an integer: about once per 1e6 channel-ms, for a few milliseconds each time) the millisecond's sums
-// are formed on the spot for the right lag (exact_epl_generic over the block: a "repair" step) and the record's
-// code phase / peak offset are corrected.  The exact state travels from sub-block to sub-block in DllExact and is written
-// back into the channel state by the last one, so the next call starts from it.
-struct DllExact {
-    double dll;            // self.phase
-    int32_t code_phase;    // current_prn_code_phase_shift
-    int32_t repairs;       // repair steps so far in this call (telemetry)
+// ---------------------------------------------------------------------------------------------------------
+// The code loop, exactly.  Both block tracking kernels advance their code phase on a PROVISIONAL discriminator (float32
+// taps).  The code loop is a side chain -- nothing else of the tracker reads it -- so its exact trajectory is formed
+// afterwards from the hand-over records (SpecIn: the Doppler, carrier phase and code phase each millisecond ran with):
+//   dll_exact_wave_kernel / dll_exact_block_kernel   tracker.py:297 in float64 for every (channel, millisecond) at the lag the
+//                       tracking kernel used: raw float32 samples x float64 carrier, float64 sums; all of them in parallel;
+//   dll_scan_kernel     one workgroup per channel, the milliseconds in order: tracker.py:298-303 from those values.  Where
+//                       its int(self.phase) differs from the provisional one (the two accumulators straddle an integer: about
+//                       once per 1e6 channel-ms, for a few milliseconds each time) the millisecond's sums are formed on the
+//                       spot for the right lag (a "repair" step) and the record's code phase / peak offset corrected.
+// The exact state travels in DllExact from sub-block to sub-block and is written back into the channel state by the last scan
+// of a call, so the next call -- and its provisional loop -- starts from it.
+// ---------------------------------------------------------------------------------------------------------
+struct DllExactParams {
+    const cf* iq;
+    int64_t stream_stride;
+    int32_t n_ms, ms_begin, ms_end;
+    const double* start_time;
+    const ChanState* states;
+    int32_t n_chan;
+    const SpecIn* spec;
+    double* disc_out;          // [n_chan][n_ms]
+    const float* chipf;        // CodeTables::chipf
+    double inv_fs;
+    const int32_t* only_if;    // optional: only channels with only_if[ch] != 0 (the re-run of failed speculations)
 };
+
+// acc * w + x  (complex, x a float32 sample): one Horner step of sum_i x_i w^i
+__device__ __forceinline__ double2 horner64(double2 acc, double2 w, cf x) {
+    return make_double2(fma(acc.x, w.x, fma(-acc.y, w.y, (double)x.x)), fma(acc.x, w.y, fma(acc.y, w.x, (double)x.y)));
+}
+// One chip's share of {P, d_e, d_l} before the chip's anchor carrier (see the derivation above exact_epl_generic): Horner in
+// rho = exp(-2 pi i du) over the two runs of samples, i >= R meeting replica chip j and i < R chip j-1.  R = s mod K is uniform
+// and compiled in (one body per value behind a scalar switch: the samples sit in registers).
+template <int K, int R>
+__device__ __forceinline__ void exact_chip(const cf (&x)[K], double2 rho, double2 rho_r, double2 rho_e, float cm1, float c0, float cp1,
+                                           double2& pc, double2& ec, double2& lc) {
+    constexpr int RE = R ? R - 1 : K - 1;   // offset of the early-side boundary sample
+    const double dj = (double)c0, djm1 = (double)cm1, gl = (double)(cm1 - c0), ge = (double)(R ? cm1 - c0 : c0 - cp1);
+    double2 h = make_double2((double)x[K - 1].x, (double)x[K - 1].y);
+#pragma unroll
+    for (int i = K - 2; i >= R; --i) h = horner64(h, rho, x[i]);
+    h = cmul64(h, rho_r);
+    pc = make_double2(dj * h.x, dj * h.y);
+    if (R > 0) {
+        double2 g = make_double2((double)x[R - 1].x, (double)x[R - 1].y);
+#pragma unroll
+        for (int i = R - 2; i >= 0; --i) g = horner64(g, rho, x[i]);
+        pc.x = fma(djm1, g.x, pc.x); pc.y = fma(djm1, g.y, pc.y);
+    }
+    const double2 tl = cmul64(make_double2((double)x[R].x, (double)x[R].y), rho_r);
+    const double2 te = cmul64(make_double2((double)x[RE].x, (double)x[RE].y), rho_e);
+    lc = make_double2(gl * tl.x, gl * tl.y);
+    ec = make_double2(ge * te.x, ge * te.y);
+}
+// One wavefront per (channel, millisecond): lane l owns chips m = l + 64 c (c < 16; consecutive lanes read consecutive
+// 8K-byte chunks: coalesced), folds them last chip first with the chip-stride rotation (Horner again) and applies its anchor
+// carrier once; six DPP reductions finish the unit.  No LDS, no barrier.
+template <int K, int R>
+__device__ __forceinline__ void exact_wave_unit(const cf* __restrict__ block, double u0, double du, int q, const float* __restrict__ chipf,
+                                                int lane, double (&acc)[6]) {
+    constexpr int CH = 16;
+    const double2 rho = carrier64(du), rho_r = carrier64(du * (double)R), rho_e = carrier64(du * (double)(R ? R - 1 : K - 1));
+    const double2 step = carrier64(du * (double)(K * 64));
+    double2 sp = make_double2(0.0, 0.0), se = sp, sl = sp;
+#pragma unroll 2
+    for (int c = CH - 1; c >= 0; --c) {
+        const int m = lane + 64 * c;
+        const bool on = m < kChips;                 // chip 1023 does not exist (lane 63's last)
+        cf x[K];
+        load_samples<K>(block + K * (on ? m : 0), x);
+        int j = m - q;
+        j = j < 0 ? j + kChips : j;                 // (m - q) mod 1023
+        const float* cp = chipf + j + kChips;
+        const float z = on ? 1.f : 0.f;
+        double2 pc, ec, lc;
+        exact_chip<K, R>(x, rho, rho_r, rho_e, cp[-1] * z, cp[0] * z, cp[1] * z, pc, ec, lc);
+        const double2 a = cmul64(sp, step), b = cmul64(se, step), d = cmul64(sl, step);
+        sp = make_double2(a.x + pc.x, a.y + pc.y);
+        se = make_double2(b.x + ec.x, b.y + ec.y);
+        sl = make_double2(d.x + lc.x, d.y + lc.y);
+    }
+    const double2 anchor = carrier64(u0 + du * (double)(K * lane));
+    const double2 p = cmul64(sp, anchor), e = cmul64(se, anchor), l = cmul64(sl, anchor);
+    acc[0] = p.x; acc[1] = p.y; acc[2] = e.x; acc[3] = e.y; acc[4] = l.x; acc[5] = l.y;
+}
+template <int K>
+__global__ __launch_bounds__(256) void dll_exact_wave_kernel(DllExactParams p) {
+    static_assert(K <= 8, "a chip's samples in registers");
+    constexpr int N = K * kChips;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n_units = p.n_chan * (p.ms_end - p.ms_begin);
+    const int n_groups = (n_units + 3) >> 2;
+    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        // four consecutive units per workgroup, consecutive groups inside an XCD's slice: the channels of a stream-ms (shared IQ) meet in one L2
+        const int u = ((n_groups & 7) ? g : xcd_contiguous(g, n_groups)) * 4 + wave;
+        if (u >= n_units) continue;
+        const int ms = p.ms_begin + u / p.n_chan, ch = u % p.n_chan;
+        if (p.only_if && !p.only_if[ch]) continue;                // wave-uniform
+        const int64_t at = (int64_t)ch * p.n_ms + ms;
+        const SpecIn in = p.spec[at];
+        if (in.key == kSpecKeyLost) continue;                     // wave-uniform
+        const ChanState* st = p.states + ch;
+        const int sat = __builtin_amdgcn_readfirstlane(st->sat_id), stream = __builtin_amdgcn_readfirstlane(st->stream);
+        const cf* block = p.iq + (int64_t)stream * p.stream_stride + (int64_t)ms * N;
+        const float* chipf = p.chipf + (sat - 1) * 2048;
+        const double du = in.doppler * p.inv_fs;
+        const double u0 = in.doppler * p.start_time[ms] + in.carrier_phase * 0.15915494309189533577;
+        const int sN = __builtin_amdgcn_readfirstlane(mod_n(in.code_phase, N));
+        const int q = sN / K, r = sN % K;
+        double acc[6];
+        switch (r) {   // scalar
+            case 0: exact_wave_unit<K, 0>(block, u0, du, q, chipf, lane, acc); break;
+#define GYP_CASE(RR) case RR: if constexpr (RR < K) exact_wave_unit<K, (RR < K ? RR : 0)>(block, u0, du, q, chipf, lane, acc); break;
+            GYP_CASE(1) GYP_CASE(2) GYP_CASE(3) GYP_CASE(4) GYP_CASE(5) GYP_CASE(6) GYP_CASE(7)
+#undef GYP_CASE
+            default: break;
+        }
+#pragma unroll
+        for (int v = 0; v < 6; ++v) acc[v] = wave_sum_last(acc[v]);
+        if (lane == 63) p.disc_out[at] = dll_discriminator_exact(acc);
+    }
+}
+// Rates above 8 samples per chip (16.368 ... 49.104 Msps): one 256-thread workgroup per unit walks the block (exact_epl_generic).
+template <int K>
+__global__ __launch_bounds__(256) void dll_exact_block_kernel(DllExactParams p) {
+    constexpr int N = K * kChips;
+    __shared__ double part[4][6];
+    const int tid = threadIdx.x;
+    const int n_units = p.n_chan * (p.ms_end - p.ms_begin);
+    for (int v = blockIdx.x; v < n_units; v += gridDim.x) {
+        const int u = (n_units & 7) ? v : xcd_contiguous(v, n_units);
+        const int ms = p.ms_begin + u / p.n_chan, ch = u % p.n_chan;
+        if (p.only_if && !p.only_if[ch]) continue;                // uniform
+        const int64_t at = (int64_t)ch * p.n_ms + ms;
+        const SpecIn in = p.spec[at];
+        if (in.key == kSpecKeyLost) continue;                     // uniform
+        const ChanState* st = p.states + ch;
+        const cf* block = p.iq + (int64_t)st->stream * p.stream_stride + (int64_t)ms * N;
+        const double du = in.doppler * p.inv_fs;
+        const double u0 = in.doppler * p.start_time[ms] + in.carrier_phase * 0.15915494309189533577;
+        double acc[6];
+        exact_epl_generic<K, 256>(block, u0, du, mod_n(in.code_phase, N), p.chipf + (st->sat_id - 1) * 2048, tid, acc);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] = wave_sum_last(acc[k]);
+        __syncthreads();                       // the previous unit's reader is done with `part`
+        if ((tid & 63) == 63) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) part[tid >> 6][k] = acc[k];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double ex[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ex[k] = (part[0][k] + part[1][k]) + (part[2][k] + part[3][k]);
+            p.disc_out[at] = dll_discriminator_exact(ex);
+        }
+    }
+}
+
 struct DllScanParams {
     const cf* iq;
     int64_t stream_stride;
     int32_t n_ms, ms_begin, ms_end;
     const double* start_time;
     ChanState* states;
-    const ChanState* ckpt;     // the states before the call
+    const ChanState* ckpt;     // the states before the call, or null: the tracking kernel left them in `exact` (throughput path)
     int32_t n_chan;
     const SpecIn* spec;
     const double* disc;
     gyp_track_rec* rec_out;
     DllExact* exact;
-    const int32_t* bad;
+    const int32_t* bad;        // optional per-channel flags of failed speculations ...
+    int32_t only_bad;          // ... 0: flagged channels are left alone (the re-run gives them everything); 1: ONLY flagged ones (after it)
     const float* chipf;
     double inv_fs, dll_gain, dll_modulus, n_samples;
     int32_t first, final;
@@ -2547,12 +2591,13 @@ __global__ __launch_bounds__(kScanThreads) void dll_scan_kernel(DllScanParams p)
     constexpr int N = K * kChips;
     __shared__ double part[kScanThreads / 64][6];
     const int ch = blockIdx.x, tid = threadIdx.x;
-    if (ch >= p.n_chan || p.bad[ch]) return;   // (a channel sent back through the transform kernel gets everything from there)
+    if (ch >= p.n_chan) return;
+    if (p.bad && (p.bad[ch] != 0) != (p.only_bad != 0)) return;
     const ChanState* st = p.states + ch;
     double a;
     int s, repairs;
-    if (p.first) { a = p.ckpt[ch].dll_phase; s = p.ckpt[ch].code_phase; repairs = 0; }
-    else { const DllExact x = p.exact[ch]; a = x.dll; s = x.code_phase; repairs = x.repairs; }
+    if (p.first && p.ckpt) { a = p.ckpt[ch].dll_phase; s = p.ckpt[ch].code_phase; repairs = 0; }
+    else { const DllExact x = p.exact[ch]; a = x.dll; s = x.code_phase; repairs = p.first ? 0 : x.repairs; }
     const float* chipf = p.chipf + (st->sat_id - 1) * 2048;
     const cf* stream = p.iq + (int64_t)st->stream * p.stream_stride;
     // (the hand-over records do not depend on the chain: the next millisecond's are requested one iteration early, so the
