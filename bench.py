@@ -392,6 +392,7 @@ def run_cfg3(eng, comm, args, rng) -> dict:
     eng.set_params(acq_reuse_level_records=1.0)
     sym_ok = None
     state = su.bank.state()
+    repairs = su.bank.dll_repairs()     # of the last tracking call (HIP-event loop above): the exact code loop's repair steps
     if su.rec_dev is not None:
         sym_ok = su.symbol_agreement(su.records())
     f_trk = C_ * (2 * fft_flops(n) + 18 * n)                          # SURVEY 8(d5), per stream-ms
@@ -412,6 +413,8 @@ def run_cfg3(eng, comm, args, rng) -> dict:
                   "acquire_ms_per_step_without_level_record_reuse": round(acq_noreuse_ms, 3),
                   "level_record_reuse_gives_identical_results": same,
                   "acquisition_seed_hits": f"{su.acq_ok}/{B * C_}", "channels_lost": int(state["lost"].sum()),
+                  "dll_repair_steps": {"total": int(repairs.sum()), "channels_with_any": int((repairs > 0).sum()),
+                                       "max_in_one_channel": int(repairs.max()), "channel_ms": B * C_ * T},
                   "symbol_agreement_ok_fraction": sym_ok,
                   "symbol_agreement_note": "fraction of sampled channels whose last 200 pseudosymbols match the generated "
                                            "navigation bits > 95 %; the float64 oracle's own fraction on equivalent scenes is "

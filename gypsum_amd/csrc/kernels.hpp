@@ -1000,6 +1000,13 @@ __device__ __forceinline__ double dll_discriminator_exact(const double (&ex)[6])
     return __dsub_rn(e2, l2) / 2.0;
 }
 
+// Carrier cycles at a chunk's first sample, f t0 + phi / 2 pi, reduced to a few cycles WITHOUT losing the fraction of f t0: the
+// product is ~2e5 cycles after 40 s and its rounding (3e-11 cycles) would turn every sum of the millisecond by 2e-10 rad.
+__device__ __forceinline__ double carrier_cycles(double f, double t0, double phi) {
+    const double prod = f * t0, err = fma(f, t0, -prod);      // f t0 = prod + err exactly
+    return (prod - rint(prod)) + (err + phi * 0.15915494309189533577);
+}
+
 // One wavefront's share of the three sums -> red->expart[wave]; epl_finish* adds the wavefronts up after its barrier.
 __device__ __forceinline__ void exact_publish(double (&acc)[6], RedScratch* red, int tid) {
 #pragma unroll
@@ -1029,6 +1036,7 @@ __device__ __forceinline__ void exact_epl_generic(const cf* __restrict__ block, 
                                                   int tid, double (&acc)[6]) {
     constexpr int N = K * kChips;
     constexpr int L = (N + T - 1) / T;
+    constexpr int B = 16;                         // samples requested together (one exposed memory latency per batch)
 #pragma unroll
     for (int v = 0; v < 6; ++v) acc[v] = 0.0;
     const int n0 = tid * L;
@@ -1039,22 +1047,27 @@ __device__ __forceinline__ void exact_epl_generic(const cf* __restrict__ block, 
     int k = n0 - sN;                              // (n - s) mod N: replica chip k / K, offset k % K
     k = k < 0 ? k + N : k;
     int c = k / K, ph = k - c * K;
-    for (int n = n0; n < n1; ++n) {
-        const cf x = block[n];
-        const double2 w = cmul64(make_double2((double)x.x, (double)x.y), car);
-        const float cc = chipf[c];
-        const double d = (double)cc;
-        acc[0] = fma(d, w.x, acc[0]); acc[1] = fma(d, w.y, acc[1]);
-        if (ph == K - 1) {                        // lag s-1 sees the next replica chip here
-            const double g = (double)(cc - chipf[c + 1]);
-            acc[2] = fma(g, w.x, acc[2]); acc[3] = fma(g, w.y, acc[3]);
+    for (int nb = n0; nb < n1; nb += B) {
+        cf xs[B];
+#pragma unroll
+        for (int i = 0; i < B; ++i) xs[i] = block[min(nb + i, N - 1)];
+#pragma unroll
+        for (int i = 0; i < B; ++i) {               // straight-line: the boundary terms carry a zero weight elsewhere
+            const float on = nb + i < n1 ? 1.f : 0.f;
+            const double2 w = cmul64(make_double2((double)xs[i].x, (double)xs[i].y), car);
+            const float cc = chipf[c] * on, cn = chipf[c + 1] * on, cb = chipf[c + kChips - 1] * on;
+            const double d = (double)cc;
+            const double ge = (double)(ph == K - 1 ? cc - cn : 0.f);   // lag s-1 sees the next replica chip at a chip's last sample
+            const double gl = (double)(ph == 0 ? cb - cc : 0.f);       // lag s+1 the previous one at its first
+            acc[0] = fma(d, w.x, acc[0]); acc[1] = fma(d, w.y, acc[1]);
+            acc[2] = fma(ge, w.x, acc[2]); acc[3] = fma(ge, w.y, acc[3]);
+            acc[4] = fma(gl, w.x, acc[4]); acc[5] = fma(gl, w.y, acc[5]);
+            car = cmul64(car, rot);
+            ++ph;
+            c += ph == K ? 1 : 0;
+            ph = ph == K ? 0 : ph;
+            c = c == kChips ? 0 : c;
         }
-        if (ph == 0) {                            // lag s+1 sees the previous one
-            const double g = (double)(chipf[c + kChips - 1] - cc);
-            acc[4] = fma(g, w.x, acc[4]); acc[5] = fma(g, w.y, acc[5]);
-        }
-        car = cmul64(car, rot);
-        if (++ph == K) { ph = 0; if (++c == kChips) c = 0; }
     }
 }
 
@@ -1246,7 +1259,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void 
         const cf* rep = replica_of(p.replica_table, in.sat_id - 1);
         // tracker.py:271-281: carrier = exp(-1j*(2*pi*f*t + phi)), t = n/fs + chunk.start_time
         const double du = in.doppler_hz * p.inv_fs;
-        const double u0 = in.doppler_hz * p.start_time[in.stream] + in.carrier_phase * 0.15915494309189533577;
+        const double u0 = carrier_cycles(in.doppler_hz, p.start_time[in.stream], in.carrier_phase);
         const cf* block = p.iq + (int64_t)in.stream * p.stream_stride;
         const EplResult r = track_ms<K, true>(block, u0, du, carrier_steps<K>(du), in.code_phase, mod_n(in.code_phase, N),
                                         sm, rep, p.profile_out ? p.profile_out + (int64_t)ch * N : nullptr, p.chipf + (in.sat_id - 1) * 2048);
@@ -2433,68 +2446,77 @@ struct DllExactParams {
     const int32_t* only_if;    // optional: only channels with only_if[ch] != 0 (the re-run of failed speculations)
 };
 
-// acc * w + x  (complex, x a float32 sample): one Horner step of sum_i x_i w^i
-__device__ __forceinline__ double2 horner64(double2 acc, double2 w, cf x) {
-    return make_double2(fma(acc.x, w.x, fma(-acc.y, w.y, (double)x.x)), fma(acc.x, w.y, fma(acc.y, w.x, (double)x.y)));
+// acc * w + x  (complex): one Horner step of sum_i x_i w^i
+__device__ __forceinline__ double2 horner64(double2 acc, double2 w, double2 x) {
+    return make_double2(fma(acc.x, w.x, fma(-acc.y, w.y, x.x)), fma(acc.x, w.y, fma(acc.y, w.x, x.y)));
 }
-// One chip's share of {P, d_e, d_l} before the chip's anchor carrier (see the derivation above exact_epl_generic): Horner in
-// rho = exp(-2 pi i du) over the two runs of samples, i >= R meeting replica chip j and i < R chip j-1.  R = s mod K is uniform
-// and compiled in (one body per value behind a scalar switch: the samples sit in registers).
-template <int K, int R>
-__device__ __forceinline__ void exact_chip(const cf (&x)[K], double2 rho, double2 rho_r, double2 rho_e, float cm1, float c0, float cp1,
-                                           double2& pc, double2& ec, double2& lc) {
-    constexpr int RE = R ? R - 1 : K - 1;   // offset of the early-side boundary sample
-    const double dj = (double)c0, djm1 = (double)cm1, gl = (double)(cm1 - c0), ge = (double)(R ? cm1 - c0 : c0 - cp1);
-    double2 h = make_double2((double)x[K - 1].x, (double)x[K - 1].y);
+__device__ __forceinline__ double2 cvt64(cf x) { return make_double2((double)x.x, (double)x.y); }
+// One wavefront per (channel, millisecond), any K <= 8.  With s = K q + r the samples are taken in REPLICA-aligned windows:
+// "virtual chip" m (m = -1 .. 1022) is the K samples n = K m + r + i, i < K -- exactly the samples that meet replica chip
+// j = (m - q) mod 1023 at lag s -- so no window is split between two code chips and nothing in the arithmetic depends on r
+// (it only moves the load address by r samples; the vector loads are 8-byte aligned).  The circular block is cut at its ends:
+// window -1 holds the first r samples (its i < K - r fall before the block: zero), window 1022 the last K - r; both meet
+// replica chip (1022 - q) mod 1023, and the carrier of sample n is exp(-2 pi i (u0 + du n)) for either.  1024 windows = 64
+// lanes x 16: lane l owns m = l + 64 c - 1 (consecutive lanes read consecutive 8K-byte pieces).  Per window
+//     h = sum_i x_i rho^i  (Horner, rho = exp(-2 pi i du)),   P += chip[j] h,
+//     E += (chip[j] - chip[j+1]) x_{K-1}  (lag s-1 sees the next replica chip at a window's last sample),
+//     L += (chip[j-1] - chip[j]) x_0      (lag s+1 the previous one at its first);
+// windows are folded last one first with the window-stride rotation S = rho^(64 K) (Horner again: acc = acc S + term), the
+// lane's anchor carrier (times rho^(K-1) for E) is applied once at the end, six DPP reductions finish the unit.  No LDS, no
+// barrier; ~46 float64 operations + 19 converts per window.
+template <int K, bool EDGE>
+__device__ __forceinline__ void exact_window(const cf* __restrict__ block, int m, int r, int q, const float* __restrict__ chipf,
+                                             double2 rho, double2 step, double2& sp, double2& se, double2& sl) {
+    constexpr int N = K * kChips;
+    const int n0 = K * m + r;                        // first sample of the window; [n0, n0 + K) leaves [0, N) only at m = -1 / 1022
+    cf x[K];
+    if constexpr (EDGE) {
 #pragma unroll
-    for (int i = K - 2; i >= R; --i) h = horner64(h, rho, x[i]);
-    h = cmul64(h, rho_r);
-    pc = make_double2(dj * h.x, dj * h.y);
-    if (R > 0) {
-        double2 g = make_double2((double)x[R - 1].x, (double)x[R - 1].y);
+        for (int i = 0; i < K; ++i) {
+            const int n = n0 + i;
+            const cf v = block[min(max(n, 0), N - 1)];
+            const bool in = n >= 0 && n < N;
+            x[i] = make_float2(in ? v.x : 0.f, in ? v.y : 0.f);
+        }
+    } else {
+        typedef float4 __attribute__((aligned(8))) float4_a8;
+        typedef float2 __attribute__((aligned(8))) float2_a8;
+        const cf* src = block + n0;
 #pragma unroll
-        for (int i = R - 2; i >= 0; --i) g = horner64(g, rho, x[i]);
-        pc.x = fma(djm1, g.x, pc.x); pc.y = fma(djm1, g.y, pc.y);
+        for (int i = 0; i + 1 < K; i += 2) {
+            const float4 v = *reinterpret_cast<const float4_a8*>(src + i);
+            x[i] = make_float2(v.x, v.y);
+            x[i + 1] = make_float2(v.z, v.w);
+        }
+        if (K & 1) x[K - 1] = *reinterpret_cast<const float2_a8*>(src + K - 1);
     }
-    const double2 tl = cmul64(make_double2((double)x[R].x, (double)x[R].y), rho_r);
-    const double2 te = cmul64(make_double2((double)x[RE].x, (double)x[RE].y), rho_e);
-    lc = make_double2(gl * tl.x, gl * tl.y);
-    ec = make_double2(ge * te.x, ge * te.y);
-}
-// One wavefront per (channel, millisecond): lane l owns chips m = l + 64 c (c < 16; consecutive lanes read consecutive
-// 8K-byte chunks: coalesced), folds them last chip first with the chip-stride rotation (Horner again) and applies its anchor
-// carrier once; six DPP reductions finish the unit.  No LDS, no barrier.
-template <int K, int R>
-__device__ __forceinline__ void exact_wave_unit(const cf* __restrict__ block, double u0, double du, int q, const float* __restrict__ chipf,
-                                                int lane, double (&acc)[6]) {
-    constexpr int CH = 16;
-    const double2 rho = carrier64(du), rho_r = carrier64(du * (double)R), rho_e = carrier64(du * (double)(R ? R - 1 : K - 1));
-    const double2 step = carrier64(du * (double)(K * 64));
-    double2 sp = make_double2(0.0, 0.0), se = sp, sl = sp;
-#pragma unroll 2
-    for (int c = CH - 1; c >= 0; --c) {
-        const int m = lane + 64 * c;
-        const bool on = m < kChips;                 // chip 1023 does not exist (lane 63's last)
-        cf x[K];
-        load_samples<K>(block + K * (on ? m : 0), x);
-        int j = m - q;
-        j = j < 0 ? j + kChips : j;                 // (m - q) mod 1023
-        const float* cp = chipf + j + kChips;
-        const float z = on ? 1.f : 0.f;
-        double2 pc, ec, lc;
-        exact_chip<K, R>(x, rho, rho_r, rho_e, cp[-1] * z, cp[0] * z, cp[1] * z, pc, ec, lc);
-        const double2 a = cmul64(sp, step), b = cmul64(se, step), d = cmul64(sl, step);
-        sp = make_double2(a.x + pc.x, a.y + pc.y);
-        se = make_double2(b.x + ec.x, b.y + ec.y);
-        sl = make_double2(d.x + lc.x, d.y + lc.y);
-    }
-    const double2 anchor = carrier64(u0 + du * (double)(K * lane));
-    const double2 p = cmul64(sp, anchor), e = cmul64(se, anchor), l = cmul64(sl, anchor);
-    acc[0] = p.x; acc[1] = p.y; acc[2] = e.x; acc[3] = e.y; acc[4] = l.x; acc[5] = l.y;
+    int j = m - q;
+    j = j < 0 ? j + kChips : j;                      // (m - q) mod 1023 for m >= 0; m = -1 -> (1022 - q) mod 1023 (q <= 1022)
+    j = j < 0 ? j + kChips : j;
+    const float* cp = chipf + j + kChips;
+    const float cm1 = cp[-1], c0 = cp[0], cp1 = cp[1];
+    const double dj = (double)c0, gl = (double)(cm1 - c0), ge = (double)(c0 - cp1);
+    double2 h = cvt64(x[K - 1]);
+#pragma unroll
+    for (int i = K - 2; i >= 0; --i) h = horner64(h, rho, cvt64(x[i]));
+    const double2 xe = cvt64(x[K - 1]), xl = cvt64(x[0]);
+    sp = horner64(sp, step, make_double2(dj * h.x, dj * h.y));
+    se = horner64(se, step, make_double2(ge * xe.x, ge * xe.y));
+    sl = horner64(sl, step, make_double2(gl * xl.x, gl * xl.y));
 }
 template <int K>
-__global__ __launch_bounds__(256) void dll_exact_wave_kernel(DllExactParams p) {
-    static_assert(K <= 8, "a chip's samples in registers");
+__device__ __forceinline__ double2 cpow_km1(double2 w) {   // w^(K-1), K <= 8
+    double2 r = make_double2(1.0, 0.0);
+#pragma unroll
+    for (int i = 0; i < K - 1; ++i) r = cmul64(r, w);
+    return r;
+}
+#ifndef GYP_EXACT_OCC
+#define GYP_EXACT_OCC 4
+#endif
+template <int K>
+__global__ __launch_bounds__(256, GYP_EXACT_OCC) void dll_exact_wave_kernel(DllExactParams p) {
+    static_assert(K <= 8, "a window's samples in registers");
     constexpr int N = K * kChips;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -2514,17 +2536,18 @@ __global__ __launch_bounds__(256) void dll_exact_wave_kernel(DllExactParams p) {
         const cf* block = p.iq + (int64_t)stream * p.stream_stride + (int64_t)ms * N;
         const float* chipf = p.chipf + (sat - 1) * 2048;
         const double du = in.doppler * p.inv_fs;
-        const double u0 = in.doppler * p.start_time[ms] + in.carrier_phase * 0.15915494309189533577;
+        const double u0 = carrier_cycles(in.doppler, p.start_time[ms], in.carrier_phase);
         const int sN = __builtin_amdgcn_readfirstlane(mod_n(in.code_phase, N));
         const int q = sN / K, r = sN % K;
-        double acc[6];
-        switch (r) {   // scalar
-            case 0: exact_wave_unit<K, 0>(block, u0, du, q, chipf, lane, acc); break;
-#define GYP_CASE(RR) case RR: if constexpr (RR < K) exact_wave_unit<K, (RR < K ? RR : 0)>(block, u0, du, q, chipf, lane, acc); break;
-            GYP_CASE(1) GYP_CASE(2) GYP_CASE(3) GYP_CASE(4) GYP_CASE(5) GYP_CASE(6) GYP_CASE(7)
-#undef GYP_CASE
-            default: break;
-        }
+        const double2 rho = carrier64(du), step = carrier64(du * (double)(K * 64));
+        double2 sp = make_double2(0.0, 0.0), se = sp, sl = sp;
+        exact_window<K, true>(block, lane + 64 * 15 - 1, r, q, chipf, rho, step, sp, se, sl);     // holds window 1022 (lane 63)
+#pragma unroll 2
+        for (int c = 14; c >= 1; --c) exact_window<K, false>(block, lane + 64 * c - 1, r, q, chipf, rho, step, sp, se, sl);
+        exact_window<K, true>(block, lane - 1, r, q, chipf, rho, step, sp, se, sl);               // holds window -1 (lane 0)
+        const double2 anchor = carrier64(u0 + du * (double)(K * (lane - 1) + r));
+        const double2 pp = cmul64(sp, anchor), ee = cmul64(cmul64(se, cpow_km1<K>(rho)), anchor), ll = cmul64(sl, anchor);
+        double acc[6] = {pp.x, pp.y, ee.x, ee.y, ll.x, ll.y};
 #pragma unroll
         for (int v = 0; v < 6; ++v) acc[v] = wave_sum_last(acc[v]);
         if (lane == 63) p.disc_out[at] = dll_discriminator_exact(acc);
@@ -2547,7 +2570,7 @@ __global__ __launch_bounds__(256) void dll_exact_block_kernel(DllExactParams p) 
         const ChanState* st = p.states + ch;
         const cf* block = p.iq + (int64_t)st->stream * p.stream_stride + (int64_t)ms * N;
         const double du = in.doppler * p.inv_fs;
-        const double u0 = in.doppler * p.start_time[ms] + in.carrier_phase * 0.15915494309189533577;
+        const double u0 = carrier_cycles(in.doppler, p.start_time[ms], in.carrier_phase);
         double acc[6];
         exact_epl_generic<K, 256>(block, u0, du, mod_n(in.code_phase, N), p.chipf + (st->sat_id - 1) * 2048, tid, acc);
 #pragma unroll
@@ -2585,79 +2608,153 @@ struct DllScanParams {
     double inv_fs, dll_gain, dll_modulus, n_samples;
     int32_t first, final;
 };
-constexpr int kScanThreads = 512;
+constexpr int kScanThreads = 256;
+constexpr int kScanChunk = 512;     // milliseconds staged in LDS at a time
+constexpr int kSpecKeyRepaired = -3;
 template <int K>
 __global__ __launch_bounds__(kScanThreads) void dll_scan_kernel(DllScanParams p) {
     constexpr int N = K * kChips;
+    // One chunk of the channel's hand-over data in LDS: loaded and written back by all threads (coalesced), walked by wavefront 0
+    // alone (every lane the same values: broadcast reads, no cross-lane traffic) -- the serial loop never touches global memory.
+    __shared__ double s_disc[kScanChunk];   // in: tracker.py:297 at the provisional lag; out: at the lag the exact loop ran with
+    __shared__ int s_cpin[kScanChunk];      // provisional code phase of the millisecond
+    __shared__ int s_cpout[kScanChunk];     // exact code phase after the update (the record's)
+    __shared__ int s_key[kScanChunk];       // SpecIn::key; kSpecKeyRepaired once the millisecond has been repaired
     __shared__ double part[kScanThreads / 64][6];
+    __shared__ float s_chipf[2048];         // this satellite's +-1 code twice over, fetched at the first repair
+    __shared__ double s_a;
+    __shared__ int s_s, s_pos, s_repairs;
+    bool have_code = false;
     const int ch = blockIdx.x, tid = threadIdx.x;
     if (ch >= p.n_chan) return;
     if (p.bad && (p.bad[ch] != 0) != (p.only_bad != 0)) return;
     const ChanState* st = p.states + ch;
-    double a;
-    int s, repairs;
-    if (p.first && p.ckpt) { a = p.ckpt[ch].dll_phase; s = p.ckpt[ch].code_phase; repairs = 0; }
-    else { const DllExact x = p.exact[ch]; a = x.dll; s = x.code_phase; repairs = p.first ? 0 : x.repairs; }
+    if (tid == 0) {
+        if (p.first && p.ckpt) { s_a = p.ckpt[ch].dll_phase; s_s = p.ckpt[ch].code_phase; s_repairs = 0; }
+        else { const DllExact x = p.exact[ch]; s_a = x.dll; s_s = x.code_phase; s_repairs = p.first ? 0 : x.repairs; }
+    }
     const float* chipf = p.chipf + (st->sat_id - 1) * 2048;
     const cf* stream = p.iq + (int64_t)st->stream * p.stream_stride;
-    // (the hand-over records do not depend on the chain: the next millisecond's are requested one iteration early, so the
-    // serial loop never waits for memory)
-    SpecIn in_next = p.spec[(int64_t)ch * p.n_ms + p.ms_begin];
-    double d_next = p.disc[(int64_t)ch * p.n_ms + p.ms_begin];
-    for (int ms = p.ms_begin; ms < p.ms_end; ++ms) {
-        const int64_t at = (int64_t)ch * p.n_ms + ms;
-        const SpecIn in = in_next;
-        double d = d_next;
-        if (ms + 1 < p.ms_end) { in_next = p.spec[at + 1]; d_next = p.disc[at + 1]; }
-        gyp_track_rec* rec = p.rec_out ? p.rec_out + at : nullptr;
-        if (in.key == kSpecKeyLost) {          // not processed: the loop state stands (the status-2 record carries it)
-            if (rec && tid == 0) rec->code_phase = s;
-            continue;
+    const int64_t row = (int64_t)ch * p.n_ms;
+    for (int c0 = p.ms_begin; c0 < p.ms_end; c0 += kScanChunk) {
+        const int len = min(kScanChunk, p.ms_end - c0);
+        for (int i = tid; i < len; i += kScanThreads) {
+            const SpecIn* in = p.spec + row + c0 + i;
+            const int key = in->key;
+            s_key[i] = key;
+            s_cpin[i] = in->code_phase;
+            s_disc[i] = key == kSpecKeyLost ? 0.0 : p.disc[row + c0 + i];
         }
-        if (s != in.code_phase) {              // uniform
-            double acc[6];
-            const double du = in.doppler * p.inv_fs;
-            const double u0 = in.doppler * p.start_time[ms] + in.carrier_phase * 0.15915494309189533577;
-            exact_epl_generic<K, kScanThreads>(stream + (int64_t)ms * N, u0, du, mod_n(s, N), chipf, tid, acc);
-#pragma unroll
-            for (int v = 0; v < 6; ++v) acc[v] = wave_sum_last(acc[v]);
-            __syncthreads();                   // the previous repair's readers are done with `part`
-            if ((tid & 63) == 63) {
-#pragma unroll
-                for (int v = 0; v < 6; ++v) part[tid >> 6][v] = acc[v];
+        if (tid == 0) s_pos = 0;
+        __syncthreads();
+        while (true) {   // uniform: every thread sees the same s_pos
+            if (tid < 64) {   // wavefront 0 walks until the chunk ends or a millisecond needs its sums formed again
+                // Every lane carries the same values.  The common case -- processed, lags agree, accumulator in its usual range -- is
+                // straight-line vector code behind ONE scalar branch per millisecond (each vector-to-scalar hand-over costs the
+                // pipeline's depth), with the next millisecond's hand-over values already requested from LDS.
+                double a = s_a;
+                int s = s_s, i = __builtin_amdgcn_readfirstlane(s_pos);   // (i: scalar loop control)
+                bool stop = false;
+                int key_n = 0, cp_n = 0;
+                double d_n = 0.0;
+                if (i < len) { key_n = s_key[i]; cp_n = s_cpin[i]; d_n = s_disc[i]; }
+                while (i < len && !stop) {   // uniform
+                    const int key = key_n, cp = cp_n;
+                    const double d = d_n;
+                    if (i + 1 < len) { key_n = s_key[i + 1]; cp_n = s_cpin[i + 1]; d_n = s_disc[i + 1]; }
+                    const double dll = __dadd_rn(a, __dmul_rn(d, p.dll_gain));   // tracker.py:298: product and sum rounded separately, as Python does
+                    const double whole = trunc(dll);
+                    // (bitwise, not short-circuit: one predicate, no branch per clause)
+                    const int usual = (int)(key != kSpecKeyLost) & ((int)(key == kSpecKeyRepaired) | (int)(s == cp)) &
+                                      (int)(fabs(whole) < 2147483648.0) & (int)(dll > -p.dll_modulus) & (int)(dll < 2.0 * p.dll_modulus);
+                    if (__builtin_amdgcn_readfirstlane(usual)) {
+                        double r = dll >= p.dll_modulus ? dll - p.dll_modulus : dll;   // pymod_uniform's fast range
+                        r += (r != 0.0 && r < 0.0) ? p.dll_modulus : 0.0;
+                        r += r < 0.0 ? p.dll_modulus : 0.0;
+                        a = r;
+                        s = (int)whole;
+                        if (tid == 0) s_cpout[i] = s;
+                        ++i;
+                        continue;
+                    }
+                    if (uniform(key == kSpecKeyLost)) {                   // not processed: the loop state stands (the status-2 record carries it)
+                        if (tid == 0) s_cpout[i] = s;
+                        ++i;
+                        continue;
+                    }
+                    if (uniform(key != kSpecKeyRepaired && s != cp)) { stop = true; break; }
+                    double r = pymod_uniform(dll, p.dll_modulus);         // the accumulator outside its usual range
+                    r += r < 0.0 ? p.dll_modulus : 0.0;
+                    a = r;
+                    s = uniform(fabs(whole) < 2147483648.0) ? (int)whole : code_phase_beyond_int32(whole, p.n_samples);
+                    if (tid == 0) s_cpout[i] = s;
+                    ++i;
+                }
+                if (tid == 0) { s_a = a; s_s = s; s_pos = i; }
             }
             __syncthreads();
-            double ex[6];
+            const int pos = s_pos;
+            if (pos >= len) break;
+            {   // repair: this millisecond's float64 sums for the lag the exact loop is at
+                const int ms = c0 + pos;
+                const SpecIn in = p.spec[row + ms];
+                const double du = in.doppler * p.inv_fs;
+                const double u0 = carrier_cycles(in.doppler, p.start_time[ms], in.carrier_phase);
+                if (!have_code) {   // uniform
+                    for (int k = tid; k < 2048; k += kScanThreads) s_chipf[k] = chipf[k];
+                    have_code = true;
+                    __syncthreads();
+                }
+                double acc[6];
+                exact_epl_generic<K, kScanThreads>(stream + (int64_t)ms * N, u0, du, mod_n(s_s, N), s_chipf, tid, acc);
 #pragma unroll
-            for (int v = 0; v < 6; ++v) {
-                double t = part[0][v];
+                for (int v = 0; v < 6; ++v) acc[v] = wave_sum_last(acc[v]);
+                if ((tid & 63) == 63) {
 #pragma unroll
-                for (int w = 1; w < kScanThreads / 64; ++w) t += part[w][v];
-                ex[v] = t;
-            }
-            d = dll_discriminator_exact(ex);
-            ++repairs;
-            if (rec && tid == 0) {             // the arg-max LAG stands; its index in the profile of the PRN rolled by s moves
-                int lag = rec->peak_offset + mod_n(in.code_phase, N);
-                lag = lag >= N ? lag - N : lag;
-                int key = lag - mod_n(s, N);
-                rec->peak_offset = key < 0 ? key + N : key;
+                    for (int v = 0; v < 6; ++v) part[tid >> 6][v] = acc[v];
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    double ex[6];
+#pragma unroll
+                    for (int v = 0; v < 6; ++v) {
+                        double t = part[0][v];
+#pragma unroll
+                        for (int w = 1; w < kScanThreads / 64; ++w) t += part[w][v];
+                        ex[v] = t;
+                    }
+                    s_disc[pos] = dll_discriminator_exact(ex);
+                    s_key[pos] = kSpecKeyRepaired;
+                    if (p.rec_out) {   // the arg-max LAG stands; its index in the profile of the PRN rolled by s moves with s
+                        gyp_track_rec* rec = p.rec_out + row + ms;
+                        int lag = rec->peak_offset + mod_n(in.code_phase, N);
+                        lag = lag >= N ? lag - N : lag;
+                        const int k2 = lag - mod_n(s_s, N);
+                        rec->peak_offset = k2 < 0 ? k2 + N : k2;
+                    }
+                    ++s_repairs;
+                }
+                __syncthreads();
             }
         }
-        // tracker.py:298-303, as dll_update
-        double dll = a + d * p.dll_gain;
-        const double whole = trunc(dll);
-        const int s_next = uniform(fabs(whole) < 2147483648.0) ? (int)whole : code_phase_beyond_int32(whole, p.n_samples);
-        dll = pymod_uniform(dll, p.dll_modulus);
-        dll += dll < 0.0 ? p.dll_modulus : 0.0;
-        a = dll;
-        s = s_next;
-        if (rec && tid == 0) { rec->discriminator = (float)d; rec->code_phase = s_next; }
+        // write-back: the record's discriminator and code phase
+#ifdef GYP_SCAN_NOWB
+        if (false) {
+#else
+        if (p.rec_out) {
+#endif
+            for (int i = tid; i < len; i += kScanThreads) {
+                gyp_track_rec* rec = p.rec_out + row + c0 + i;
+                rec->code_phase = s_cpout[i];
+                if (s_key[i] != kSpecKeyLost) rec->discriminator = (float)s_disc[i];
+            }
+        }
+        __syncthreads();   // the arrays are reused by the next chunk
     }
     if (tid == 0) {
-        DllExact x; x.dll = a; x.code_phase = s; x.repairs = repairs;
+        DllExact x; x.dll = s_a; x.code_phase = s_s; x.repairs = s_repairs;
         p.exact[ch] = x;
-        if (p.final) { p.states[ch].dll_phase = a; p.states[ch].code_phase = s; }
+        if (p.final) { p.states[ch].dll_phase = s_a; p.states[ch].code_phase = s_s; }
     }
 }
 
