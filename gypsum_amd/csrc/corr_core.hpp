@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "fft32_gen.hpp"   // generated 32-point codelets (tools/gen_fft32.py)
 
 namespace gyp {
 
@@ -153,6 +154,15 @@ __device__ __forceinline__ void fft32_dit(cf (&x)[32]) {
     }
 }
 
+#ifdef GYP_OLD_FFT32   // A/B switch: the hand-rolled radix-2 loops of r01/r02 instead of the generated codelets
+__device__ __forceinline__ void fft32_fwd_nat_br_(cf (&x)[32]) { fft32_dif<-1>(x); }
+__device__ __forceinline__ void fft32_inv_br_nat_(cf (&x)[32]) { fft32_dit<+1>(x); }
+__device__ __forceinline__ void fft32_inv_nat_br_(cf (&x)[32]) { fft32_dif<+1>(x); }
+#define fft32_fwd_nat_br fft32_fwd_nat_br_
+#define fft32_inv_br_nat fft32_inv_br_nat_
+#define fft32_inv_nat_br fft32_inv_nat_br_
+#endif
+
 // All 64 lanes of this wavefront have issued their LDS writes; make them visible to the reads that follow.
 // LDS operations of one wavefront execute in order, so only the compiler needs restraining.
 __device__ __forceinline__ void wave_lds_fence() {
@@ -165,6 +175,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 struct LdsTables {
     const cf* tw1024;  // LDS   [32][32]: exp(-2*pi*i * g*n / 1024)
     const cf* tw2048;  // global [1024] : exp(-2*pi*i * n / 2048), L1-resident; only the odd half-wave reads it
+    const cf* ones = nullptr;   // global [1024] of 1 + 0i behind tw2048 (wave_fft_fwd<.., true>: the even half-wave's "twiddle")
 };
 
 // 32x32 transpose inside each half-wave: lane l, register g  ->  lane g, register l.  The real parts of all 64
@@ -215,15 +226,22 @@ __device__ __forceinline__ void twiddle_batch(cf (&x)[32], const cf* __restrict_
 
 // Forward transform.  In: x[j] = y[32*j + l] (identical in both half-waves; y[1023] must be 0).
 // Out: physical register i holds bin f = 2*(l + 32*bitrev5(i)) + h.
-template <int B = kTwBatch>
+// ONES: the radix-2 twiddle pass runs on BOTH half-waves, the even one reading a table of ones (same instruction stream, same
+// cost in issue slots as the masked form -- the masked lanes idle through it anyway -- but no branch, and none of the ~64
+// register copies the allocator spends re-joining the two paths of `if (h)`).  Multiplying by 1 + 0i is exact.
+template <int B = kTwBatch, bool ONES = false>
 __device__ __forceinline__ void wave_fft_fwd(cf (&x)[32], float* tile_half, const LdsTables& t, int l, int h) {
-    if (h) {
+    if constexpr (ONES) {
+        const cf* tab = (h ? t.tw2048 : t.ones) + launder(l);
+#pragma unroll
+        for (int b = 0; b < 32; b += B) twiddle_batch<false, false, B>(x, tab, b, [](int g) { return g; });
+    } else if (h) {
         const cf* tab = t.tw2048 + launder(l);
 #pragma unroll
         for (int b = 0; b < 32; b += B) twiddle_batch<false, false, B>(x, tab, b, [](int g) { return g; });
     }
     __builtin_amdgcn_sched_barrier(0);
-    fft32_dif<-1>(x);
+    fft32_fwd_nat_br(x);
     __builtin_amdgcn_sched_barrier(0);
     {
         const cf* tab = t.tw1024 + l;
@@ -232,7 +250,7 @@ __device__ __forceinline__ void wave_fft_fwd(cf (&x)[32], float* tile_half, cons
     }
     transpose32(x, tile_half, l, [](int g) { return bitrev5(g); });
     __builtin_amdgcn_sched_barrier(0);
-    fft32_dif<-1>(x);
+    fft32_fwd_nat_br(x);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -242,7 +260,7 @@ __device__ __forceinline__ void wave_fft_fwd(cf (&x)[32], float* tile_half, cons
 template <int B = kTwBatch>
 __device__ __forceinline__ void wave_fft_inv(cf (&x)[32], cf (&c)[16], float* tile_half, const LdsTables& t, int l, int h) {
     __builtin_amdgcn_sched_barrier(0);
-    fft32_dit<+1>(x);
+    fft32_inv_br_nat(x);
     __builtin_amdgcn_sched_barrier(0);
     {
         const cf* tab = t.tw1024 + l;
@@ -251,7 +269,7 @@ __device__ __forceinline__ void wave_fft_inv(cf (&x)[32], cf (&c)[16], float* ti
     }
     transpose32(x, tile_half, l, [](int q) { return q; });
     __builtin_amdgcn_sched_barrier(0);
-    fft32_dif<+1>(x);
+    fft32_inv_nat_br(x);
     __builtin_amdgcn_sched_barrier(0);
     // lag q = l + 32*qb sits in x[bitrev5(qb)] of both half-waves: the even-bin part in the low half, the odd-bin
     // part -- still to be multiplied by exp(+2*pi*i*q/2048) -- in the high half.  Registers bitrev5(qb) and

@@ -125,7 +125,7 @@ struct gyp_ctx {
     int32_t n = 0;
     int k = 0;
     cf* d_replicas = nullptr;  // [32][32][64]
-    cf* d_tw = nullptr;        // tw1024[1024] ++ tw2048[1024]
+    cf* d_tw = nullptr;        // tw1024[1024] ++ tw2048[1024] ++ ones[1024]
     uint8_t* d_chips = nullptr;  // [32][1023]: synthetic generator, float64 tie-breaks
     uint16_t* d_ones = nullptr;  // [32][512]: positions of the 512 ones of each code (float64 strength tie-break)
     uint16_t* d_trans = nullptr; // [32][kMaxTrans]: chip transitions (float64 early/late boundary sums)
@@ -415,7 +415,8 @@ int gyp_set_stream_format(gyp_ctx* ctx, int64_t fs_hz, int32_t samples_per_ms) {
         if (make_prn_chips(chips.data()) != GYP_OK) return fail(ctx, GYP_E_BAD_ARG, "PRN self-check against IS-GPS-200 markers failed");
         std::vector<float> rep(32 * 32 * 64 * 2);
         for (int sv = 0; sv < 32; ++sv) make_replica_lane_layout(chips.data() + sv * kChips, rep.data() + (size_t)sv * 32 * 64 * 2);
-        std::vector<float> tw(2048 * 2);
+        std::vector<float> tw(3072 * 2);   // tw1024, tw2048, 1024 ones (the even half-wave's radix-2 "twiddle", wave_fft_fwd)
+        for (int n = 0; n < 1024; ++n) { tw[(2048 + n) * 2 + 0] = 1.0f; tw[(2048 + n) * 2 + 1] = 0.0f; }
         for (int g = 0; g < 32; ++g)
             for (int n = 0; n < 32; ++n) {
                 const double a = -2.0 * M_PI * (double)(g * n) / 1024.0;

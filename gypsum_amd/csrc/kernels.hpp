@@ -137,6 +137,7 @@ static_assert(sizeof(RedScratch) <= kRedBytes, "reduction scratch too large");
 struct Smem {
     cf* tw1024;
     const cf* tw2048;   // global
+    const cf* ones;     // global: 1024 x (1 + 0i) behind the twiddle tables; null where tw2048 was moved into LDS
     cf* xch;
     RedScratch* red;
     cf* halo;           // [16][K] prefix sums of the lane-0 chips (halo-free staging, K == 8 only)
@@ -148,6 +149,7 @@ __device__ __forceinline__ Smem carve_smem(char* base, const cf* __restrict__ tw
     Smem s;
     s.tw1024 = reinterpret_cast<cf*>(base);
     s.tw2048 = tw_global + 1024;
+    s.ones = tw_global + 2048;
     s.xch = s.tw1024 + 1024;
     s.red = reinterpret_cast<RedScratch*>(base + kTablesBytes + lds_rows<K>() * kXchWaveBytes);
     s.halo = reinterpret_cast<cf*>(base + kTablesBytes + lds_rows<K>() * kXchWaveBytes + kRedBytes);
@@ -174,8 +176,8 @@ __device__ __forceinline__ void transform_staged(const Smem& sm, const cf* __res
     if (HALO) halo_fixup<K>(x, sm.halo, row, l);
     wave_lds_fence();
     float* tile_half = reinterpret_cast<float*>(sm.xch + row * kXchWave) + h * kXchTile;
-    const LdsTables t{sm.tw1024, sm.tw2048};
-    wave_fft_fwd(x, tile_half, t, l, h);
+    const LdsTables t{sm.tw1024, sm.tw2048, sm.ones};
+    wave_fft_fwd<kTwBatch, true>(x, tile_half, t, l, h);   // (every caller carves its tables with carve_smem: tw2048 / ones in global memory)
     spectrum_mul_from(x, rep_table_sat, lane);
     wave_fft_inv(x, c, tile_half, t, l, h);
 }
@@ -483,6 +485,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, 2) void corr_cells_pipe_kernel(C
     sm.tw1024 = reinterpret_cast<cf*>(smem_raw);
     cf* tw2048 = sm.tw1024 + 1024;          // both twiddle tables live in LDS here: no global load inside a transform
     sm.tw2048 = tw2048;
+    sm.ones = nullptr;
     sm.xch = tw2048 + 1024;
     sm.red = reinterpret_cast<RedScratch*>(smem_raw + 2 * kTablesBytes + 2 * W * kXchWaveBytes);
     cf* halo_base = reinterpret_cast<cf*>(smem_raw + 2 * kTablesBytes + 2 * W * kXchWaveBytes + kRedBytes);
@@ -1590,7 +1593,9 @@ __device__ __forceinline__ void dll_update(RedScratch* red, double disc, int lan
 }
 // tracker.py:246-262 Costas loop with the is_locked() bandwidth switch, :346-389 histories and circularity watchdog.
 // Owns everything else in LoopState, dstate, istate[1], steps.
-template <int K>
+// MEAS: also the record's measurement fields (peak, strength, error, peak offset, path) -- the throughput block kernel leaves
+// those to another wavefront (spec_record_fields), off the serial path.
+template <int K, bool MEAS = true>
 __device__ __forceinline__ void costas_update(const LoopConst& kc, ChanState* st, RedScratch* red, double t0, int lane,
                                               const MsMeasure& r, const double (&leave)[3]) {
     constexpr int N = K * kChips;
@@ -1660,18 +1665,21 @@ __device__ __forceinline__ void costas_update(const LoopConst& kc, ChanState* st
         red->istate[1] = lost;
         red->steps = tracking_steps<K>(nf * kc.inv_fs);
         gyp_track_rec& o = red->rec;
-        o.peak_re = r.peak.x; o.peak_im = r.peak.y;
-        if (r.strength_pending) {
-            o.strength = 0.0f;                  // filled in by track_verify_kernel
-        } else {
-            const float mean_excl = (float)((r.sum - (double)r.n_max * (double)r.peak_mag) / (double)(N - r.n_max));
-            o.strength = r.peak_mag / mean_excl;
+        if constexpr (MEAS) {
+            o.peak_re = r.peak.x; o.peak_im = r.peak.y;
+            if (r.strength_pending) {
+                o.strength = 0.0f;                  // filled in by track_verify_kernel
+            } else {
+                const float mean_excl = (float)((r.sum - (double)r.n_max * (double)r.peak_mag) / (double)(N - r.n_max));
+                o.strength = r.peak_mag / mean_excl;
+            }
+            o.error = err;
+            o.peak_offset = r.key;
+            o.path_info = r.path_info;
         }
-        o.doppler_hz = rec_f; o.carrier_phase = rec_phi; o.error = err;
-        o.peak_offset = r.key;
+        o.doppler_hz = rec_f; o.carrier_phase = rec_phi;
         o.pseudosymbol = (int8_t)(pr > 0.0 ? 1 : (pr < 0.0 ? -1 : 0));
         o.locked = locked ? 1 : 0; o.status = (int8_t)status; o.nudged = (int8_t)nudged;
-        o.path_info = r.path_info;
     }
 }
 // red->rec -> global memory: 14 dwords, one per lane.  The caller has made the LDS record visible to this wavefront.
@@ -2061,6 +2069,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
         cf* tw2048 = reinterpret_cast<cf*>(smem_raw + lds_bytes<K>());
         for (int i = threadIdx.x; i < 1024; i += kThreadsHere) tw2048[i] = p.tw_tables[1024 + i];
         sm.tw2048 = tw2048;
+        sm.ones = nullptr;
     }
     if (SPEC) {
         char* b = smem_raw + lds_bytes<K>() + kTablesBytes;
@@ -2147,6 +2156,10 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
         // (speculative mode: a load issued here would be waited for -- a few hundred cycles -- by the first carrier of the
         // wipe-off; wavefront 5 fetched the value into LDS during the previous millisecond's loop updates)
         const double t0 = SPEC ? launder_lds(sm.red)->t0_next : p.start_time[launder(ms)];
+        if (!SPEC && have_prev) {   // the previous millisecond's record (complete since the barrier that ended it)
+            if (wave == 1) rec_flush(sm.red, rec ? rec - 1 : nullptr, lane);
+            have_prev = false;
+        }
         if (sm.red->istate[1]) {  // a dropped channel stays dropped until the host re-creates it (receiver.py:259-267)
             if (SPEC && have_prev) {   // the millisecond that dropped it took the slow path: only its record is outstanding
                 if (wave == 1) rec_flush_spec(sm.red, rec ? rec - 1 : nullptr, lane);
@@ -2327,13 +2340,24 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
             if (wave == 1) dll_update(launder_lds(sm.red), m.disc, lane, kc->lp);
             if (wave == 2) costas_candidate<K>(kc->inv_fs, launder_lds(sm.red), m.peak, f, phi, kc->lp.alpha_locked, kc->lp.beta_locked, 0, lane);
             if (wave == 3) costas_candidate<K>(kc->inv_fs, launder_lds(sm.red), m.peak, f, phi, kc->lp.alpha_unlocked, kc->lp.beta_unlocked, 1, lane);
-        } else if (wave == 0) {
+        } else {
+            // Three wavefronts side by side: the Costas loop with the lock verdict (the serial chain the next wipe-off waits for),
+            // the code loop, the record's measurement fields.  The record leaves for global memory at the top of the next
+            // millisecond (rec_flush by wavefront 1), off this path too.
             RedScratch* red = launder_lds(sm.red);
-            fetch_leaving(st, red, leave);
-            dll_update(red, m.disc, lane, red->kc.lp);
-            costas_update<K>(red->kc, st, red, t0, lane, m, leave);
-            workgroup_mem_fence_wave();
-            rec_flush(red, rec, lane);
+            if (wave == 0) {
+                const long long u0_ = prof ? (long long)__builtin_readcyclecounter() : 0;
+                fetch_leaving(st, red, leave);
+                if (prof) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const long long u1_ = prof ? (long long)__builtin_readcyclecounter() : 0;
+                costas_update<K, false>(red->kc, st, red, t0, lane, m, leave);
+                if (prof) { tp[6] += u1_ - u0_; tp[8] += (long long)__builtin_readcyclecounter() - u1_; }
+            } else if (wave == 1) {
+                dll_update(red, m.disc, lane, red->kc.lp);
+            } else if (wave == 2) {
+                spec_record_fields<K>(red, m, lane);
+            }
+            have_prev = true;
         }
         asm volatile("; MARK_UPDATE_END");
         long long t_d = prof ? (long long)__builtin_readcyclecounter() : 0;
@@ -2350,6 +2374,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
         if (wave == 0) spec_error_side(st, sm.red, 0.0, lane, sm.red->kc.lp);
         if (wave == 1) rec_flush_spec(sm.red, p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + (p.ms_end - 1) : nullptr, lane);
     }
+    if (!SPEC && have_prev && wave == 1) rec_flush(sm.red, p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + (p.ms_end - 1) : nullptr, lane);
     if (threadIdx.x == 0) {
         st->doppler = SPEC ? sm.red->cc[sm.red->cand_sel].nf : sm.red->dstate[0];
         st->carrier_phase = SPEC ? sm.red->cc[sm.red->cand_sel].nphi : sm.red->dstate[1];

@@ -51,6 +51,10 @@ def main():
     print(f"  total {tot / steps:.0f} cycles/ms (constant 100 MHz counter if s_memrealtime, else shader clock)")
     print(f"  speculative mode: phases are stage | window + decision | transform path (if taken) + loop update | barrier; "
           f"{out[5]} of {steps} ms took the transform path in workgroup 0")
+    if "--full" in sys.argv:
+        for i, nm in enumerate(["ring entries leaving the lock windows (3 global loads)", "code loop", "Costas loop + lock verdict + record", "record flush"]):
+            print(f"    update: {nm:60s} {out[6 + i] / steps:8.0f} cycles/ms")
+        return
     r = rec.download(TRACK_REC, B * C_ * T).reshape(B * C_, T)
     stamps = ["state read", "sample requests", "staging emit", "boundary sums + partial writes", "barrier A", "window + partial sums",
               "barrier B", "decision", "(transform path)", "loop update"]
