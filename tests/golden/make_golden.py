@@ -225,7 +225,10 @@ if __name__ == "__main__":
         make_grid_kat()
     if "acq" in what:
         make_acquisition("2046", 2_046_000, 20260926, None)
-        make_acquisition("8184", 8_184_000, 20260927, [1, 2, 3])
+    if "acq" in what or "acq8184" in what:
+        # r03: all 32 satellites at the headline rate too (24 of them noise-only: the cells where top-two gaps are ~1e-2 and
+        # the cross-level near-ties of acquisition.py:92-101 live); r01/r02 held the rows of satellites 1, 2, 3 + three visible
+        make_acquisition("8184", 8_184_000, 20260927, None)
     if "track" in what:
         make_tracking("2046", 2_046_000, 20260928, 700, 3)
         make_tracking("8184", 8_184_000, 20260929, 300, 2)

@@ -77,3 +77,23 @@ def run_acq_scene(args):
         r = orc.acquire_satellite(s.sat_id, iq, fs, n, orc.prn_as_complex(chips[s.sat_id - 1], n))
         out.append((int(s.sat_id), int(r.doppler_shift), int(r.prn_phase_shift)))
     return seed, out
+
+
+def run_full_sky_scene(args):
+    """args = (fs, seed).  The oracle's full 10-level acquisition of ALL 32 satellites of a 6-satellite scene -- 26 of them
+    noise-only, where the top-two gaps are ~1e-2 and the cross-level near-ties of acquisition.py:92-101 live:
+    [(sat_id, doppler_shift, prn_phase_shift, correlation_strength)].  Satellites are spread over a pool of processes by the
+    caller (one call = one scene = 32 searches)."""
+    fs, seed = args
+    from gypsum_amd import synth
+    from oracle import gypsum_oracle as orc
+
+    n = fs // 1000
+    scene = synth.random_scene(fs, 10, 6, seed, with_nav_bits=False, max_code_phase=(2046 if n > 2046 else None))
+    iq = synth.render(scene)
+    chips = orc.generate_ca_codes()
+    out = []
+    for sv in range(1, 33):
+        r = orc.acquire_satellite(sv, iq, fs, n, orc.prn_as_complex(chips[sv - 1], n))
+        out.append((sv, int(r.doppler_shift), int(r.prn_phase_shift), float(r.correlation_strength)))
+    return seed, out

@@ -210,3 +210,27 @@ def test_acquisition_survey(engine_factory, fs, n_scenes):
                 assert int(g["code_phase"]) == cp, (seed, sv)
                 tot += 1
     print(f"{tot} visible-satellite acquisitions at {fs / 1e6:.3f} Msps bit-exact")
+
+
+@pytest.mark.parametrize("fs,n_scenes", [(2_046_000, 24), (8_184_000, 12)])
+def test_full_sky_acquisition_survey(engine_factory, fs, n_scenes):
+    """cfg3 searches 32 satellites of which ~20 are not there.  All 32 of every scene, noise-only included, against the oracle's
+    10-level search: Doppler bin and code phase bit-exact, strength to 1e-4."""
+    n = fs // 1000
+    eng = engine_factory(fs, n)
+    procs = max(1, min(48, (os.cpu_count() or 2) - 2, n_scenes))
+    ids = list(range(1, 33))
+    tot = noise = 0
+    with mp.get_context("spawn").Pool(procs) as pool:
+        for seed, want in pool.imap_unordered(survey_worker.run_full_sky_scene, [(fs, 350000 + SEED_OFFSET + k) for k in range(n_scenes)]):
+            scene = synth.random_scene(fs, 10, 6, seed, with_nav_bits=False, max_code_phase=(2046 if n > 2046 else None))
+            present = {s.sat_id for s in scene.sats}
+            got = eng.acquire(synth.render(scene), 1, 10, ids)
+            for g, (sv, dop, cp, strength) in zip(got, want):
+                assert int(g["sat_id"]) == sv
+                assert int(g["doppler_hz"]) == dop, (seed, sv, sv in present, int(g["doppler_hz"]), dop)
+                assert int(g["code_phase"]) == cp, (seed, sv, sv in present, int(g["code_phase"]), cp)
+                assert abs(float(g["strength"]) - strength) <= 1e-4 * strength, (seed, sv, float(g["strength"]), strength)
+                tot += 1
+                noise += sv not in present
+    print(f"{tot} acquisitions ({noise} of satellites that are not in the scene) at {fs / 1e6:.3f} Msps bit-exact, strength within 1e-4")
