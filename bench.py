@@ -295,15 +295,15 @@ def cpu_baseline_cfg2(fs: int, n: int) -> dict:
 class Cfg3Setup:
     """B streams x T ms of synthetic 8.184 Msps IQ in HBM, every stream acquired once (untimed) and its 12 channels seeded."""
 
-    def __init__(self, eng, rng, B: int, T: int, seed: int, records: bool = True) -> None:
+    def __init__(self, eng, rng, B: int, T: int, seed: int, records: bool = True, amplitude: float = 0.005, sigma: float = 0.03) -> None:
         self.fs, self.n, self.C = 8_184_000, 8184, 12
         fs, n, C_ = self.fs, self.n, self.C
         eng.set_stream_format(fs, n)
         self.eng, self.B, self.T, self.seed = eng, B, T, seed
-        self.scene = make_scene(rng, B, C_, fs, 0.005)          # SURVEY section 8 d2 (a*N = 41, sigma = 6a)
+        self.scene = make_scene(rng, B, C_, fs, amplitude)      # SURVEY section 8 d2 (a*N = 41, sigma = 6a) by default
         self.stride = T * n
         self.iq = eng.alloc(B * T * n * 8)
-        eng.synth_iq(self.iq, B, self.stride, T, self.scene, 0.03, seed)
+        eng.synth_iq(self.iq, B, self.stride, T, self.scene, sigma, seed)
         acq_buf = eng.alloc(B * 32 * ACQ_RESULT.itemsize)
         eng.acquire_dev(self.iq.ptr.value, B, self.stride, 10, ALL_IDS, acq_buf.ptr.value)
         acq = acq_buf.download(ACQ_RESULT, B * 32).reshape(B, 32)

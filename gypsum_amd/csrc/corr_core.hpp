@@ -769,6 +769,25 @@ __device__ __forceinline__ void wave_sum_last_4f1d(float& a, float& b, float& c,
     GYP_BCAST(0x143, 0xC, 1);
 #undef GYP_BCAST
 }
+// wave_sum_last of six floats at once (see wave_sum_last_4f1d).  Valid in lane 63 only.
+__device__ __forceinline__ void wave_sum_last_6f(float& a, float& b, float& c, float& d, float& e, float& f) {
+#define GYP_STEP(CTRL) do { a += dpp_f<CTRL>(a); b += dpp_f<CTRL>(b); c += dpp_f<CTRL>(c); d += dpp_f<CTRL>(d); e += dpp_f<CTRL>(e); f += dpp_f<CTRL>(f); } while (0)
+    GYP_STEP(kDppXor1);
+    GYP_STEP(kDppXor2);
+    GYP_STEP(kDppHalfMirror);
+    GYP_STEP(kDppMirror);
+#undef GYP_STEP
+#define GYP_BCAST(CTRL, MASK) do { \
+        a += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(a), CTRL, MASK, 0xF, false)); \
+        b += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(b), CTRL, MASK, 0xF, false)); \
+        c += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(c), CTRL, MASK, 0xF, false)); \
+        d += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(d), CTRL, MASK, 0xF, false)); \
+        e += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(e), CTRL, MASK, 0xF, false)); \
+        f += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(f), CTRL, MASK, 0xF, false)); } while (0)
+    GYP_BCAST(0x142, 0xA);
+    GYP_BCAST(0x143, 0xC);
+#undef GYP_BCAST
+}
 // Best of 16 values replicated in every 16-lane row (lane & 15 indexes the value): result uniform across the wavefront.
 __device__ __forceinline__ Best row16_best(Best b) {
     b = best_step<kDppXor1>(b);

@@ -129,7 +129,7 @@ struct RedScratch {
     int32_t defer, pad3;   // 1: the last millisecond's error has not joined se / see and its ring entries are not stored yet
     double t0_next;        // start time of the next millisecond's chunk, fetched by an idle wavefront during the loop updates
     LoopConst kc;
-    struct CostasCand { double nf, nphi; cf rot1; cf step; double pscale; } cc[3];   // step: the carrier over 4096 samples (second chip of a thread)
+    struct CostasCand { double nf, nphi; cf rot1; cf step; double pad; } cc[3];   // step: the carrier over 4096 samples (second chip of a thread)
     int cand_sel, rec_sel, pad2[2];
 };
 static_assert(sizeof(RedScratch) <= kRedBytes, "reduction scratch too large");
@@ -955,46 +955,6 @@ struct CodeTables {
     const float* chipf;       // [32][2048]: +-1.0f, chipf[i] = chip[i mod 1023]
 };
 
-// (speculative kernel's provisional code loop: boundary samples gathered through the transition table)
-struct ElSample {
-    cf xl, xe;      // raw samples at (s + K*m) mod N and one before
-    int nl;         // (s + K*m) mod N, or -1: nothing to do
-    float g;        // chip[m-1] - chip[m]: +-2
-};
-// The same for a thread whose transition is fixed (sample offset K*m, or < 0: none).
-template <int K>
-__device__ __forceinline__ ElSample el_fetch_const(const cf* __restrict__ block, int sN, int off, float g) {
-    constexpr int N = K * kChips;
-    ElSample s;
-    s.nl = -1; s.g = g; s.xl = s.xe = make_float2(0.f, 0.f);
-    if (off >= 0) {
-        int nl = sN + off;
-        nl = nl >= N ? nl - N : nl;
-        s.nl = nl;
-        s.xl = block[nl];
-        s.xe = block[nl == 0 ? N - 1 : nl - 1];
-    }
-    return s;
-}
-template <int K>
-__device__ __forceinline__ void el_accumulate(const ElSample& s, double u0, double du, double (&acc)[4]) {
-    constexpr int N = K * kChips;
-    if (s.nl < 0) return;
-    const double2 cl = carrier64(u0 + du * (double)s.nl);
-    // carrier(n-1) = carrier(n) * exp(+2*pi*i*du); the sample before sample 0 is sample N-1 of the same block
-    const double2 ce = s.nl == 0 ? carrier64(u0 + du * (double)(N - 1)) : cmul64(cl, carrier64_small(-du));
-    const double2 pl = cmul64(make_double2((double)s.xl.x, (double)s.xl.y), cl);
-    const double2 pe = cmul64(make_double2((double)s.xe.x, (double)s.xe.y), ce);
-    const double g = (double)s.g;
-    acc[0] = fma(g, pe.x, acc[0]); acc[1] = fma(g, pe.y, acc[1]);
-    acc[2] = fma(g, pl.x, acc[2]); acc[3] = fma(g, pl.y, acc[3]);
-}
-// tracker.py:297 from float32 prompt value + float64 boundary sums: the speculative kernel's PROVISIONAL discriminator
-// (dll_scan_kernel re-integrates the code loop from the exact sums the verify pass forms).
-__device__ __forceinline__ double dll_discriminator(double p_re, double p_im, const double* d) {
-    const double er = p_re - d[0], ei = p_im - d[1], lr = p_re + d[2], li = p_im + d[3];
-    return ((er * er + ei * ei) - (lr * lr + li * li)) / 2.0;
-}
 // tracker.py:297, in the reference's association, from the exact sums ex = {P, d_e, d_l} (re, im each); no contraction
 // into FMAs: Python rounds every product.
 __device__ __forceinline__ double dll_discriminator_exact(const double (&ex)[6]) {
@@ -1554,21 +1514,6 @@ __device__ __forceinline__ CarrierSteps tracking_steps(double du) {
     }
 }
 
-// The wipe-off multiplies sample i of every chip by anchor * rot1^i in float32; rot1 (and, in the speculative kernel, the
-// half-block rotation that takes a thread's first carrier to its second chip) is rounded to float32, so its modulus is
-// 1 + e with |e| < 6e-8 -- the SAME e for every chip and for as long as the Doppler estimate stays put.  The prompt value P
-// comes out scaled by 1 + (K-1)/2 * e (+ e_step / 2), a bias, not noise: through Re(P conj(L - E)) it shifts the DLL
-// accumulator by bias x (net travel of the accumulator), ~1e-6 of a sample after a few hundred milliseconds, and the
-// reference's code loop dithers across integer boundaries (tracker.py:297-303), where int(self.phase) then comes out
-// different for some milliseconds (one such passage in 3e6 channel-ms surveyed).  The discriminator therefore takes P
-// times this factor, formed in float64 from the very float32 constants the wipe-off uses.
-template <int K>
-__device__ __forceinline__ double prompt_scale(cf rot1, cf step) {
-    const double e1 = fma((double)rot1.x, (double)rot1.x, (double)rot1.y * (double)rot1.y) - 1.0;      // |rot1|^2 - 1
-    const double es = fma((double)step.x, (double)step.x, (double)step.y * (double)step.y) - 1.0;
-    return 1.0 - (0.25 * (double)(K - 1)) * e1 - 0.25 * es;     // 1 / (mean_i |rot1|^i * (1 + |step|) / 2) to first order
-}
-
 // The loop updates of one millisecond of one channel, in two independent halves so that two wavefronts can run them
 // side by side (all lanes, uniform values).  Loop state lives in `red` (LDS), the history rings in `st`; the
 // millisecond's record is assembled in red->rec and written out by rec_flush.
@@ -1708,7 +1653,6 @@ __device__ __forceinline__ void costas_candidate(double inv_fs, RedScratch* red,
         const cf rot1 = make_float2((float)rot.x, (float)rot.y);
         red->cc[slot].rot1 = rot1;
         red->cc[slot].step = step;
-        red->cc[slot].pscale = prompt_scale<K>(rot1, step);
     }
 }
 // Everything else of costas_update -- histories, lock verdict, watchdog, the record's fields -- arranged so that ONLY the
@@ -1845,7 +1789,6 @@ __device__ __forceinline__ void spec_lock_verdict(const LoopParams& lp, double i
                         const cf rot1 = make_float2((float)rot.x, (float)rot.y);
                         red->cc[2].rot1 = rot1;
                         red->cc[2].step = step;
-                        red->cc[2].pscale = prompt_scale<K>(rot1, step);
                     }
                 }
             }
@@ -1908,23 +1851,19 @@ __device__ __forceinline__ void rec_flush_spec(const RedScratch* red_, gyp_track
 }
 
 // LDS of the speculative mode, after the latency variant's regions.
-constexpr int kSpecPartBytes = 4 * 512 * 8;      // el_delta partials [4][512] float64
 constexpr int kSpecEinBytes = 512 * 4;           // per-thread sample-energy partials
 constexpr int kSpecFinBytes = 256;               // fin64[8], win16 below
 constexpr int kSpecWinBytes = 32 * 8;
 constexpr int kSpecChipBytes = 2048 * 4;
-constexpr int kSpecTransBytes = kMaxTrans * 2;
 template <int K>
 constexpr int lds_bytes_spec() {
-    return lds_bytes<K>() + kTablesBytes + kSpecChipBytes + kSpecTransBytes + kSpecPartBytes + kSpecEinBytes + kSpecFinBytes + kSpecWinBytes;
+    return lds_bytes<K>() + kTablesBytes + kSpecChipBytes + kSpecEinBytes + kSpecFinBytes + kSpecWinBytes;
 }
 struct SpecLds {
     float* chipf;     // [2048] +-1.0f, this channel's code twice over
-    uint16_t* trans;  // [kMaxTrans] this channel's chip transitions
-    double* part;     // [4][512]
     float* ein_part;  // [512]
-    double* fin;      // [0..7] boundary sums, two halves each; [8..9] (as 4 floats) sample-energy quarters
-    cf* win;          // [0..7] c0 at the window lags centre-4 .. centre+3, [8..11] four partial sums of c0 at the prompt lag s
+    double* fin;      // [8..9] (as 4 floats) sample-energy halves
+    cf* win;          // [0..7] c0 at the window lags centre-4 .. centre+3, [8..11] / [12..15] four partial sums of c0 at the lags s-1 / s+1
 };
 constexpr int kSpecHalf = 4;   // window: 8 lags centre - 4 .. centre + 3 around the previous millisecond's peak lag
 
@@ -1939,13 +1878,11 @@ constexpr int kSpecHalf = 4;   // window: 8 lags centre - 4 .. centre + 3 around
 struct WinCache {
     float c[16], ch;   // window lag: chip[(lane + 64k - q) mod 1023], and the halo chip's
     int q;
-    float p[4], ph;    // prompt-lag quarter
-    int qs;
+    float e[4], eh, l[4], lh;   // the early / late lag's quarter
+    int qe, ql;
 };
 template <int K>
 __device__ __forceinline__ void spec_window(const Smem& sm, const SpecLds& sl, int centre, int sN, int tid, WinCache& wc) {
-    // (ends with this wavefront's share of the float64 boundary-sum partials: on the wavefronts that also form a prompt quarter the five
-    // reductions -- window lag re/im, prompt re/im, one float64 boundary sum -- run interleaved, see wave_sum_last_4f1d)
     static_assert(kSpecRate<K>, "one window lag per wavefront of the 512-thread workgroup");
     constexpr int N = K * kChips;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -1976,50 +1913,59 @@ __device__ __forceinline__ void spec_window(const Smem& sm, const SpecLds& sl, i
         for (int k = 0; k < 16; ++k) { ar = fmaf(wc.c[k], y[k].x, ar); ai = fmaf(wc.c[k], y[k].y, ai); }
         ar = fmaf(wc.ch, hv.x, ar); ai = fmaf(wc.ch, hv.y, ai);
     }
-    // this wavefront's float64 partials: requested now, consumed by the reduction below
-    const int pv = wave & 3, phalf = wave >> 2;
-    const double* psrc = sl.part + pv * 512 + 256 * phalf + lane;
-    const double pa0 = psrc[0], pa1 = psrc[64], pa2 = psrc[128], pa3 = psrc[192];
-    double pacc = (pa0 + pa1) + (pa2 + pa3);
     if (wave < 2) {
         ar = wave_sum_last(ar); ai = wave_sum_last(ai);
         if (lane == 63) sl.win[wave] = make_float2(ar, ai);
-        pacc = wave_sum_last(pacc);
-        if (lane == 63) sl.fin[2 * pv + phalf] = pacc;
     } else if (wave >= 6) {   // the sample energy, half per wavefront, in the same interleaved reduction
         const float* src = sl.ein_part + 256 * (wave - 6) + lane;
-        float en = (src[0] + src[64]) + (src[128] + src[192]), zero = 0.f;
-        wave_sum_last_4f1d(ar, ai, en, zero, pacc);
+        float en = (src[0] + src[64]) + (src[128] + src[192]), z0 = 0.f, z1 = 0.f, z2 = 0.f;
+        wave_sum_last_6f(ar, ai, en, z0, z1, z2);
         if (lane == 63) {
             sl.win[wave] = make_float2(ar, ai);
-            sl.fin[2 * pv + phalf] = pacc;
             reinterpret_cast<float*>(sl.fin + 8)[wave - 6] = en;
         }
-    } else {   // a quarter of the prompt lag each: chips j = lane + 64*(4*pq + k); quarter 0 adds the halo terms
-        const int pq = wave - 2;     // (wavefronts 0 and 1 prepare the loop updates meanwhile, 6 and 7 sum the sample energy)
+    } else {
+        // The PROVISIONAL code loop's two taps, c0[s-1] and c0[s+1] (tracker.py:289-295), a quarter each on wavefronts 2..5:
+        // chips j = lane + 64*(4*pq + k); quarter 0 adds the halo terms.  (Wavefronts 0 and 1 prepare the loop updates
+        // meanwhile, 6 and 7 sum the sample energy.)  float32 is enough here: the loop is re-integrated from float64 sums
+        // afterwards (dll_exact / dll_scan) -- nothing float64 sits on the serial path any more.
+        const int pq = wave - 2;
         const int ss = __builtin_amdgcn_readfirstlane(sN);
-        const int rs = ss % K, qs = ss / K;
-        if (qs != wc.qs) {
-            const float* cp = sl.chipf + (kChips - qs) + lane + 256 * pq;
+        const int se = ss == 0 ? N - 1 : ss - 1, sl_ = ss + 1 == N ? 0 : ss + 1;
+        const int re = se % K, qe = se / K, rl = sl_ % K, ql = sl_ / K;
+        if (qe != wc.qe) {
+            const float* cp = sl.chipf + (kChips - qe) + lane + 256 * pq;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) wc.p[k] = cp[64 * k];
-            wc.ph = (on && pq == 0) ? sl.chipf[jf - qs + kChips] : 0.f;
-            wc.qs = qs;
+            for (int k = 0; k < 4; ++k) wc.e[k] = cp[64 * k];
+            wc.eh = (on && pq == 0) ? sl.chipf[jf - qe + kChips] : 0.f;
+            wc.qe = qe;
         }
-        const cf* rowp = sm.xch + rs * kXchWave + lane + 256 * pq;
-        float pr = 0.f, pi = 0.f;
+        if (ql != wc.ql) {
+            const float* cp = sl.chipf + (kChips - ql) + lane + 256 * pq;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wc.l[k] = cp[64 * k];
+            wc.lh = (on && pq == 0) ? sl.chipf[jf - ql + kChips] : 0.f;
+            wc.ql = ql;
+        }
+        const cf* rowe = sm.xch + re * kXchWave + lane + 256 * pq;
+        const cf* rowl = sm.xch + rl * kXchWave + lane + 256 * pq;
+        cf ye[4], yl[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ye[k] = rowe[64 * k]; yl[k] = rowl[64 * k]; }
+        const cf he = sm.halo[hrow + re], hl = sm.halo[hrow + rl];
+        float er = 0.f, ei = 0.f, lr = 0.f, li = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const cf y = rowp[64 * k];
-            pr = fmaf(wc.p[k], y.x, pr); pi = fmaf(wc.p[k], y.y, pi);
+            er = fmaf(wc.e[k], ye[k].x, er); ei = fmaf(wc.e[k], ye[k].y, ei);
+            lr = fmaf(wc.l[k], yl[k].x, lr); li = fmaf(wc.l[k], yl[k].y, li);
         }
-        const cf hv = sm.halo[hrow + rs];
-        pr = fmaf(wc.ph, hv.x, pr); pi = fmaf(wc.ph, hv.y, pi);
-        wave_sum_last_4f1d(ar, ai, pr, pi, pacc);
+        er = fmaf(wc.eh, he.x, er); ei = fmaf(wc.eh, he.y, ei);
+        lr = fmaf(wc.lh, hl.x, lr); li = fmaf(wc.lh, hl.y, li);
+        wave_sum_last_6f(ar, ai, er, ei, lr, li);
         if (lane == 63) {
             sl.win[wave] = make_float2(ar, ai);
-            sl.win[2 * kSpecHalf + pq] = make_float2(pr, pi);
-            sl.fin[2 * pv + phalf] = pacc;
+            sl.win[2 * kSpecHalf + pq] = make_float2(er, ei);          // [8..11] early-lag quarters
+            sl.win[2 * kSpecHalf + 4 + pq] = make_float2(lr, li);      // [12..15] late-lag quarters
         }
     }
 }
@@ -2074,8 +2020,6 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
     if (SPEC) {
         char* b = smem_raw + lds_bytes<K>() + kTablesBytes;
         sl.chipf = reinterpret_cast<float*>(b); b += kSpecChipBytes;
-        sl.trans = reinterpret_cast<uint16_t*>(b); b += kSpecTransBytes;
-        sl.part = reinterpret_cast<double*>(b); b += kSpecPartBytes;
         sl.ein_part = reinterpret_cast<float*>(b); b += kSpecEinBytes;
         sl.fin = reinterpret_cast<double*>(b); b += kSpecFinBytes;
         sl.win = reinterpret_cast<cf*>(b);
@@ -2097,12 +2041,9 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
     const int sat_index = __builtin_amdgcn_readfirstlane(st->sat_id) - 1;
     const cf* rep = replica_of(p.replica_table, sat_index);
     const cf* stream = p.iq + (int64_t)__builtin_amdgcn_readfirstlane(st->stream) * p.stream_stride;
-    const uint16_t* trans = p.codes.trans + sat_index * kMaxTrans;
-    const int nt = p.codes.n_trans[sat_index];
     if (SPEC) {
         const float* src = p.codes.chipf + sat_index * 2048;
         for (int i = threadIdx.x; i < 2048; i += kThreadsHere) sl.chipf[i] = src[i];
-        for (int i = threadIdx.x; i < kMaxTrans; i += kThreadsHere) sl.trans[i] = trans[i];
     }
     // Loop state lives in LDS between milliseconds (RedScratch::dstate / istate / steps / loop) and is re-read where
     // it is needed, so that no wavefront carries it in registers across the transforms.
@@ -2121,7 +2062,6 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
         sm.red->cc[0].nf = st->doppler; sm.red->cc[0].nphi = st->carrier_phase;
         sm.red->cc[0].rot1 = sm.red->steps.rot1;
         sm.red->cc[0].step = carrier_from_cycles_fast(st->doppler * p.inv_fs * (double)(K * kSpecThreads));
-        sm.red->cc[0].pscale = prompt_scale<K>(sm.red->cc[0].rot1, sm.red->cc[0].step);
         sm.red->cand_sel = 0; sm.red->rec_sel = 0;
         sm.red->defer = 0;
         if (SPEC && p.ms_begin < p.ms_end) sm.red->t0_next = p.start_time[p.ms_begin];
@@ -2140,16 +2080,8 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
     if constexpr (LAT) {
         if (p.ms_begin < p.ms_end) stage_fetch_own<K>(stream + (int64_t)p.ms_begin * N, smp, launder(threadIdx.x));
     }
-    // speculative mode: this thread's chip transitions (sample offset K*m, coefficient +-2), fixed for the whole launch
     WinCache wcache;
-    wcache.q = -1; wcache.qs = -1;
-    int el_off0 = -1, el_off1 = -1;
-    float el_g0 = 0.f, el_g1 = 0.f;
-    if constexpr (SPEC) {
-        const int e0 = launder(threadIdx.x), e1 = e0 + kSpecThreads;
-        if (e0 < nt) { const unsigned t = trans[e0]; el_off0 = K * (int)(t & 0x3ffu); el_g0 = (t & 0x8000u) ? -2.0f : 2.0f; }
-        if (e1 < nt) { const unsigned t = trans[e1]; el_off1 = K * (int)(t & 0x3ffu); el_g1 = (t & 0x8000u) ? -2.0f : 2.0f; }
-    }
+    wcache.q = -1; wcache.qe = -1; wcache.ql = -1;
     bool have_prev = false;   // speculative mode: the previous millisecond's record (and possibly its histories) await completion
     for (int ms = p.ms_begin; ms < p.ms_end; ++ms) {
         gyp_track_rec* rec = p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + ms : nullptr;
@@ -2157,7 +2089,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
         // wipe-off; wavefront 5 fetched the value into LDS during the previous millisecond's loop updates)
         const double t0 = SPEC ? launder_lds(sm.red)->t0_next : p.start_time[launder(ms)];
         if (!SPEC && have_prev) {   // the previous millisecond's record (complete since the barrier that ended it)
-            if (wave == 1) rec_flush(sm.red, rec ? rec - 1 : nullptr, lane);
+            if (wave == (Geom<K>::W >= 2 ? 1 : 0)) rec_flush(sm.red, rec ? rec - 1 : nullptr, lane);
             have_prev = false;
         }
         if (sm.red->istate[1]) {  // a dropped channel stays dropped until the host re-creates it (receiver.py:259-267)
@@ -2185,15 +2117,12 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
         double f, phi;
         CarrierSteps cs;
         cf half_step = make_float2(1.f, 0.f);
-        double pscale;        // see prompt_scale
         if constexpr (SPEC) {
             const auto cand = sm.red->cc[sm.red->cand_sel];
             f = cand.nf; phi = cand.nphi; cs.rot1 = cand.rot1; cs.rot_wrap = make_float2(1.f, 0.f);
             half_step = cand.step;
-            pscale = cand.pscale;
         } else {
             f = sm.red->dstate[0]; phi = sm.red->dstate[1]; cs = sm.red->steps;
-            pscale = 1.0;   // (unused here)
         }
         {
             const int code_phase = sm.red->istate[0];
@@ -2204,13 +2133,8 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
                 const int sN = mod_n(code_phase, N);
                 asm volatile("; MARK_STAGE_BEGIN");
                 GYP_STAMP(0);
-                // the boundary samples of the float64 early/late sums are requested first, consumed after the staging
                 if (wave == 0) leave[0] = fetch_leaving_error(st, sm.red);
                 if (wave == 1) fetch_leaving_peak(st, sm.red, leave[1], leave[2]);
-                const ElSample el0 = el_fetch_const<K>(block, sN, el_off0, el_g0);
-                ElSample el1;
-                el1.nl = -1;
-                if (nt > kSpecThreads) el1 = el_fetch_const<K>(block, sN, el_off1, el_g1);   // uniform
                 GYP_STAMP(1);
                 // (the last thread's second chip is the padding chip: its registers hold a copy of chip 1022, see stage_fetch_own)
                 const bool chip1 = tid + kSpecThreads < kChips;
@@ -2230,11 +2154,6 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
                     stage_emit_own_anchored<K>(smp, anchor, cs, y_rows, sm.halo, tid);
                 }
                 GYP_STAMP(2);
-                double acc[4] = {0.0, 0.0, 0.0, 0.0};
-                el_accumulate<K>(el0, u0, du, acc);
-                if (nt > kSpecThreads && __any(el1.nl >= 0)) el_accumulate<K>(el1, u0, du, acc);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) sl.part[v * kSpecThreads + tid] = acc[v];
                 sl.ein_part[tid] = e_in;
                 asm volatile("; MARK_STAGE_END");
                 GYP_STAMP(3);
@@ -2296,10 +2215,11 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
                     next_centre = r.best.key + sN;
                     next_centre = next_centre >= N ? next_centre - N : next_centre;
                 }
-                if (wave == 1) {   // the code loop runs beside the Costas loop (wavefront 0)
-                    const cf p0 = sl.win[2 * kSpecHalf], p1 = sl.win[2 * kSpecHalf + 1], p2 = sl.win[2 * kSpecHalf + 2], p3 = sl.win[2 * kSpecHalf + 3];
-                    const double d[4] = {sl.fin[0] + sl.fin[1], sl.fin[2] + sl.fin[3], sl.fin[4] + sl.fin[5], sl.fin[6] + sl.fin[7]};
-                    m.disc = dll_discriminator((double)((p0.x + p1.x) + (p2.x + p3.x)) * pscale, (double)((p0.y + p1.y) + (p2.y + p3.y)) * pscale, d) + p.prov_bias;   // PROVISIONAL: dll_scan_kernel re-integrates the loop exactly
+                if (wave == 1) {   // the (provisional) code loop runs beside the Costas loop (wavefront 0): tracker.py:297 from float32 taps
+                    const cf* w = sl.win + 2 * kSpecHalf;
+                    const float er = (w[0].x + w[1].x) + (w[2].x + w[3].x), ei = (w[0].y + w[1].y) + (w[2].y + w[3].y);
+                    const float lr = (w[4].x + w[5].x) + (w[6].x + w[7].x), li = (w[4].y + w[5].y) + (w[6].y + w[7].y);
+                    m.disc = (((double)er * (double)er + (double)ei * (double)ei) - ((double)lr * (double)lr + (double)li * (double)li)) / 2.0 + p.prov_bias;
                 }
                 if (wave == 3 && lane == 0) {
                     SpecIn si;
@@ -2345,6 +2265,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
             // the code loop, the record's measurement fields.  The record leaves for global memory at the top of the next
             // millisecond (rec_flush by wavefront 1), off this path too.
             RedScratch* red = launder_lds(sm.red);
+            constexpr int kW = Geom<K>::W;          // (rates whose workgroup has fewer than three wavefronts double up)
             if (wave == 0) {
                 const long long u0_ = prof ? (long long)__builtin_readcyclecounter() : 0;
                 fetch_leaving(st, red, leave);
@@ -2352,11 +2273,9 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
                 const long long u1_ = prof ? (long long)__builtin_readcyclecounter() : 0;
                 costas_update<K, false>(red->kc, st, red, t0, lane, m, leave);
                 if (prof) { tp[6] += u1_ - u0_; tp[8] += (long long)__builtin_readcyclecounter() - u1_; }
-            } else if (wave == 1) {
-                dll_update(red, m.disc, lane, red->kc.lp);
-            } else if (wave == 2) {
-                spec_record_fields<K>(red, m, lane);
             }
+            if (wave == (kW >= 2 ? 1 : 0)) dll_update(red, m.disc, lane, red->kc.lp);
+            if (wave == (kW >= 3 ? 2 : 0)) spec_record_fields<K>(red, m, lane);
             have_prev = true;
         }
         asm volatile("; MARK_UPDATE_END");
@@ -2374,7 +2293,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
         if (wave == 0) spec_error_side(st, sm.red, 0.0, lane, sm.red->kc.lp);
         if (wave == 1) rec_flush_spec(sm.red, p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + (p.ms_end - 1) : nullptr, lane);
     }
-    if (!SPEC && have_prev && wave == 1) rec_flush(sm.red, p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + (p.ms_end - 1) : nullptr, lane);
+    if (!SPEC && have_prev && wave == (Geom<K>::W >= 2 ? 1 : 0)) rec_flush(sm.red, p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + (p.ms_end - 1) : nullptr, lane);
     if (threadIdx.x == 0) {
         st->doppler = SPEC ? sm.red->cc[sm.red->cand_sel].nf : sm.red->dstate[0];
         st->carrier_phase = SPEC ? sm.red->cc[sm.red->cand_sel].nphi : sm.red->dstate[1];
