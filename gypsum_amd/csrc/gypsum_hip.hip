@@ -136,6 +136,7 @@ struct gyp_ctx {
     int comm_rank = 0, comm_world = 1;
     gyp_params params;
     bool no_spec = false;        // GYP_NO_SPEC=1: A/B switch: lightly loaded banks use the throughput kernel too
+    int spec_fail_at = -1;       // GYP_SPEC_FAIL_AT=ms (test hook): channel 0's verification is made to fail at that millisecond of a block
     bool spec_debug = false;     // GYP_SPEC_DEBUG=1: per-ms window dump of the speculative tracker (gyp_debug_spec_read)
     double dll_prov_bias = 0.0;  // GYP_DLL_PROV_BIAS=x (test hook): added to the speculative kernel's PROVISIONAL discriminator, so
                                  // that dll_scan_kernel's repair path runs; results must not depend on it
@@ -161,6 +162,8 @@ struct gyp_bank {
     DllExact* d_dllx = nullptr;  // [n_chan] the exactly re-integrated code loop between sub-blocks
     size_t spec_cap = 0;         // in records
     int32_t* d_bad = nullptr;
+    int32_t* d_bad_from = nullptr;   // per channel: first verify sub-block that failed
+    DllExact* d_hist = nullptr;      // [kMaxSub][n_chan] the exact code loop at the sub-block starts
     float* d_dbg = nullptr;      // GYP_SPEC_DEBUG: per-ms window dump of the last block
     size_t dbg_cap = 0;
     hipStream_t verify_stream = nullptr;
@@ -319,6 +322,7 @@ int gyp_create(int device_ordinal, gyp_ctx** out) {
     ctx->no_spec = std::getenv("GYP_NO_SPEC") != nullptr;
     ctx->spec_debug = std::getenv("GYP_SPEC_DEBUG") != nullptr;
     if (const char* b = std::getenv("GYP_DLL_PROV_BIAS")) ctx->dll_prov_bias = std::atof(b);
+    if (const char* b = std::getenv("GYP_SPEC_FAIL_AT")) ctx->spec_fail_at = std::atoi(b);
     gyp_params_default(&ctx->params);
     if (const char* kv = std::getenv("GYP_SPEC_KAPPA")) ctx->params.spec_confidence_kappa = std::atof(kv);
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -1053,6 +1057,8 @@ void gyp_bank_destroy(gyp_bank* bank) {
     if (bank->d_disc) (void)hipFree(bank->d_disc);
     if (bank->d_dllx) (void)hipFree(bank->d_dllx);
     if (bank->d_bad) (void)hipFree(bank->d_bad);
+    if (bank->d_bad_from) (void)hipFree(bank->d_bad_from);
+    if (bank->d_hist) (void)hipFree(bank->d_hist);
     if (bank->d_dbg) (void)hipFree(bank->d_dbg);
     if (bank->verify_stream) { (void)hipStreamSynchronize(bank->verify_stream); (void)hipStreamDestroy(bank->verify_stream); }
     if (bank->ev_spec) (void)hipEventDestroy(bank->ev_spec);
@@ -1118,7 +1124,7 @@ static DllExactParams dll_exact_params(gyp_bank* bank, const TrackBlockParams& p
     DllExactParams x;
     x.iq = p.iq; x.stream_stride = p.stream_stride; x.n_ms = p.n_ms; x.ms_begin = 0; x.ms_end = p.n_ms; x.start_time = p.start_time;
     x.states = bank->d_states; x.n_chan = bank->n_chan; x.spec = bank->d_spec; x.disc_out = bank->d_disc; x.chipf = ctx->d_chipf;
-    x.inv_fs = p.inv_fs; x.only_if = nullptr;
+    x.inv_fs = p.inv_fs; x.only_if = nullptr; x.from_sub = nullptr; x.sub_len = 0;
     return x;
 }
 static DllScanParams dll_scan_params(gyp_bank* bank, const TrackBlockParams& p) {
@@ -1128,25 +1134,27 @@ static DllScanParams dll_scan_params(gyp_bank* bank, const TrackBlockParams& p) 
     d.states = bank->d_states; d.ckpt = nullptr; d.n_chan = bank->n_chan; d.spec = bank->d_spec; d.disc = bank->d_disc;
     d.rec_out = p.rec_out; d.exact = bank->d_dllx; d.bad = nullptr; d.only_bad = 0; d.chipf = ctx->d_chipf;
     d.inv_fs = p.inv_fs; d.dll_gain = p.lp.dll_gain; d.dll_modulus = p.lp.dll_modulus; d.n_samples = p.lp.n_samples;
-    d.first = 1; d.final = 1;
+    d.first = 1; d.final = 1; d.from_sub = nullptr; d.sub_len = 0; d.hist_out = nullptr;
     return d;
 }
 
 // The throughput tracking kernel with its code loop re-integrated exactly behind it (same stream).  only_if / restore_from: the
 // re-run of channels whose speculation failed verification.
-static int track_block_throughput(gyp_bank* bank, TrackBlockParams p, const int32_t* only_if, const ChanState* restore_from) {
+static int track_block_throughput(gyp_bank* bank, TrackBlockParams p, const int32_t* only_if, const ChanState* restore_from,
+                                  const int32_t* from_sub = nullptr, const DllExact* exact_hist = nullptr, int sub_len = 0) {
     gyp_ctx* ctx = bank->ctx;
     int rc;
     if ((rc = ensure_dll_buffers(bank, (size_t)bank->n_chan * p.n_ms))) return rc;
     p.ms_begin = 0; p.ms_end = p.n_ms;
     p.spec_out = bank->d_spec; p.exact0 = bank->d_dllx; p.dbg = nullptr;
     p.only_if = only_if; p.restore_from = restore_from;
+    p.from_sub = from_sub; p.exact_hist = exact_hist; p.sub_len = sub_len;
     if ((rc = launch_track_block(ctx, p, 0))) return rc;
     DllExactParams x = dll_exact_params(bank, p);
-    x.only_if = only_if;
+    x.only_if = only_if; x.from_sub = from_sub; x.sub_len = sub_len;
     if ((rc = launch_dll_exact(ctx, x, ctx->stream))) return rc;
     DllScanParams d = dll_scan_params(bank, p);
-    d.bad = only_if; d.only_bad = only_if ? 1 : 0;
+    d.bad = only_if; d.only_bad = only_if ? 1 : 0; d.from_sub = from_sub; d.sub_len = sub_len;
     return launch_dll_scan(ctx, d, ctx->stream);
 }
 
@@ -1155,22 +1163,26 @@ static int track_block_throughput(gyp_bank* bank, TrackBlockParams p, const int3
 // stream while the next sub-block is being tracked, and its code loop is re-integrated there (dll_exact + dll_scan); channels
 // that failed verification are re-run from the checkpoint by the transform kernel.  Everything is enqueued; nothing
 // synchronises with the host.
+static constexpr int kMaxSub = 16;
 static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
     gyp_ctx* ctx = bank->ctx;
     const size_t n_rec = (size_t)bank->n_chan * p.n_ms;
     int rc;
     if (!bank->d_ckpt) {
-        HIP_TRY(ctx, hipMalloc((void**)&bank->d_ckpt, (size_t)bank->n_chan * sizeof(ChanState)));
+        HIP_TRY(ctx, hipMalloc((void**)&bank->d_ckpt, (size_t)kMaxSub * bank->n_chan * sizeof(ChanState)));
         HIP_TRY(ctx, hipMalloc((void**)&bank->d_bad, (size_t)bank->n_chan * sizeof(int32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&bank->d_bad_from, (size_t)bank->n_chan * sizeof(int32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&bank->d_hist, (size_t)kMaxSub * bank->n_chan * sizeof(DllExact)));
         HIP_TRY(ctx, hipStreamCreateWithFlags(&bank->verify_stream, hipStreamNonBlocking));
         HIP_TRY(ctx, hipEventCreateWithFlags(&bank->ev_spec, hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&bank->ev_verify, hipEventDisableTiming));
     }
     if ((rc = ensure_dll_buffers(bank, n_rec))) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(bank->d_ckpt, bank->d_states, (size_t)bank->n_chan * sizeof(ChanState), hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(bank->d_bad, 0, (size_t)bank->n_chan * sizeof(int32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)bank->d_bad_from, 0x7fffffff, (size_t)bank->n_chan, ctx->stream));
     p.spec_out = bank->d_spec;
     p.exact0 = nullptr;
+    p.from_sub = nullptr; p.exact_hist = nullptr; p.sub_len = 0;
     p.spec_kappa = (float)ctx->params.spec_confidence_kappa;
     if (ctx->spec_debug) {
         if (bank->dbg_cap < n_rec * 20) {
@@ -1183,15 +1195,20 @@ static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
     TrackVerifyParams v;
     v.iq = p.iq; v.stream_stride = p.stream_stride; v.n_ms = p.n_ms; v.start_time = p.start_time;
     v.states = bank->d_states; v.n_chan = bank->n_chan; v.spec = bank->d_spec; v.rec_out = p.rec_out; v.bad = bank->d_bad;
+    v.bad_from = bank->d_bad_from; v.force_fail_ms = ctx->spec_fail_at;
     v.replica_table = ctx->d_replicas; v.tw_tables = ctx->d_tw; v.inv_fs = p.inv_fs; v.tie_tol = 4e-6f;
     DllExactParams x = dll_exact_params(bank, p);
     DllScanParams d = dll_scan_params(bank, p);
     d.ckpt = bank->d_ckpt; d.bad = bank->d_bad; d.only_bad = 0;
     // the last sub-block's verification trails the tracking (1.9 ms for 2500 ms x 12 channels): more, shorter sub-blocks
-    // for long blocks (each launch re-reads the channel state and the tables: ~20 us)
-    const int n_sub = p.n_ms >= 4096 ? 16 : (p.n_ms >= 256 ? 4 : 1);
+    // for long blocks (each launch re-reads the channel state and the tables: ~20 us).  Every sub-block starts from a checkpoint
+    // of the channel states (18 KB per channel) so that a failed verification costs a re-run from that sub-block, not the block.
+    const int n_sub = p.n_ms >= 4096 ? kMaxSub : (p.n_ms >= 256 ? 4 : 1);
     const int sub = (p.n_ms + n_sub - 1) / n_sub;
-    for (int b0 = 0; b0 < p.n_ms; b0 += sub) {
+    int j = 0;
+    for (int b0 = 0; b0 < p.n_ms; b0 += sub, ++j) {
+        HIP_TRY(ctx, hipMemcpyAsync(bank->d_ckpt + (size_t)j * bank->n_chan, bank->d_states, (size_t)bank->n_chan * sizeof(ChanState),
+                                    hipMemcpyDeviceToDevice, ctx->stream));
         p.ms_begin = b0;
         p.ms_end = std::min(p.n_ms, b0 + sub);
         if ((rc = launch_track_block(ctx, p, 2))) return rc;
@@ -1199,18 +1216,20 @@ static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
         HIP_TRY(ctx, hipStreamWaitEvent(bank->verify_stream, bank->ev_spec, 0));
         v.ms_begin = p.ms_begin;
         v.ms_end = p.ms_end;
+        v.sub_index = j;
         if ((rc = launch_track_verify(ctx, v, bank->verify_stream))) return rc;
         x.ms_begin = p.ms_begin; x.ms_end = p.ms_end;
         if ((rc = launch_dll_exact(ctx, x, bank->verify_stream))) return rc;
         d.ms_begin = p.ms_begin; d.ms_end = p.ms_end; d.first = b0 == 0 ? 1 : 0; d.final = p.ms_end == p.n_ms ? 1 : 0;
+        d.hist_out = p.ms_end < p.n_ms ? bank->d_hist + (size_t)(j + 1) * bank->n_chan : nullptr;
         if ((rc = launch_dll_scan(ctx, d, bank->verify_stream))) return rc;
     }
     HIP_TRY(ctx, hipEventRecord(bank->ev_verify, bank->verify_stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, bank->ev_verify, 0));
-    // channels whose window maximum was not the global one (never observed on real signals; any count is handled): the whole
-    // block again from the checkpoint through the transform kernel, their code loop re-integrated behind it
+    // channels whose window maximum was not the global one somewhere (any count is handled): again from the checkpoint of the
+    // sub-block in which that happened, through the transform kernel, their code loop re-integrated behind it
     p.dbg = nullptr;
-    return track_block_throughput(bank, p, bank->d_bad, bank->d_ckpt);
+    return track_block_throughput(bank, p, bank->d_bad, bank->d_ckpt, bank->d_bad_from, bank->d_hist, sub);
 }
 
 int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stride_samples, int32_t n_ms,
@@ -1254,6 +1273,7 @@ int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stri
     p.prov_bias = ctx->dll_prov_bias;
     p.only_if = nullptr;
     p.restore_from = nullptr;
+    p.from_sub = nullptr; p.exact_hist = nullptr; p.sub_len = 0;
     p.dbg = nullptr;
     const bool light = (ctx->k == 8 || ctx->k == 2) && p.n_chan <= ctx->n_cus && !ctx->no_pipe;   // one workgroup per CU anyway
     if (light && !ctx->no_spec) return track_block_speculative(bank, p);

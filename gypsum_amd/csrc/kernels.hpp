@@ -183,10 +183,14 @@ __device__ __forceinline__ void transform_staged(const Smem& sm, const cf* __res
 }
 
 // One millisecond block, round rho: stage (all wavefronts) -> barrier -> per-wavefront correlation.
+// `pre` (halo-free staging only): the block's raw samples, already requested by the caller (the throughput block kernel asks for
+// the next millisecond's while the loop update runs); null: fetched here.
 template <int K>
+struct PreSamples { typedef OwnSamples<kOwnStaging<K> ? K : 1> type; };
+template <int K, bool HAVE_PRE = false>
 __device__ __forceinline__ void correlate_round(const cf* __restrict__ block, int rho, double u0, double du,
                                                 const CarrierSteps& cs, const Smem& sm,
-                                                const cf* __restrict__ rep_table_sat, cf (&c)[16]) {
+                                                const cf* __restrict__ rep_table_sat, cf (&c)[16], typename PreSamples<K>::type& pre) {
     constexpr int W = Geom<K>::W;
     const int tid = launder(threadIdx.x);
     if constexpr (kOwnStaging<K>) {
@@ -194,9 +198,13 @@ __device__ __forceinline__ void correlate_round(const cf* __restrict__ block, in
             cf* y_all[K];
 #pragma unroll
             for (int r = 0; r < K; ++r) y_all[r] = sm.xch + r * kXchWave;
-            OwnSamples<K> smp;
-            stage_fetch_own<K>(block, smp, tid);
-            stage_emit_own<K>(smp, u0, du, cs, y_all, sm.halo, tid);
+            if constexpr (HAVE_PRE) {   // (by reference and decided at compile time: the samples must stay in registers)
+                stage_emit_own<K>(pre, u0, du, cs, y_all, sm.halo, tid);
+            } else {
+                OwnSamples<K> smp;
+                stage_fetch_own<K>(block, smp, tid);
+                stage_emit_own<K>(smp, u0, du, cs, y_all, sm.halo, tid);
+            }
         }
         transform_staged<K, true>(sm, rep_table_sat, c, tid, rho * W, rho == 0);
     } else {
@@ -207,6 +215,14 @@ __device__ __forceinline__ void correlate_round(const cf* __restrict__ block, in
         else stage_general<K, W>(block, 1, rho, u0, 0.0, du, cs, y_rows, tid);
         transform_staged<K>(sm, rep_table_sat, c, tid);
     }
+}
+
+template <int K>
+__device__ __forceinline__ void correlate_round(const cf* __restrict__ block, int rho, double u0, double du,
+                                                const CarrierSteps& cs, const Smem& sm,
+                                                const cf* __restrict__ rep_table_sat, cf (&c)[16]) {
+    typename PreSamples<K>::type none;
+    correlate_round<K, false>(block, rho, u0, du, cs, sm, rep_table_sat, c, none);
 }
 
 // Coherent integration of n_blocks millisecond blocks, round rho, with ONE transform (pre-folded inputs).
@@ -1165,10 +1181,10 @@ __device__ __forceinline__ EplResult epl_finish(const LaneStats& ls, RedScratch*
 // `probe`: one more lag (0 <= probe < N) whose complex value is returned in EplResult::probe.
 // WANT_EX (gyp_track_step): also the code loop's three lags in float64 (EplResult::ex), by a pass of the workgroup over the
 // block (exact_epl_generic).  The block kernels do not ask for it: their code loop is re-integrated from dll_exact_*_kernel.
-template <int K, bool WANT_EX = false>
+template <int K, bool WANT_EX = false, bool HAVE_PRE = false>
 __device__ __forceinline__ EplResult track_ms(const cf* __restrict__ block, double u0, double du, const CarrierSteps& cs,
                                               int code_phase, int probe, const Smem& sm, const cf* __restrict__ rep, float* profile_row,
-                                              const float* chipf = nullptr) {
+                                              const float* chipf, typename PreSamples<K>::type& pre) {
     constexpr int N = K * kChips;
     const int s = mod_n(code_phase, N);
     auto generic_ex = [&]() {
@@ -1181,7 +1197,7 @@ __device__ __forceinline__ EplResult track_ms(const cf* __restrict__ block, doub
     };
     if constexpr (Geom<K>::R == 1) {
         cf c[16];
-        correlate_round<K>(block, 0, u0, du, cs, sm, rep, c);
+        correlate_round<K, HAVE_PRE>(block, 0, u0, du, cs, sm, rep, c, pre);
         epl_round_wave<K>(c, s, probe, sm.red, profile_row, launder(threadIdx.x));
         generic_ex();
         return epl_finish_wave<K, WANT_EX>(sm.red);
@@ -1193,7 +1209,7 @@ __device__ __forceinline__ EplResult track_ms(const cf* __restrict__ block, doub
 #pragma unroll 1
         for (int rho = 0; rho < Geom<K>::R; ++rho) {
             cf c[16];
-            correlate_round<K>(block, rho, u0, du, cs, sm, rep, c);
+            correlate_round<K, HAVE_PRE>(block, rho, u0, du, cs, sm, rep, c, pre);
             epl_round<K>(c, rho, s, probe, ls, sm.red, profile_row, launder(threadIdx.x));
         }
         generic_ex();
@@ -1208,6 +1224,14 @@ __device__ __forceinline__ EplResult track_ms(const cf* __restrict__ block, doub
     }
     generic_ex();
     return epl_finish<K, WANT_EX>(ls, sm.red, launder(threadIdx.x));
+}
+
+template <int K, bool WANT_EX = false>
+__device__ __forceinline__ EplResult track_ms(const cf* __restrict__ block, double u0, double du, const CarrierSteps& cs,
+                                              int code_phase, int probe, const Smem& sm, const cf* __restrict__ rep, float* profile_row,
+                                              const float* chipf = nullptr) {
+    typename PreSamples<K>::type none;
+    return track_ms<K, WANT_EX, false>(block, u0, du, cs, code_phase, probe, sm, rep, profile_row, chipf, none);
 }
 
 template <int K>
@@ -1453,9 +1477,15 @@ struct TrackBlockParams {
     float spec_kappa;          // window peak^2 must reach spec_kappa * (energy of the millisecond's samples)
     double prov_bias;          // test hook: added to the provisional discriminator (see dll_scan_kernel)
     DllExact* exact0;          // throughput path: the code loop's state before this launch is left here for dll_scan_kernel
-    // re-run mode: only channels with only_if[ch] != 0 run, after restoring their state from restore_from[ch]
+    // re-run mode: only channels with only_if[ch] != 0 run, after restoring their state from a checkpoint.  A block of the
+    // speculative tracker is checkpointed at the start of every verify sub-block: channel ch restarts at sub-block
+    // j = from_sub[ch] (the first one in which its verification failed) from restore_from[j * n_chan + ch], with the EXACT code
+    // loop of that point (exact_hist[j * n_chan + ch]; j == 0: the checkpoint's own), at millisecond j * sub_len.
     const int32_t* only_if;
     const ChanState* restore_from;
+    const int32_t* from_sub;
+    const DllExact* exact_hist;
+    int32_t sub_len;
     float* dbg;                // optional [n_chan][n_ms][20]: |window|^2 x 16, sample energy, code phase mod N, 0, 0 (debug)
 };
 
@@ -2030,10 +2060,19 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
     const int ch = xcd_contiguous(blockIdx.x, p.n_chan);
     if (p.only_if && !p.only_if[ch]) return;
     ChanState* st = p.states + ch;
-    if (p.restore_from) {   // re-run of a channel whose speculation failed verification: back to the state before the block
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(p.restore_from + ch);
+    int ms_first = p.ms_begin;
+    if (p.restore_from) {   // re-run of a channel whose speculation failed verification: back to the checkpoint before the failure
+        const int j = p.from_sub ? min(p.from_sub[ch], (p.n_ms - 1) / max(p.sub_len, 1)) : 0;
+        ms_first = p.from_sub ? j * p.sub_len : p.ms_begin;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(p.restore_from + (size_t)j * p.n_chan + ch);
         uint32_t* dst = reinterpret_cast<uint32_t*>(st);
         for (int i = threadIdx.x; i < (int)(sizeof(ChanState) / 4); i += kThreadsHere) dst[i] = src[i];
+        __threadfence();
+        __syncthreads();
+        if (j > 0 && p.exact_hist && threadIdx.x == 0) {   // (the checkpoint carries the serial kernel's provisional code loop)
+            const DllExact x = p.exact_hist[(size_t)j * p.n_chan + ch];
+            st->dll_phase = x.dll; st->code_phase = x.code_phase;
+        }
         __threadfence();
         __syncthreads();
     }
@@ -2077,17 +2116,35 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
     // speculative mode: tp[6 + i] accumulates the cycles between stamp i-1 and stamp i of workgroup 0's thread 0
 #define GYP_STAMP(i) do { if (prof) { const long long now_ = (long long)__builtin_readcyclecounter(); tp[6 + (i)] += now_ - t_last; t_last = now_; } } while (0)
     OwnSamples<LAT ? K : 1, LAT ? kSpecThreads : 64> smp;   // LAT: the next millisecond's raw samples
+    // Throughput form, halo-free staging: the next millisecond's raw samples are requested while the loop update runs -- by
+    // wavefronts 1.. before they wait at the millisecond's last barrier, by wavefront 0 behind its update (so the 2 x K sample
+    // registers are never live across the update's own register needs) -- instead of at the top of the millisecond with every
+    // wavefront waiting for them.
+    // (Both forms measured and switched off: at the 128-register budget the allocator parks the requested samples in scratch
+    // memory between the request and the wipe-off -- 78 ms per launch against 58 -- and a TOUCH of one dword per 64-byte line of
+    // the next millisecond, to pull the lines into L2 / L1 under the update, costs more in extra address traffic than the
+    // latency it hides -- 60.1 against 58.4.  With two workgroups per CU the other workgroup already covers the wait.)
+    constexpr bool PRE = false;
+    constexpr bool TOUCH = false;
+    float touch = 0.f;
+    typename PreSamples<K>::type pre;
+    if constexpr (PRE) {
+        if (ms_first < p.ms_end && !sm.red->istate[1]) stage_fetch_own<K>(stream + (int64_t)ms_first * N, pre, launder(threadIdx.x));
+    }
     if constexpr (LAT) {
         if (p.ms_begin < p.ms_end) stage_fetch_own<K>(stream + (int64_t)p.ms_begin * N, smp, launder(threadIdx.x));
     }
     WinCache wcache;
     wcache.q = -1; wcache.qe = -1; wcache.ql = -1;
     bool have_prev = false;   // speculative mode: the previous millisecond's record (and possibly its histories) await completion
-    for (int ms = p.ms_begin; ms < p.ms_end; ++ms) {
+    for (int ms = ms_first; ms < p.ms_end; ++ms) {   // (ms_first == p.ms_begin except in a re-run from a later checkpoint)
         gyp_track_rec* rec = p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + ms : nullptr;
         // (speculative mode: a load issued here would be waited for -- a few hundred cycles -- by the first carrier of the
         // wipe-off; wavefront 5 fetched the value into LDS during the previous millisecond's loop updates)
         const double t0 = SPEC ? launder_lds(sm.red)->t0_next : p.start_time[launder(ms)];
+        if constexpr (TOUCH) {   // (never true: it only keeps the touched values -- and the wait for them -- in the program)
+            if (touch == 1.2345e38f && p.dbg) p.dbg[0] = touch;
+        }
         if (!SPEC && have_prev) {   // the previous millisecond's record (complete since the barrier that ended it)
             if (wave == (Geom<K>::W >= 2 ? 1 : 0)) rec_flush(sm.red, rec ? rec - 1 : nullptr, lane);
             have_prev = false;
@@ -2234,7 +2291,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
                     si.doppler = f; si.carrier_phase = phi; si.code_phase = code_phase; si.key = kSpecKeyTransform;
                     p.spec_out[(int64_t)ch * p.n_ms + ms] = si;
                 }
-                const EplResult r = track_ms<K>(block, u0, du, cs, code_phase, mod_n(code_phase, N), sm, rep, nullptr);
+                const EplResult r = track_ms<K, false, PRE>(block, u0, du, cs, code_phase, mod_n(code_phase, N), sm, rep, nullptr, nullptr, pre);
                 if (prof) t_b = (long long)__builtin_readcyclecounter();
                 m.peak = r.peak; m.peak_mag = r.best.v; m.key = r.best.key; m.sum = r.sum; m.n_max = r.n_max;
                 m.strength_pending = false;
@@ -2276,12 +2333,22 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
             }
             if (wave == (kW >= 2 ? 1 : 0)) dll_update(red, m.disc, lane, red->kc.lp);
             if (wave == (kW >= 3 ? 2 : 0)) spec_record_fields<K>(red, m, lane);
+            if constexpr (PRE) {   // (wavefront 0 gets here behind its update; a channel the watchdog has just dropped asks for samples nobody uses)
+                if (ms + 1 < p.ms_end) stage_fetch_own<K>(stream + (int64_t)(ms + 1) * N, pre, launder(threadIdx.x));
+            }
+            if constexpr (TOUCH) {
+                if (ms + 1 < p.ms_end) {
+                    const cf* nb = stream + (int64_t)(ms + 1) * N;
+                    const int t_ = launder(threadIdx.x);
+                    touch = nb[K * t_].x + nb[K * min(t_ + Geom<K>::kThreads, kChips - 1)].x;
+                }
+            }
             have_prev = true;
         }
         asm volatile("; MARK_UPDATE_END");
         long long t_d = prof ? (long long)__builtin_readcyclecounter() : 0;
         GYP_STAMP(9);
-        if constexpr (SPEC) lds_barrier(); else __syncthreads();
+        if constexpr (SPEC || PRE || TOUCH) lds_barrier(); else __syncthreads();   // (LDS traffic only: the sample requests / touches stay in flight)
         if (SPEC) have_prev = true;   // the record is flushed by wavefront 1 in the next window phase (or after the loop)
         if (prof) {
             const long long t_e = (long long)__builtin_readcyclecounter();
@@ -2323,10 +2390,13 @@ struct TrackVerifyParams {
     const SpecIn* spec;
     gyp_track_rec* rec_out;
     int32_t* bad;
+    int32_t* bad_from;         // per channel: the first verify sub-block in which a verification failed (INT_MAX: none)
+    int32_t sub_index;         // which sub-block this launch covers
     const cf* replica_table;
     const cf* tw_tables;
     double inv_fs;
     float tie_tol;
+    int32_t force_fail_ms;     // test hook (GYP_SPEC_FAIL_AT): channel 0's verification "fails" at this millisecond; < 0: off
 };
 
 template <int K>
@@ -2350,10 +2420,12 @@ __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void 
         probe = probe >= N ? probe - N : probe;
         const EplResult r = track_ms<K>(block, u0, du, carrier_steps<K>(du), in.code_phase, probe, sm, rep, nullptr);
         if (threadIdx.x == 0) {
+            bool failed = ch == 0 && ms == p.force_fail_ms;
             if (r.best.key != in.key) {
                 const float vp = fmaf(r.probe.x, r.probe.x, r.probe.y * r.probe.y), vm = r.best.v * r.best.v;
-                if (!(vp >= vm * (1.0f - p.tie_tol))) p.bad[ch] = 1;
+                failed = failed || !(vp >= vm * (1.0f - p.tie_tol));
             }
+            if (failed) { p.bad[ch] = 1; atomicMin(p.bad_from + ch, p.sub_index); }
             if (p.rec_out) {
                 const float mean_excl = (float)((r.sum - (double)r.n_max * (double)r.best.v) / (double)(N - r.n_max));
                 p.rec_out[(int64_t)ch * p.n_ms + ms].strength = r.best.v / mean_excl;
@@ -2387,7 +2459,9 @@ struct DllExactParams {
     double* disc_out;          // [n_chan][n_ms]
     const float* chipf;        // CodeTables::chipf
     double inv_fs;
-    const int32_t* only_if;    // optional: only channels with only_if[ch] != 0 (the re-run of failed speculations)
+    const int32_t* only_if;    // optional: only channels with only_if[ch] != 0 (the re-run of failed speculations) ...
+    const int32_t* from_sub;   // ... and of those only the milliseconds from sub-block from_sub[ch] on (sub_len milliseconds each)
+    int32_t sub_len;
 };
 
 // acc * w + x  (complex): one Horner step of sum_i x_i w^i
@@ -2472,6 +2546,7 @@ __global__ __launch_bounds__(256, GYP_EXACT_OCC) void dll_exact_wave_kernel(DllE
         if (u >= n_units) continue;
         const int ms = p.ms_begin + u / p.n_chan, ch = u % p.n_chan;
         if (p.only_if && !p.only_if[ch]) continue;                // wave-uniform
+        if (p.from_sub && ms < p.from_sub[ch] * p.sub_len) continue;
         const int64_t at = (int64_t)ch * p.n_ms + ms;
         const SpecIn in = p.spec[at];
         if (in.key == kSpecKeyLost) continue;                     // wave-uniform
@@ -2508,6 +2583,7 @@ __global__ __launch_bounds__(256) void dll_exact_block_kernel(DllExactParams p) 
         const int u = (n_units & 7) ? v : xcd_contiguous(v, n_units);
         const int ms = p.ms_begin + u / p.n_chan, ch = u % p.n_chan;
         if (p.only_if && !p.only_if[ch]) continue;                // uniform
+        if (p.from_sub && ms < p.from_sub[ch] * p.sub_len) continue;
         const int64_t at = (int64_t)ch * p.n_ms + ms;
         const SpecIn in = p.spec[at];
         if (in.key == kSpecKeyLost) continue;                     // uniform
@@ -2548,6 +2624,9 @@ struct DllScanParams {
     DllExact* exact;
     const int32_t* bad;        // optional per-channel flags of failed speculations ...
     int32_t only_bad;          // ... 0: flagged channels are left alone (the re-run gives them everything); 1: ONLY flagged ones (after it)
+    const int32_t* from_sub;   // only_bad: the re-run started at sub-block from_sub[ch] (sub_len milliseconds each)
+    int32_t sub_len;
+    DllExact* hist_out;        // optional: the loop's state at the end of this launch's range is also left here (the next sub-block's checkpoint)
     const float* chipf;
     double inv_fs, dll_gain, dll_modulus, n_samples;
     int32_t first, final;
@@ -2580,7 +2659,8 @@ __global__ __launch_bounds__(kScanThreads) void dll_scan_kernel(DllScanParams p)
     const float* chipf = p.chipf + (st->sat_id - 1) * 2048;
     const cf* stream = p.iq + (int64_t)st->stream * p.stream_stride;
     const int64_t row = (int64_t)ch * p.n_ms;
-    for (int c0 = p.ms_begin; c0 < p.ms_end; c0 += kScanChunk) {
+    const int ms_first = (p.only_bad && p.from_sub) ? max(p.ms_begin, min(p.from_sub[ch], (p.n_ms - 1) / max(p.sub_len, 1)) * p.sub_len) : p.ms_begin;
+    for (int c0 = ms_first; c0 < p.ms_end; c0 += kScanChunk) {
         const int len = min(kScanChunk, p.ms_end - c0);
         for (int i = tid; i < len; i += kScanThreads) {
             const SpecIn* in = p.spec + row + c0 + i;
@@ -2698,6 +2778,7 @@ __global__ __launch_bounds__(kScanThreads) void dll_scan_kernel(DllScanParams p)
     if (tid == 0) {
         DllExact x; x.dll = s_a; x.code_phase = s_s; x.repairs = s_repairs;
         p.exact[ch] = x;
+        if (p.hist_out) p.hist_out[ch] = x;
         if (p.final) { p.states[ch].dll_phase = s_a; p.states[ch].code_phase = s_s; }
     }
 }

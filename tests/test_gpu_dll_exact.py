@@ -202,3 +202,29 @@ def test_failed_speculation_is_recovered_bit_for_bit():
     for i in np.nonzero(bad == 0)[0]:                        # the others stayed on the speculative path and agree on every integer
         for f in ("code_phase", "peak_offset", "pseudosymbol", "locked"):
             assert np.array_equal(rec_s[i][f], rec_t[i][f]), (i, f)
+
+
+def test_a_failed_verification_reruns_from_its_sub_block_only():
+    """Blocks of the speculative tracker are verified in sub-blocks, each starting from a checkpoint: a verification failure
+    in sub-block j (forced here for channel 0 at ms 250 of a 400-ms block = 4 sub-blocks of 100) sends that channel back
+    through the transform kernel from ms 200 on -- not from ms 0 -- and every integer still equals the transform kernel's."""
+    fs, n = 8_184_000, 8184
+    n_ms = 409
+    iq, inits = _scene_and_inits(fs, n, n_ms, 4, 5150)
+    eng_t = _engine_with_env(fs, n, GYP_NO_SPEC=1)
+    rec_t, st_t, _, _ = _bank_run(eng_t, iq, inits, n, fs, n_ms)
+    eng_t.close()
+    eng_s = _engine_with_env(fs, n, GYP_SPEC_FAIL_AT=250)
+    rec_s, st_s, _, bad = _bank_run(eng_s, iq, inits, n, fs, n_ms)
+    eng_s.close()
+    assert bad.tolist() == [1, 0, 0, 0]
+    fast = (rec_s["path_info"] & 3) == 1
+    assert fast[0, :200].mean() > 0.9 and not fast[0, 200:].any()      # channel 0: speculative up to its checkpoint, transform kernel after
+    assert fast[1:].mean() > 0.9                                        # the others never left the speculative path
+    for f in ("code_phase", "peak_offset", "pseudosymbol", "locked"):
+        assert np.array_equal(rec_s[f], rec_t[f]), f
+    np.testing.assert_allclose(rec_s["discriminator"], rec_t["discriminator"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(rec_s["peak_re"], rec_t["peak_re"], rtol=0, atol=2e-5 * np.abs(rec_t["peak_re"]).max())
+    for key in ("code_phase", "lost"):
+        assert np.array_equal(st_s[key], st_t[key]), key
+    np.testing.assert_allclose(st_s["doppler_hz"], st_t["doppler_hz"], rtol=0, atol=1e-5)
