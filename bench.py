@@ -368,6 +368,9 @@ def run_cfg3(eng, comm, args, rng) -> dict:
     # --- per-kernel device time (HIP events on the engine's stream), outside the timed region
     reps = max(2, min(args.steps, 5))
     trk_ms = acq_ms = 0.0
+    k3 = np.zeros(3)                     # {track_block_kernel, dll_exact kernel, dll_scan_kernel}: HIP events around each launch
+    t3 = np.zeros(3, dtype=np.float32)
+    eng._check(eng.lib.gyp_debug_track_timing(eng.ctx, 1, None))
     for i in range(reps):
         eng.timer_start()
         eng.acquire_dev(su.iq.ptr.value, A, su.stride, 10, ALL_IDS, acq_send.ptr.value)
@@ -376,8 +379,14 @@ def run_cfg3(eng, comm, args, rng) -> dict:
         eng.timer_start()
         su.bank.track_block_dev(su.iq.ptr.value, su.stride, T, su.t_dev.ptr.value, su.rec_dev.ptr.value if su.rec_dev else 0)
         trk_ms += eng.timer_stop()
+        eng._check(eng.lib.gyp_debug_track_timing(eng.ctx, 1, _lib.ptr(t3)))
+        k3 += t3
+    eng._check(eng.lib.gyp_debug_track_timing(eng.ctx, 0, None))
     trk_ms /= reps
     acq_ms /= reps
+    k3 /= reps
+    if not k3[0] > 0:                    # (a lightly loaded bank takes the speculative path: no per-kernel split there)
+        k3[0] = trk_ms
     # the same scans with gyp_params::acq_reuse_level_records = 0 (every bin of every level correlated again, as the reference does
     # with its cache lookup switched off, acquisition.py:204): bit-identical results, reported beside the default
     eng.set_params(acq_reuse_level_records=0.0)
@@ -408,8 +417,13 @@ def run_cfg3(eng, comm, args, rng) -> dict:
                    "parallelism": f"streams sharded over {comm.world} GPU(s), one ncclAllGather of acquisition records per step "
                                   f"issued by the library (gyp_allgather_dev)"},
         "samples_per_step": B * T * n, "elapsed": elapsed, "fs": fs, "streams_total": B * comm.world,
-        "dominant": {"kernel": "track_block_kernel<8>", "ms": trk_ms, "flops": f_trk * B * T, "bytes": (8 * n + 64 * C_) * B * T},
+        "dominant": {"kernel": "track_block_kernel<8, false, 0>", "ms": float(k3[0]), "flops": f_trk * B * T, "bytes": (8 * n + 64 * C_) * B * T},
         "extra": {"acquire_ms_per_step": round(acq_ms, 3), "track_ms_per_step": round(trk_ms, 3),
+                  "track_kernels_ms_per_step": {"track_block_kernel<8, false, 0>": round(float(k3[0]), 3),
+                                                "dll_exact_wave_kernel<8> (float64 code-loop sums)": round(float(k3[1]), 3),
+                                                "dll_scan_kernel<8> (code loop re-integrated)": round(float(k3[2]), 3),
+                                                "how": "hipEvents on the library's stream around each launch (gyp_debug_track_timing), mean of the "
+                                                       f"{reps} repetitions outside the timed region"},
                   "acquire_ms_per_stream_32sat": round(acq_ms / A, 3),
                   "acquire_ms_per_step_without_level_record_reuse": round(acq_noreuse_ms, 3),
                   "level_record_reuse_gives_identical_results": same,
@@ -721,13 +735,16 @@ def summarise(result: dict, world: int, steps: int) -> dict:
 
 
 def measured_traffic(workload: str):
-    """HBM bytes per launch of the dominant kernel from this round's rocprofv3 --pmc passes (profiles/pmc_latest.json,
-    written by tools/profile_round.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes), or None."""
+    """HBM bytes per launch of the dominant kernel from this round's rocprofv3 --pmc passes (profiles/pmc_latest.json, written by
+    tools/summarize_profile.py from a tools/gpu_visit.sh pmc visit; counters corrected with the factors the calibration
+    microbenchmark tools/fetch_calib.hip measured for this kernel's access pattern), or None.  Also returns the record itself
+    (kernel time during the counter pass, commit) so that a stale file shows."""
     pmc = REPO / "profiles" / "pmc_latest.json"
     try:
-        return json.loads(pmc.read_text()).get(workload, {}).get("hbm_bytes_per_launch")
+        rec = json.loads(pmc.read_text()).get(workload, {})
+        return rec.get("hbm_bytes_per_launch"), rec
     except Exception:
-        return None
+        return None, {}
 
 
 def spawn_ranks(n: int, argv: list) -> int:
@@ -871,6 +888,7 @@ def main() -> None:
             result["samples_per_step"] * args.steps * (1 if result.get("divide_by_world") else world)
         value = total_samples / elapsed / 1e6
         dom = result["dominant"]
+        traffic, traffic_rec = measured_traffic(result["workload_name"])
         line = {
             "metric": "iq_msamples_per_s_32sat_acquire_plus_track" if result["workload_name"] == "cfg3" else "iq_msamples_per_s_32sat_acquisition_grid",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -883,9 +901,13 @@ def main() -> None:
             "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "traffic": measured_traffic(result["workload_name"]),
+                         "traffic": traffic,
                          "traffic_source": "profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload "
-                                           "(tools/profile_round.sh), not collected inside this run",
+                                           "(tools/gpu_visit.sh pmc), counters corrected by the factors tools/fetch_calib.hip measured for "
+                                           "this access pattern; not collected inside this run",
+                         "traffic_record": {k: traffic_rec.get(k) for k in ("commit", "kernel_ms_during_counter_pass", "fetch_factor", "write_factor")},
+                         "traffic_stale": (bool(traffic_rec.get("kernel_ms_during_counter_pass")) and
+                                           abs(traffic_rec["kernel_ms_during_counter_pass"] / dom["ms"] - 1.0) > 0.15) if traffic_rec else None,
                          "note": "algorithmic bytes (IQ read once + result records) / kernel time; this FFT/pointwise path "
                                  "is FP32-VALU/LDS bound, see roofline_valu"},
             "roofline_valu": {"bound": "fp32_valu", "kernel": dom["kernel"],

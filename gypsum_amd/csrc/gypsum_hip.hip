@@ -142,6 +142,9 @@ struct gyp_ctx {
                                  // that dll_scan_kernel's repair path runs; results must not depend on it
     // (the GYP_* environment switches are read ONCE, in gyp_create: no getenv on a hot entry point)
     long long* d_prof = nullptr; // debug: per-phase cycle counters of track_block workgroup 0
+    // gyp_debug_track_timing: HIP events around the three launches of the throughput tracking path (tracking kernel, exact sums, scan)
+    bool time_track = false;
+    hipEvent_t ev_track[4] = {nullptr, nullptr, nullptr, nullptr};
     // growable scratch for the host-buffer entry points and the acquisition driver
     static constexpr int kScratchSlots = 10;
     void* scratch[kScratchSlots] = {};
@@ -349,6 +352,7 @@ void gyp_destroy(gyp_ctx* ctx) {
     if (ctx->d_ntrans) (void)hipFree(ctx->d_ntrans);
     if (ctx->d_chipf) (void)hipFree(ctx->d_chipf);
     if (ctx->d_prof) (void)hipFree(ctx->d_prof);
+    for (int i = 0; i < 4; ++i) if (ctx->ev_track[i]) (void)hipEventDestroy(ctx->ev_track[i]);
     if (ctx->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->comm);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -1149,13 +1153,19 @@ static int track_block_throughput(gyp_bank* bank, TrackBlockParams p, const int3
     p.spec_out = bank->d_spec; p.exact0 = bank->d_dllx; p.dbg = nullptr;
     p.only_if = only_if; p.restore_from = restore_from;
     p.from_sub = from_sub; p.exact_hist = exact_hist; p.sub_len = sub_len;
+    const bool timed = ctx->time_track && !only_if;
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_track[0], ctx->stream));
     if ((rc = launch_track_block(ctx, p, 0))) return rc;
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_track[1], ctx->stream));
     DllExactParams x = dll_exact_params(bank, p);
     x.only_if = only_if; x.from_sub = from_sub; x.sub_len = sub_len;
     if ((rc = launch_dll_exact(ctx, x, ctx->stream))) return rc;
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_track[2], ctx->stream));
     DllScanParams d = dll_scan_params(bank, p);
     d.bad = only_if; d.only_bad = only_if ? 1 : 0; d.from_sub = from_sub; d.sub_len = sub_len;
-    return launch_dll_scan(ctx, d, ctx->stream);
+    if ((rc = launch_dll_scan(ctx, d, ctx->stream))) return rc;
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_track[3], ctx->stream));
+    return GYP_OK;
 }
 
 // Speculative block tracking (8.184 / 2.046 Msps, at most one channel per CU): the tracking kernel advances on window maxima
@@ -1476,6 +1486,18 @@ int gyp_debug_track_profile(gyp_ctx* ctx, int enable, long long* out8) {
         HIP_TRY(ctx, hipMemcpy(out8, ctx->d_prof, 16 * sizeof(long long), hipMemcpyDeviceToHost));
     }
     if (!enable && ctx->d_prof) { HIP_TRY(ctx, hipFree(ctx->d_prof)); ctx->d_prof = nullptr; }
+    return GYP_OK;
+}
+
+int gyp_debug_track_timing(gyp_ctx* ctx, int enable, float* out3) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    if (enable && !ctx->ev_track[0])
+        for (int i = 0; i < 4; ++i) HIP_TRY(ctx, hipEventCreate(&ctx->ev_track[i]));
+    if (out3 && ctx->time_track && ctx->ev_track[0]) {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev_track[3]));
+        for (int i = 0; i < 3; ++i) HIP_TRY(ctx, hipEventElapsedTime(out3 + i, ctx->ev_track[i], ctx->ev_track[i + 1]));
+    }
+    ctx->time_track = enable != 0;
     return GYP_OK;
 }
 

@@ -481,10 +481,13 @@ int gyp_debug_track_profile(gyp_ctx* ctx, int enable, long long* out16);
  * (previous peak lag - 4 .. + 3), 8 zeros, the sample-energy estimate, code_phase mod N, the window centre, 0.  bad_out (may be NULL): per
  * channel, 1 if the verify pass sent the channel back through the transform kernel.  Synchronises the stream. */
 int gyp_debug_spec_read(gyp_bank* bank, float* out, int32_t n_floats, int32_t* bad_out);
-/* Debug / telemetry (speculative block tracker): repairs_out[n_chan] = milliseconds of the last gyp_track_block(_dev) call in
- * which the exactly re-integrated code loop (dll_scan_kernel) had int(self.phase) differ from the tracking kernel's provisional
- * one and formed that millisecond's float64 sums again for the right lag.  Zeros for banks on the throughput kernel (its code
- * loop is exact in line).  Synchronises the stream. */
+/* Debug / measurement: HIP events on the context's stream around the three launches behind gyp_track_block(_dev) on the
+ * throughput path (banks of more than one channel per CU): enable != 0 arms it; out3 (may be NULL) receives the durations of the
+ * last call in ms: {track_block_kernel, dll_exact kernel, dll_scan_kernel}.  bench.py's per-kernel roofline uses it. */
+int gyp_debug_track_timing(gyp_ctx* ctx, int enable, float* out3);
+/* Debug / telemetry (either tracking path): repairs_out[n_chan] = milliseconds of the last gyp_track_block(_dev) call in which
+ * the exactly re-integrated code loop (dll_scan_kernel) had int(self.phase) differ from the tracking kernel's provisional one
+ * and formed that millisecond's float64 sums again for the right lag.  Synchronises the stream. */
 int gyp_debug_dll_read(gyp_bank* bank, int32_t* repairs_out);
 /* Debug: time `iters` forward+inverse wavefront transform pairs per wavefront, `wgs` workgroups of `waves_per_wg`
  * wavefronts (LDS-resident data, no global traffic): the floor the correlator kernels are measured against. */

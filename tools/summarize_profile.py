@@ -1,60 +1,93 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/prof_<tag>/ (see tools/profile_round.sh) into the committed evidence under profiles/."""
+"""Condense a tools/gpu_visit.sh visit (steps bench / kt / pmc, plus tools/fetch_calib.sh) under gpurun_out/<tag>/ into the
+committed evidence under profiles/:  <tag>_bench_cfg3.json, <tag>_bench_cfg3_kernel_stats.csv, <tag>_pmc_summary.json,
+<tag>_fetch_calibration.txt and pmc_latest.json (what bench.py's roofline.traffic reads).
+    python tools/summarize_profile.py <tag>"""
 import collections
 import csv
 import json
+import re
 import shutil
+import subprocess
 import sys
 from pathlib import Path
 
 REPO = Path(__file__).resolve().parents[1]
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-src = REPO / "gpurun_out" / f"prof_{tag}"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+src = REPO / "gpurun_out" / tag
 dst = REPO / "profiles"
 dst.mkdir(exist_ok=True)
 
 
 def pmc(dirname):
+    """kernel -> counter -> {mean_per_launch, launches}; and kernel -> mean launch duration in ms during that pass"""
     out = collections.defaultdict(lambda: collections.defaultdict(list))
-    f = src / dirname / "bench_counter_collection.csv"
-    if not f.exists():
-        return {}
-    for r in csv.DictReader(open(f)):
-        out[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: {c: {"mean_per_launch": sum(v) / len(v), "launches": len(v)} for c, v in cs.items()} for k, cs in out.items()}
+    dur = collections.defaultdict(list)
+    for f in (src / dirname).rglob("*counter_collection.csv"):
+        seen = set()
+        for r in csv.DictReader(open(f)):
+            out[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if r["Dispatch_Id"] not in seen:
+                seen.add(r["Dispatch_Id"])
+                dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
+    return ({k: {c: {"mean_per_launch": sum(v) / len(v), "launches": len(v)} for c, v in cs.items()} for k, cs in out.items()},
+            {k: sum(v) / len(v) for k, v in dur.items()})
 
 
-summary = {"tag": tag, "commands": "tools/profile_round.sh (rocprofv3 --kernel-trace --stats; --pmc passes separately)"}
-for wl in ("cfg3", "cfg2"):
-    ks = src / f"kt_{wl}" / "bench_kernel_stats.csv"
-    if ks.exists():
-        shutil.copy(ks, dst / f"{tag}_bench_{wl}_kernel_stats.csv")
-    b = src / f"bench_{wl}.json"
-    if b.exists() and b.read_text().strip():
-        shutil.copy(b, dst / f"{tag}_bench_{wl}.json")
-    entry = {}
-    for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        for k, v in pmc(f"pmc_{c}_{wl}").items():
-            entry.setdefault(k, {}).update(v)
-    summary[wl] = entry
-ks = src / "kt_single" / "bench_kernel_stats.csv"
-if ks.exists():
-    shutil.copy(ks, dst / f"{tag}_single_stream_kernel_stats.csv")
-for name in ("pmc_sq1_cfg3", "pmc_sq2_cfg3"):
-    for k, v in pmc(name).items():
-        summary.setdefault("sq_cfg3", {}).setdefault(k, {}).update(v)
+summary = {"tag": tag, "commands": "tools/gpu_visit.sh <tag> bench kt pmc (rocprofv3 --kernel-trace --stats; every --pmc set in a pass of its own: "
+                                   "bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1) + tools/fetch_calib.sh"}
+for name, out_name in (("bench_cfg3.json", f"{tag}_bench_cfg3.json"), ("fetch_calibration.txt", f"{tag}_fetch_calibration.txt")):
+    if (src / name).exists() and (src / name).read_text().strip():
+        shutil.copy(src / name, dst / out_name)
+for f in (src / "kt_cfg3").rglob("*kernel_stats.csv"):
+    shutil.copy(f, dst / f"{tag}_bench_cfg3_kernel_stats.csv")
+
+# calibration factors: bytes moved per counted byte, for the tracking kernel's read / write patterns
+factor = {"read_contiguous": 2.0, "read_staging": 2.0, "read_windows": 1.0, "write_records": 1.0, "write_contiguous": 1.0}
+cal = src / "fetch_calibration.txt"
+if cal.exists():
+    for line in cal.read_text().splitlines():
+        m = re.match(r"(\w+)\s+\w+: counted .* multiply the counter by ([0-9.]+)", line)
+        if m:
+            factor[m.group(1)] = float(m.group(2))
+summary["calibration_factors"] = factor
+
+entry, durs = {}, {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    vals, d = pmc(f"pmc_{c}")
+    for k, v in vals.items():
+        entry.setdefault(k, {}).update(v)
+    durs.update(d)
+summary["cfg3"] = {k: v for k, v in entry.items() if "gyp::" in k}
+for name in ("pmc_sq1", "pmc_sq2"):
+    vals, _ = pmc(name)
+    for k, v in vals.items():
+        if "gyp::" in k:
+            summary.setdefault("sq_cfg3", {}).setdefault(k, {}).update(v)
 json.dump(summary, open(dst / f"{tag}_pmc_summary.json", "w"), indent=1)
 
-# HBM bytes per launch of the dominant kernels, corrected as MI355X_MICROARCH.md prescribes:
-# FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of a wide coalesced stream -> x2.
+try:
+    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=REPO, capture_output=True, text=True).stdout.strip()
+except Exception:
+    commit = None
 latest = {}
-for wl, needle in (("cfg3", "track_block_kernel"), ("cfg2", "grid_cells_wave_pipe_kernel<2>")):
-    for k, v in summary.get(wl, {}).items():
-        if needle in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-            fetch, write = v["FETCH_SIZE"]["mean_per_launch"], v["WRITE_SIZE"]["mean_per_launch"]
-            latest[wl] = {"kernel": k, "fetch_kb_raw": fetch, "write_kb_raw": write,
-                          "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
-                          "correction": "FETCH_SIZE x2 (gfx950 wide-coalesced under-report), WRITE_SIZE uncorrected; "
-                                        "the PMC passes ran bench.py --steps 2 --warmup 1 with the default stream count"}
+for k, v in entry.items():
+    if "track_block_kernel<8, false, 0>" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        fetch, write = v["FETCH_SIZE"]["mean_per_launch"], v["WRITE_SIZE"]["mean_per_launch"]
+        ff, wf = factor["read_staging"], factor["write_records"]
+        latest["cfg3"] = {"kernel": k, "fetch_kb_raw": fetch, "write_kb_raw": write, "fetch_factor": ff, "write_factor": wf,
+                          "hbm_bytes_per_launch": (ff * fetch + wf * write) * 1024.0,
+                          "kernel_ms_during_counter_pass": durs.get(k), "commit": commit, "tag": tag,
+                          "correction": "FETCH_SIZE / WRITE_SIZE are in KB; factors = bytes moved per counted byte measured by "
+                                        "tools/fetch_calib.hip for this kernel's patterns (16 B per lane at a 64-byte lane stride: "
+                                        "read_staging; 56-byte records written dword by dword: write_records)"}
+    if "dll_exact_wave_kernel<8>" in k and "FETCH_SIZE" in v:
+        latest["cfg3_dll_exact"] = {"kernel": k, "fetch_kb_raw": v["FETCH_SIZE"]["mean_per_launch"], "fetch_factor": factor["read_windows"],
+                                    "hbm_bytes_per_launch": factor["read_windows"] * v["FETCH_SIZE"]["mean_per_launch"] * 1024.0,
+                                    "kernel_ms_during_counter_pass": durs.get(k)}
 json.dump(latest, open(dst / "pmc_latest.json", "w"), indent=1)
 print(json.dumps(latest, indent=1))
+sq = summary.get("sq_cfg3", {})
+for k, v in sq.items():
+    if "track_block_kernel<8, false, 0>" in k or "dll_exact" in k:
+        print(k[:60], {c: round(x["mean_per_launch"]) for c, x in v.items()})
