@@ -471,9 +471,10 @@ def run_single_stream(eng, eng2, steps: int = 10, warmup: int = 2) -> dict:
         "channels_rerun_by_the_verify_pass": su.bad_channels(),
         "symbol_agreement_ok_fraction": su.symbol_agreement(rec),
         "channels_lost": int(su.bank.state()["lost"].sum()),
-        "method": "speculative tracker: window correlations around the last peak lag + float64 early/late boundary sums on "
-                  "the serial path (one CU per channel), every millisecond's full profile verified by track_verify_kernel "
-                  "in parallel inside the timed region",
+        "method": "speculative tracker: window correlations around the last peak lag and a float32 code loop on the serial "
+                  "path (one CU per channel); every millisecond's full profile verified by track_verify_kernel and the "
+                  "code loop re-integrated in float64 (dll_exact_wave_kernel + dll_scan_kernel) per sub-block on a second "
+                  "stream, all inside the timed region",
     }
     su.bank.close()
     return out
