@@ -171,6 +171,11 @@ struct gyp_bank {
     size_t dbg_cap = 0;
     hipStream_t verify_stream = nullptr;
     hipEvent_t ev_spec = nullptr, ev_verify = nullptr;
+    // gyp_bank_keep_profiles: the last call's trailing prompt profiles (tracker.py:154,308-309)
+    float* d_prof_tail = nullptr;    // [n_chan][prof_depth][n]
+    int32_t* d_prof_delta = nullptr; // [n_chan][prof_depth] exact - provisional code phase (repaired milliseconds only)
+    int prof_depth = 0;
+    int prof_rows = 0;               // rows valid after the last gyp_track_block(_dev)
 };
 
 // RCCL, resolved at run time (see the multi-GPU section of the C ABI below)
@@ -572,7 +577,8 @@ static int launch_track_block_t(gyp_ctx* ctx, const TrackBlockParams& p, int mod
 }
 // mode 0: throughput kernel; 2: latency form + speculation (at most one workgroup per CU)
 static int launch_track_block(gyp_ctx* ctx, const TrackBlockParams& p, int mode) {
-    return p.prof ? launch_track_block_t<true>(ctx, p, mode) : launch_track_block_t<false>(ctx, p, mode);
+    // (the instrumented instantiation also carries the optional profile rows: the fast one stays free of both)
+    return (p.prof || p.prof_tail) ? launch_track_block_t<true>(ctx, p, mode) : launch_track_block_t<false>(ctx, p, mode);
 }
 static int launch_track_verify(gyp_ctx* ctx, const TrackVerifyParams& p, hipStream_t stream) {
     const int n_units = p.n_chan * (p.ms_end - p.ms_begin);
@@ -1064,6 +1070,8 @@ void gyp_bank_destroy(gyp_bank* bank) {
     if (bank->d_bad_from) (void)hipFree(bank->d_bad_from);
     if (bank->d_hist) (void)hipFree(bank->d_hist);
     if (bank->d_dbg) (void)hipFree(bank->d_dbg);
+    if (bank->d_prof_tail) (void)hipFree(bank->d_prof_tail);
+    if (bank->d_prof_delta) (void)hipFree(bank->d_prof_delta);
     if (bank->verify_stream) { (void)hipStreamSynchronize(bank->verify_stream); (void)hipStreamDestroy(bank->verify_stream); }
     if (bank->ev_spec) (void)hipEventDestroy(bank->ev_spec);
     if (bank->ev_verify) (void)hipEventDestroy(bank->ev_verify);
@@ -1139,6 +1147,7 @@ static DllScanParams dll_scan_params(gyp_bank* bank, const TrackBlockParams& p) 
     d.rec_out = p.rec_out; d.exact = bank->d_dllx; d.bad = nullptr; d.only_bad = 0; d.chipf = ctx->d_chipf;
     d.inv_fs = p.inv_fs; d.dll_gain = p.lp.dll_gain; d.dll_modulus = p.lp.dll_modulus; d.n_samples = p.lp.n_samples;
     d.first = 1; d.final = 1; d.from_sub = nullptr; d.sub_len = 0; d.hist_out = nullptr;
+    d.prof_delta = p.prof_tail ? bank->d_prof_delta : nullptr; d.prof_from = p.prof_from; d.prof_depth = p.prof_depth;
     return d;
 }
 
@@ -1285,9 +1294,58 @@ int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stri
     p.restore_from = nullptr;
     p.from_sub = nullptr; p.exact_hist = nullptr; p.sub_len = 0;
     p.dbg = nullptr;
+    p.prof_tail = nullptr; p.prof_from = 0; p.prof_depth = 0;
+    if (bank->prof_depth > 0) {   // profiles kept: the transform kernel forms every millisecond's full profile anyway
+        bank->prof_rows = std::min(bank->prof_depth, (int)n_ms);
+        p.prof_tail = bank->d_prof_tail; p.prof_from = n_ms - bank->prof_rows; p.prof_depth = bank->prof_depth;
+        HIP_TRY(ctx, hipMemsetAsync(bank->d_prof_delta, 0, (size_t)bank->n_chan * bank->prof_depth * sizeof(int32_t), ctx->stream));
+        return track_block_throughput(bank, p, nullptr, nullptr);
+    }
     const bool light = (ctx->k == 8 || ctx->k == 2) && p.n_chan <= ctx->n_cus && !ctx->no_pipe;   // one workgroup per CU anyway
     if (light && !ctx->no_spec) return track_block_speculative(bank, p);
     return track_block_throughput(bank, p, nullptr, nullptr);
+}
+
+int gyp_bank_keep_profiles(gyp_bank* bank, int32_t depth) {
+    if (!bank) return GYP_E_BAD_ARG;
+    gyp_ctx* ctx = bank->ctx;
+    if (depth < 0 || depth > 4096) return fail(ctx, GYP_E_BAD_ARG, "gyp_bank_keep_profiles: depth must be in 0..4096");
+    if (depth == bank->prof_depth) return GYP_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (bank->d_prof_tail) { hipFree(bank->d_prof_tail); bank->d_prof_tail = nullptr; }
+    if (bank->d_prof_delta) { hipFree(bank->d_prof_delta); bank->d_prof_delta = nullptr; }
+    bank->prof_depth = 0; bank->prof_rows = 0;
+    if (depth == 0) return GYP_OK;
+    const size_t rows = (size_t)bank->n_chan * depth;
+    if (hipMalloc((void**)&bank->d_prof_tail, rows * bank->n * sizeof(float)) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ctx, GYP_E_NOMEM, "gyp_bank_keep_profiles: " + std::to_string(rows * bank->n * sizeof(float)) + " bytes of profile rows do not fit");
+    }
+    HIP_TRY(ctx, hipMalloc((void**)&bank->d_prof_delta, rows * sizeof(int32_t)));
+    bank->prof_depth = depth;
+    return GYP_OK;
+}
+
+int gyp_bank_read_profiles(gyp_bank* bank, int32_t channel, float* out, int32_t* n_rows_out) {
+    if (!bank || !n_rows_out) return GYP_E_BAD_ARG;
+    gyp_ctx* ctx = bank->ctx;
+    if (channel < 0 || channel >= bank->n_chan) return fail(ctx, GYP_E_BAD_ARG, "gyp_bank_read_profiles: no such channel");
+    *n_rows_out = bank->prof_rows;
+    if (!out || bank->prof_rows == 0) return GYP_OK;
+    const int n = bank->n, rows = bank->prof_rows;
+    std::vector<float> raw((size_t)rows * n);
+    std::vector<int32_t> delta(rows);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(raw.data(), bank->d_prof_tail + (size_t)channel * bank->prof_depth * n, raw.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(delta.data(), bank->d_prof_delta + (size_t)channel * bank->prof_depth, rows * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int r = 0; r < rows; ++r) {
+        // the row is roll(c0, -s_provisional); the reference's is roll(c0, -s_exact): out[k] = row[(k + s_exact - s_provisional) mod n]
+        const int d = ((delta[r] % n) + n) % n;
+        const float* row = raw.data() + (size_t)r * n;
+        std::memcpy(out + (size_t)r * n, row + d, (size_t)(n - d) * sizeof(float));
+        if (d) std::memcpy(out + (size_t)r * n + (n - d), row, (size_t)d * sizeof(float));
+    }
+    return GYP_OK;
 }
 
 int gyp_track_block(gyp_bank* bank, const float* iq_host, int32_t n_streams, int32_t n_ms, const double* start_time_host,

@@ -1487,6 +1487,11 @@ struct TrackBlockParams {
     const DllExact* exact_hist;
     int32_t sub_len;
     float* dbg;                // optional [n_chan][n_ms][20]: |window|^2 x 16, sample energy, code phase mod N, 0, 0 (debug)
+    // tracker.py:308-309 (non_coherent_correlation_profiles), throughput path only: the prompt profile of every millisecond
+    // from prof_from on goes to prof_tail[ch][ms - prof_from][N], rolled by the code phase the millisecond RAN with (the
+    // provisional one: dll_scan_kernel notes the difference to the exact one in DllScanParams::prof_delta where they differ)
+    float* prof_tail;
+    int32_t prof_from, prof_depth;
 };
 
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory queue (s_waitcnt
@@ -2291,7 +2296,9 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
                     si.doppler = f; si.carrier_phase = phi; si.code_phase = code_phase; si.key = kSpecKeyTransform;
                     p.spec_out[(int64_t)ch * p.n_ms + ms] = si;
                 }
-                const EplResult r = track_ms<K, false, PRE>(block, u0, du, cs, code_phase, mod_n(code_phase, N), sm, rep, nullptr, nullptr, pre);
+                float* prof_row = (PROF && p.prof_tail && ms >= p.prof_from)
+                                      ? p.prof_tail + ((int64_t)ch * p.prof_depth + (ms - p.prof_from)) * N : nullptr;   // uniform
+                const EplResult r = track_ms<K, false, PRE>(block, u0, du, cs, code_phase, mod_n(code_phase, N), sm, rep, prof_row, nullptr, pre);
                 if (prof) t_b = (long long)__builtin_readcyclecounter();
                 m.peak = r.peak; m.peak_mag = r.best.v; m.key = r.best.key; m.sum = r.sum; m.n_max = r.n_max;
                 m.strength_pending = false;
@@ -2630,6 +2637,8 @@ struct DllScanParams {
     const float* chipf;
     double inv_fs, dll_gain, dll_modulus, n_samples;
     int32_t first, final;
+    int32_t* prof_delta;       // optional [n_chan][prof_depth], zeroed by the host: (exact - provisional) code phase of a repaired
+    int32_t prof_from, prof_depth;   // millisecond, for the rows of TrackBlockParams::prof_tail
 };
 constexpr int kScanThreads = 256;
 constexpr int kScanChunk = 512;     // milliseconds staged in LDS at a time
@@ -2756,6 +2765,8 @@ __global__ __launch_bounds__(kScanThreads) void dll_scan_kernel(DllScanParams p)
                         const int k2 = lag - mod_n(s_s, N);
                         rec->peak_offset = k2 < 0 ? k2 + N : k2;
                     }
+                    if (p.prof_delta && ms >= p.prof_from)
+                        p.prof_delta[(int64_t)ch * p.prof_depth + (ms - p.prof_from)] = mod_n(s_s, N) - mod_n(in.code_phase, N);
                     ++s_repairs;
                 }
                 __syncthreads();

@@ -326,6 +326,19 @@ class ChannelBank:
         self.engine._check(self.engine.lib.gyp_bank_get_state(self.handle, ptr(f), ptr(phi), ptr(cp), ptr(lost)))
         return {"doppler_hz": f, "carrier_phase": phi, "code_phase": cp, "lost": lost}
 
+    def keep_profiles(self, depth: int) -> None:
+        """Keep the trailing `depth` non-coherent prompt profiles of every channel per block (tracker.py:154,308-309); 0: off."""
+        self.engine._check(self.engine.lib.gyp_bank_keep_profiles(self.handle, int(depth)))
+
+    def profiles(self, channel: int) -> np.ndarray:
+        """float32[n_rows, N]: the last block's trailing profiles of one channel, oldest first (gyp_bank_read_profiles)."""
+        n_rows = np.zeros(1, dtype=np.int32)
+        self.engine._check(self.engine.lib.gyp_bank_read_profiles(self.handle, int(channel), None, ptr(n_rows)))
+        out = np.zeros((int(n_rows[0]), self.engine.n), dtype=np.float32)
+        if out.size:
+            self.engine._check(self.engine.lib.gyp_bank_read_profiles(self.handle, int(channel), ptr(out), ptr(n_rows)))
+        return out
+
     def dll_repairs(self) -> np.ndarray:
         """Per channel: milliseconds of the last block in which the exactly re-integrated code loop differed from the
         speculative kernel's provisional one and repaired it (gyp_debug_dll_read); zeros on the throughput kernel."""

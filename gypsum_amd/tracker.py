@@ -241,13 +241,14 @@ class TrackerBank:
     `process_block` advances every channel over a block of milliseconds in one launch and appends what the
     reference's `process_samples` would have appended, per millisecond, to each channel's tracking parameters.
     It returns, per channel, the list of `EmittedPseudosymbol`s, and raises nothing: channels whose circularity
-    watchdog fired are reported in `lost` (the caller drops them like receiver.py:248-267).  The one history the block
-    path does not fill is `non_coherent_correlation_profiles` (250 x N floats per channel, visualiser only): per-ms
-    profiles are an output of the explicit-millisecond entry point (`GpsSatelliteTracker` / `gyp_track_step`).
+    watchdog fired are reported in `lost` (the caller drops them like receiver.py:248-267).
+    `non_coherent_correlation_profiles` (tracker.py:154,308-309: 250 x N floats per channel, read only by the visualiser)
+    is filled when `keep_profiles=True` (`gyp_bank_keep_profiles`: the trailing 250 profiles of every block, which is all
+    the reference's deque can hold; the bank then runs on the transform kernel).
     """
 
     def __init__(self, tracking_params: Sequence[GpsSatelliteTrackingParameters], stream_attributes: SampleProviderAttributes,
-                 stream_of_channel: Optional[Sequence[int]] = None, device: int = 0) -> None:
+                 stream_of_channel: Optional[Sequence[int]] = None, device: int = 0, keep_profiles: bool = False) -> None:
         self.params = list(tracking_params)
         self.stream_attributes = stream_attributes
         self._engine = default_engine(stream_attributes.samples_per_second,
@@ -259,6 +260,9 @@ class TrackerBank:
                         int(p.current_prn_code_phase_shift), 0)
         self._bank: ChannelBank = self._engine.create_bank(inits)
         self.lost = [False] * len(self.params)
+        self._keep_profiles = bool(keep_profiles)
+        if self._keep_profiles:
+            self._bank.keep_profiles(self.params[0].non_coherent_correlation_profiles.maxlen if self.params else 250)
 
     def process_block(self, iq: np.ndarray, n_streams: int, start_times: Sequence[float],
                       end_times: Sequence[float]) -> List[List[EmittedPseudosymbol]]:
@@ -271,6 +275,12 @@ class TrackerBank:
             emitted, lost = replay_track_records(p, rec[i], t0, t1)
             out.append(emitted)
             self.lost[i] = self.lost[i] or lost
+            if self._keep_profiles:
+                rows = self._bank.profiles(i)                       # the block's last len(rows) milliseconds, oldest first
+                stop = np.flatnonzero(rec[i]["status"] != 0)        # as replay_track_records: nothing after the raising millisecond
+                n_hist = n_ms if len(stop) == 0 else int(stop[0]) + (1 if rec[i]["status"][stop[0]] == 1 else 0)
+                first = n_ms - len(rows)
+                p.non_coherent_correlation_profiles.extend(rows[j - first].astype(np.float64) for j in range(first, n_hist))
         state = self._bank.state()
         for i, p in enumerate(self.params):
             p.current_doppler_shift = float(state["doppler_hz"][i])

@@ -317,6 +317,16 @@ int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stri
                         const double* start_time_dev, gyp_track_rec* rec_out_dev);
 int gyp_track_block(gyp_bank* bank, const float* iq_host, int32_t n_streams, int32_t n_ms,
                     const double* start_time_host, gyp_track_rec* rec_out_host);
+/* tracker.py:154,308-309 (GpsSatelliteTrackingParameters.non_coherent_correlation_profiles, read by
+ * tracker_visualizer.py:394): keep, for every channel of the bank, the non-coherent prompt profile |corr(wiped samples,
+ * PRN rolled by the code phase)| of the trailing milliseconds of each gyp_track_block(_dev) call -- the last
+ * min(depth, n_ms) of them (the reference's deque holds 250).  depth = 0 switches it off and frees the rows
+ * (n_chan * depth * N floats of device memory: meant for a receiver's dozen channels, not for a 1536-channel bank).
+ * While it is on the bank runs on the transform kernel, which forms every millisecond's full profile anyway (the
+ * speculative tracker does not).  gyp_bank_read_profiles copies one channel's rows, oldest first, to
+ * out[n_rows][N] (out may be NULL to query n_rows); rows of milliseconds a lost channel did not process are undefined. */
+int gyp_bank_keep_profiles(gyp_bank* bank, int32_t depth);
+int gyp_bank_read_profiles(gyp_bank* bank, int32_t channel, float* out, int32_t* n_rows_out);
 /* Re-initialise every channel from n_chan device-resident gyp_chan_init records (same semantics as a fresh
  * gyp_bank_create: histories cleared, DLL phase = code_phase).  Enqueued on the stream. */
 int gyp_bank_reset_dev(gyp_bank* bank, const gyp_chan_init* inits_dev);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU visit (through gpurun), steps chosen by name:
 #   gpurun --timeout 1500 -- 'bash tools/gpu_visit.sh <tag> step [step ...]'
-# steps: probe64  quick  tests  bench  benchfast  kt  pmc  surveys  single
+# steps: probe64  quick  tests  bench  benchfast  kt  pmc  surveys  single  phases  acqtl
 set -u
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -41,6 +41,11 @@ for step in "$@"; do
     surveys)
       timeout 1500 python tools/big_survey.py ${SURVEY_SCENES:-500} - 8184000 800000 > $O/survey_spec.txt 2>&1; tail -4 $O/survey_spec.txt
       timeout 1500 python tools/big_survey.py ${SURVEY_SCENES:-500} GYP_NO_SPEC 8184000 900000 > $O/survey_nospec.txt 2>&1; tail -4 $O/survey_nospec.txt ;;
+    phases)
+      timeout 300 python tools/gpu_profile_probe.py --full > $O/phases_mode0.txt 2>&1; cat $O/phases_mode0.txt ;;
+    acqtl)
+      timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/acqtl -o acq -- python tools/acq_timeline.py run > $O/acqtl.log 2>&1
+      python tools/acq_timeline.py show $O/acqtl > $O/acq_timeline.txt 2>&1; rm -rf $O/acqtl; tail -25 $O/acq_timeline.txt ;;
     single)
       timeout 600 python tools/single_stream_probe.py > $O/single_stream.txt 2>&1; tail -5 $O/single_stream.txt ;;
     *) echo "unknown step $step" ;;
