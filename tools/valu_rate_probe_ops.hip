@@ -9,6 +9,9 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters, float ks_in)
     float a[32];
     for (int i = 0; i < 32; ++i) a[i] = 0.001f * (threadIdx.x + i);
     const float kf = 1.0001f;
+    double kd, kd2;
+    { float2 t = make_float2(1.0001f, 0.9999f); kd = *(double*)&t; t = make_float2(0.5f, 1.5f); kd2 = *(double*)&t; }
+    asm volatile("" : "+v"(kd), "+v"(kd2));
     float ks = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ks_in)));
     unsigned long long mask = __ballot((threadIdx.x & 1) != 0);
     for (int it = 0; it < iters; ++it) {
@@ -31,6 +34,12 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters, float ks_in)
             if (MODE == 14) asm volatile("v_cmp_gt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(kf) : "vcc");
             if (MODE == 15) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(kf));
             if (MODE == 16) asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(*(double*)&a[i & ~1]));
+            if (MODE == 17) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(*(double*)&a[i & ~1]) : "v"(kd));
+            if (MODE == 18) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(*(double*)&a[i & ~1]) : "v"(kd));
+            if (MODE == 19) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(*(double*)&a[i & ~1]) : "v"(kd), "v"(kd2));
+            if (MODE == 20) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel:[0,0] op_sel_hi:[0,1]" : "+v"(*(double*)&a[i & ~1]) : "v"(kd));
+            if (MODE == 21) asm volatile("v_fmamk_f32 %0, %0, 0x3f8003a0, %1" : "+v"(a[i]) : "v"(kf));
+            if (MODE == 22) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(*(double*)&a[i & ~1]) : "v"(kd), "v"(kd2));
         }
     }
     float s = 0;
@@ -75,6 +84,12 @@ int main() {
         run<14>("v_cmp_gt_f32 vcc + v_cndmask_b32 vcc (pair)", 64, w);
         run<12>("v_add_f32 dpp row_shl:1", 32, w);
         run<16>("v_pk_mul_f32", 32, w);
+        run<20>("v_pk_mul_f32 v2, v2, v2 op_sel (broadcast lo)", 32, w);
+        run<18>("v_pk_add_f32 v2, v2, v2", 32, w);
+        run<17>("v_pk_fma_f32 v2, v2, k, k", 32, w);
+        run<22>("v_pk_fma_f32 v2, k, k2, v2 (three distinct)", 32, w);
+        run<19>("v_pk_fma_f32 op_sel + neg_lo (cmul second half)", 32, w);
+        run<21>("v_fmamk_f32 v, v, literal, v", 32, w);
     }
     return 0;
 }
