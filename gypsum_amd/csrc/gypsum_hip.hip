@@ -119,6 +119,7 @@ struct gyp_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cus = 256;
     bool no_pipe = false;      // GYP_NO_PIPE=1: A/B switch back to the two-workgroups-per-CU cells kernel
+    bool no_shared_fwd = false;   // GYP_NO_SHARED_FWD=1: A/B switch: flat grids transform every cell's rows themselves again
     std::string err;
     // stream format
     int64_t fs = 0;
@@ -327,6 +328,7 @@ int gyp_create(int device_ordinal, gyp_ctx** out) {
     ctx->device = device_ordinal;
     ctx->n_cus = prop.multiProcessorCount;
     ctx->no_pipe = std::getenv("GYP_NO_PIPE") != nullptr;
+    ctx->no_shared_fwd = std::getenv("GYP_NO_SHARED_FWD") != nullptr;
     ctx->no_spec = std::getenv("GYP_NO_SPEC") != nullptr;
     ctx->spec_debug = std::getenv("GYP_SPEC_DEBUG") != nullptr;
     if (const char* b = std::getenv("GYP_DLL_PROV_BIAS")) ctx->dll_prov_bias = std::atof(b);
@@ -754,6 +756,16 @@ int gyp_correlate_grid_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams,
             if (coh) hipLaunchKernelGGL((grid_fold_kernel<K, true>), fgrid, dim3(threads_for(K)), 0, ctx->stream, p);         \
             else hipLaunchKernelGGL((grid_fold_kernel<K, false>), fgrid, dim3(threads_for(K)), 0, ctx->stream, p);            \
             HIP_TRY(ctx, hipGetLastError());                                                                                  \
+        }                                                                                                                     \
+        if (n_blk == 1 && n_sats >= 4 && !ctx->no_pipe && !ctx->no_shared_fwd) { /* one wavefront per (unit, 8 satellites) */   \
+            const size_t lds = 2 * kTablesBytes + 8 * kXchWaveBytes + 8 * 8 * sizeof(SatStat);                                 \
+            const int n_groups = n_units * ((n_sats + 7) / 8);                                                                 \
+            const int wgrid = std::max(1, std::min((n_groups + 7) / 8, ctx->n_cus));                                           \
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(grid_cells_wave_shared_kernel<K, 8>),              \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
+            hipLaunchKernelGGL((grid_cells_wave_shared_kernel<K, 8>), dim3(wgrid), dim3(512), lds, ctx->stream, p);           \
+            HIP_TRY(ctx, hipGetLastError());                                                                                  \
+            return GYP_OK;                                                                                                    \
         }                                                                                                                     \
         if (n_blk == 1 && K % 2 == 0 && !ctx->no_pipe) { /* one wavefront per cell, 256 VGPRs, next row prefetched */              \
             const size_t lds = 2 * kTablesBytes + 8 * kXchWaveBytes;                                                           \

@@ -917,6 +917,90 @@ __global__ __launch_bounds__(512, 2) void grid_cells_wave_pipe_kernel(GridParams
     }
 }
 
+// The satellites of a flat grid share their (stream, bin) unit's folded rows -- and therefore its FORWARD transforms.  One
+// wavefront takes a unit and up to G satellites: per polyphase branch one row load and one forward transform, then per satellite
+// the product with its replica spectrum (read through L1/L2 in batches, like the tracking kernels do) + inverse transform +
+// statistics: (1 + G) transforms per G cells instead of 2 G.  Running statistics per satellite live in a few bytes of LDS
+// (lane 0 merges them after every branch), so the satellite loop is a real loop: one inverse transform's worth of code.
+struct SatStat { float v; int key; int cnt; int pad; double sum; };
+template <int K, int G>
+__global__ __launch_bounds__(512, 2) void grid_cells_wave_shared_kernel(GridParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cf* tw1024 = reinterpret_cast<cf*>(smem_raw);
+    cf* tw2048 = tw1024 + 1024;
+    cf* tiles = tw2048 + 1024;
+    for (int i = threadIdx.x; i < 2048; i += 512) tw1024[i] = p.tw_tables[i];
+    __syncthreads();
+    const int tid = launder(threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, l = lane & 31, h = lane >> 5;
+    float* tile_half = reinterpret_cast<float*>(tiles + wave * kXchWave) + h * kXchTile;
+    SatStat* stats = reinterpret_cast<SatStat*>(tiles + 8 * kXchWave) + wave * G;
+    const LdsTables t{tw1024, tw2048};
+    const int n_sg = (p.n_sats + G - 1) / G;
+    const int n_groups = p.n_streams * p.n_bins * n_sg;
+    for (int v = blockIdx.x * 8 + wave; v < n_groups; v += gridDim.x * 8) {
+        // satellite groups vary fastest: the groups of one unit run back to back inside one XCD's slice (its rows leave HBM once)
+        const int grp = (n_groups & 7) ? v : xcd_contiguous(v >> 3, n_groups >> 3) * 8 + (v & 7);
+        const int sg = grp % n_sg, unit_i = grp / n_sg;
+        const int bin = unit_i % p.n_bins, stream = unit_i / p.n_bins;
+        const int g_n = min(G, p.n_sats - sg * G);
+        const cf* unit = p.folded + (int64_t)unit_i * K * 1024 + launder(l);
+        if (lane < G) { SatStat z; z.v = -1.0f; z.key = 0x7fffffff; z.cnt = 0; z.pad = 0; z.sum = 0.0; stats[lane] = z; }
+#pragma unroll 1
+        for (int r = 0; r < K; ++r) {
+            cf x[32];
+            {
+                const cf* yw = unit + (int64_t)r * 1024;
+#pragma unroll
+                for (int j = 0; j < 32; ++j) x[j] = yw[32 * j];
+            }
+            // the replica spectrum of the NEXT satellite is requested before the current one's inverse transform (64 registers: the
+            // 256-register budget has room for it), the first one's before the forward transform: no load latency between transforms
+            cf prn[32];
+            auto request_replica = [&](int g) {
+                const int sat_index = __builtin_amdgcn_readfirstlane(p.sat_ids[sg * G + g]) - 1;
+                const cf* row = replica_of(p.replica_table, sat_index) + launder(lane);
+#pragma unroll
+                for (int i = 0; i < 32; ++i) prn[i] = row[64 * i];
+            };
+            request_replica(0);
+            __builtin_amdgcn_sched_barrier(0);
+            wave_fft_fwd(x, tile_half, t, l, h);
+#pragma unroll 1
+            for (int g = 0; g < g_n; ++g) {
+                cf y[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) y[i] = cmul(x[i], prn[i]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 1 < g_n) request_replica(g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                cf c[16];
+                wave_fft_inv(y, c, tile_half, t, l, h);
+                float mag[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) mag[j] = __builtin_amdgcn_sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
+                const WaveProfile wp = wave_profile(
+                    mag, nullptr, tid, [&](int j) { return mag[j]; },
+                    [&](int L, int j) { return K * ((L & 31) + 512 * (L >> 5)) + r + 32 * K * j; });
+                if (lane == 0) {   // tracker-free statistics of utils.py:111-116: max, first arg-max, sum, count of the max
+                    SatStat a = stats[g];
+                    a.sum += wp.sum;
+                    if (wp.vmax > a.v) { a.v = wp.vmax; a.key = wp.key; a.cnt = wp.cnt; }
+                    else if (wp.vmax == a.v) { a.cnt += wp.cnt; a.key = wp.key < a.key ? wp.key : a.key; }
+                    stats[g] = a;
+                }
+            }
+        }
+        if (lane < g_n) {
+            const SatStat a = stats[lane];
+            gyp_cell o;
+            o.peak = a.v; o.argmax = a.key; o.sum = a.sum; o.n_max = a.cnt; o.reserved = 0; o.tap_re = 0.f; o.tap_im = 0.f;
+            p.out[(stream * p.n_sats + sg * G + lane) * p.n_bins + bin] = o;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // tracking, one explicit millisecond
 // ---------------------------------------------------------------------------------------------------------

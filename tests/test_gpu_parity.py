@@ -295,6 +295,45 @@ def test_wide_rate_grid_fold_equals_per_cell_path(engine_factory, fs):
     assert g["argmax"][0, 0, 0] == scene.sats[0].code_phase
 
 
+@pytest.mark.parametrize("fs", [1_023_000, 2_046_000, 5_115_000, 8_184_000, 16_368_000, 49_104_000])
+def test_shared_forward_grid_kernel(engine_factory, fs):
+    """Single-block flat grids with four or more satellites share each (stream, bin) unit's forward transforms between the
+    satellites (grid_cells_wave_shared_kernel: one wavefront per unit and eight satellites).  Eleven satellites (a full group
+    and a ragged one), two streams, one non-coherent millisecond and three coherent ones: against the float64 oracle and
+    against the per-cell entry point, which transforms every cell on its own."""
+    from gypsum_amd import synth
+
+    n = fs // 1000
+    eng = engine_factory(fs, n)
+    scene = synth.random_scene(fs, 3, 3, 1234 + n, max_doppler=6000.0, with_nav_bits=False)
+    iq = synth.render(scene)
+    iq2 = np.concatenate([iq, np.conj(iq[::-1])]).astype(np.complex64)
+    sats = [s.sat_id for s in scene.sats]
+    sats += [sv for sv in (1, 5, 9, 13, 17, 21, 25, 29, 31, 32, 2) if sv not in sats][:11 - len(sats)]
+    dopp = [float(round(scene.sats[0].doppler_hz)), -1500.0, 250.0]
+    chips = orc.generate_ca_codes()
+    for integ, kind, n_ms in ((GYP_NON_COHERENT, orc.NON_COHERENT, 1), (GYP_COHERENT, orc.COHERENT, 3)):
+        two = np.concatenate([iq2[:n_ms * n], iq2[3 * n:(3 + n_ms) * n]])
+        g = eng.correlate_grid(two, 2, n_ms, sats, dopp, integ)
+        cells = np.zeros((2, len(sats), len(dopp)), dtype=CELL_DESC)
+        cells["stream"] = np.arange(2)[:, None, None]
+        cells["sat_id"] = np.array(sats)[None, :, None]
+        cells["doppler_hz"] = np.array(dopp)[None, None, :]
+        cells["tap_index"] = -1
+        c, _ = eng.correlate_cells(two, 2, n_ms, cells.reshape(-1), integ)
+        c = c.reshape(g.shape)
+        assert np.array_equal(g["argmax"], c["argmax"])
+        assert np.array_equal(g["n_max"], c["n_max"])
+        np.testing.assert_allclose(g["peak"], c["peak"], rtol=3e-6)
+        np.testing.assert_allclose(g["sum"], c["sum"], rtol=3e-6)
+        for si in (0, 7, 8, 10):          # first group, its last satellite, the ragged group's first and last
+            ref = np.abs(orc.integrate_correlation(kind, two[:n_ms * n], fs, n, dopp[0], orc.prn_as_complex(chips[sats[si] - 1], n)))
+            assert g["argmax"][0, si, 0] == int(np.argmax(ref)), (si, integ)
+            assert g["peak"][0, si, 0] == pytest.approx(ref.max(), rel=RTOL_MAG)
+            assert eng.cell_strength(g[0, si, 0:1])[0] == pytest.approx(orc.peak_strength(ref), rel=RTOL_MAG)
+    assert g["argmax"][0, 0, 0] == scene.sats[0].code_phase
+
+
 @pytest.mark.parametrize("seed,sv", [(5063, 3), (5068, 7), (5075, 20)])
 def test_cross_level_strength_near_ties_resolve_like_float64(engine_factory, seed, sv):
     """Two search levels whose winners (adjacent 1-Hz bins) differ by < 1e-7 relative in strength: the strictly-greater
