@@ -145,6 +145,7 @@ struct gyp_ctx {
     long long* d_prof = nullptr; // debug: per-phase cycle counters of track_block workgroup 0
     // gyp_debug_track_timing: HIP events around the three launches of the throughput tracking path (tracking kernel, exact sums, scan)
     bool time_track = false;
+    bool track_timed = false;   // the events below have been recorded since timing was switched on (the speculative path records none)
     hipEvent_t ev_track[4] = {nullptr, nullptr, nullptr, nullptr};
     // growable scratch for the host-buffer entry points and the acquisition driver
     static constexpr int kScratchSlots = 10;
@@ -757,13 +758,21 @@ int gyp_correlate_grid_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams,
             else hipLaunchKernelGGL((grid_fold_kernel<K, false>), fgrid, dim3(threads_for(K)), 0, ctx->stream, p);            \
             HIP_TRY(ctx, hipGetLastError());                                                                                  \
         }                                                                                                                     \
-        if (n_blk == 1 && n_sats >= 4 && !ctx->no_pipe && !ctx->no_shared_fwd) { /* one wavefront per (unit, 8 satellites) */   \
+        /* satellites per wavefront: more of them share a forward transform (1 + gs transforms per gs cells) but make fewer,   \
+           longer work items -- on a chip the grid does not fill (config 5 on one GPU, anything strong-scaled) the rounds decide */ \
+        int gs_best = 1; double cost_best = 0;                                                                                \
+        for (int gs = 1; gs <= 8; gs *= 2) {                                                                                  \
+            const double items = (double)n_units * ((n_sats + gs - 1) / gs), slots = ctx->n_cus * 8.0;                         \
+            const double cost = (gs == 1 ? 2.0 : 1.0 + gs) * std::ceil(items / slots);                                         \
+            if (gs == 1 || cost < cost_best) { gs_best = gs; cost_best = cost; }                                               \
+        }                                                                                                                     \
+        if (n_blk == 1 && gs_best > 1 && !ctx->no_pipe && !ctx->no_shared_fwd) { /* one wavefront per (unit, gs satellites) */ \
             const size_t lds = 2 * kTablesBytes + 8 * kXchWaveBytes + 8 * 8 * sizeof(SatStat);                                 \
-            const int n_groups = n_units * ((n_sats + 7) / 8);                                                                 \
+            const int n_groups = n_units * ((n_sats + gs_best - 1) / gs_best);                                                 \
             const int wgrid = std::max(1, std::min((n_groups + 7) / 8, ctx->n_cus));                                           \
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(grid_cells_wave_shared_kernel<K, 8>),              \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
-            hipLaunchKernelGGL((grid_cells_wave_shared_kernel<K, 8>), dim3(wgrid), dim3(512), lds, ctx->stream, p);           \
+            hipLaunchKernelGGL((grid_cells_wave_shared_kernel<K, 8>), dim3(wgrid), dim3(512), lds, ctx->stream, p, gs_best);  \
             HIP_TRY(ctx, hipGetLastError());                                                                                  \
             return GYP_OK;                                                                                                    \
         }                                                                                                                     \
@@ -1185,7 +1194,7 @@ static int track_block_throughput(gyp_bank* bank, TrackBlockParams p, const int3
     DllScanParams d = dll_scan_params(bank, p);
     d.bad = only_if; d.only_bad = only_if ? 1 : 0; d.from_sub = from_sub; d.sub_len = sub_len;
     if ((rc = launch_dll_scan(ctx, d, ctx->stream))) return rc;
-    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_track[3], ctx->stream));
+    if (timed) { HIP_TRY(ctx, hipEventRecord(ctx->ev_track[3], ctx->stream)); ctx->track_timed = true; }
     return GYP_OK;
 }
 
@@ -1563,10 +1572,14 @@ int gyp_debug_track_timing(gyp_ctx* ctx, int enable, float* out3) {
     if (!ctx) return GYP_E_BAD_ARG;
     if (enable && !ctx->ev_track[0])
         for (int i = 0; i < 4; ++i) HIP_TRY(ctx, hipEventCreate(&ctx->ev_track[i]));
-    if (out3 && ctx->time_track && ctx->ev_track[0]) {
-        HIP_TRY(ctx, hipEventSynchronize(ctx->ev_track[3]));
-        for (int i = 0; i < 3; ++i) HIP_TRY(ctx, hipEventElapsedTime(out3 + i, ctx->ev_track[i], ctx->ev_track[i + 1]));
+    if (out3) {
+        out3[0] = out3[1] = out3[2] = 0.0f;   // (a bank on the speculative path: no per-kernel split, zeros)
+        if (ctx->time_track && ctx->track_timed) {
+            HIP_TRY(ctx, hipEventSynchronize(ctx->ev_track[3]));
+            for (int i = 0; i < 3; ++i) HIP_TRY(ctx, hipEventElapsedTime(out3 + i, ctx->ev_track[i], ctx->ev_track[i + 1]));
+        }
     }
+    if (out3 || !enable || !ctx->time_track) ctx->track_timed = false;   // a reading belongs to the one call before it
     ctx->time_track = enable != 0;
     return GYP_OK;
 }

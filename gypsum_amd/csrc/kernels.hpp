@@ -924,7 +924,7 @@ __global__ __launch_bounds__(512, 2) void grid_cells_wave_pipe_kernel(GridParams
 // (lane 0 merges them after every branch), so the satellite loop is a real loop: one inverse transform's worth of code.
 struct SatStat { float v; int key; int cnt; int pad; double sum; };
 template <int K, int G>
-__global__ __launch_bounds__(512, 2) void grid_cells_wave_shared_kernel(GridParams p) {
+__global__ __launch_bounds__(512, 2) void grid_cells_wave_shared_kernel(GridParams p, int gs) {   // gs <= G satellites per wavefront (the host picks it by how full the chip gets)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cf* tw1024 = reinterpret_cast<cf*>(smem_raw);
     cf* tw2048 = tw1024 + 1024;
@@ -937,14 +937,14 @@ __global__ __launch_bounds__(512, 2) void grid_cells_wave_shared_kernel(GridPara
     float* tile_half = reinterpret_cast<float*>(tiles + wave * kXchWave) + h * kXchTile;
     SatStat* stats = reinterpret_cast<SatStat*>(tiles + 8 * kXchWave) + wave * G;
     const LdsTables t{tw1024, tw2048};
-    const int n_sg = (p.n_sats + G - 1) / G;
+    const int n_sg = (p.n_sats + gs - 1) / gs;
     const int n_groups = p.n_streams * p.n_bins * n_sg;
     for (int v = blockIdx.x * 8 + wave; v < n_groups; v += gridDim.x * 8) {
         // satellite groups vary fastest: the groups of one unit run back to back inside one XCD's slice (its rows leave HBM once)
         const int grp = (n_groups & 7) ? v : xcd_contiguous(v >> 3, n_groups >> 3) * 8 + (v & 7);
         const int sg = grp % n_sg, unit_i = grp / n_sg;
         const int bin = unit_i % p.n_bins, stream = unit_i / p.n_bins;
-        const int g_n = min(G, p.n_sats - sg * G);
+        const int g_n = min(gs, p.n_sats - sg * gs);
         const cf* unit = p.folded + (int64_t)unit_i * K * 1024 + launder(l);
         if (lane < G) { SatStat z; z.v = -1.0f; z.key = 0x7fffffff; z.cnt = 0; z.pad = 0; z.sum = 0.0; stats[lane] = z; }
 #pragma unroll 1
@@ -959,7 +959,7 @@ __global__ __launch_bounds__(512, 2) void grid_cells_wave_shared_kernel(GridPara
             // 256-register budget has room for it), the first one's before the forward transform: no load latency between transforms
             cf prn[32];
             auto request_replica = [&](int g) {
-                const int sat_index = __builtin_amdgcn_readfirstlane(p.sat_ids[sg * G + g]) - 1;
+                const int sat_index = __builtin_amdgcn_readfirstlane(p.sat_ids[sg * gs + g]) - 1;
                 const cf* row = replica_of(p.replica_table, sat_index) + launder(lane);
 #pragma unroll
                 for (int i = 0; i < 32; ++i) prn[i] = row[64 * i];
@@ -996,7 +996,7 @@ __global__ __launch_bounds__(512, 2) void grid_cells_wave_shared_kernel(GridPara
             const SatStat a = stats[lane];
             gyp_cell o;
             o.peak = a.v; o.argmax = a.key; o.sum = a.sum; o.n_max = a.cnt; o.reserved = 0; o.tap_re = 0.f; o.tap_im = 0.f;
-            p.out[(stream * p.n_sats + sg * G + lane) * p.n_bins + bin] = o;
+            p.out[(stream * p.n_sats + sg * gs + lane) * p.n_bins + bin] = o;
         }
     }
 }

@@ -493,7 +493,8 @@ int gyp_debug_track_profile(gyp_ctx* ctx, int enable, long long* out16);
 int gyp_debug_spec_read(gyp_bank* bank, float* out, int32_t n_floats, int32_t* bad_out);
 /* Debug / measurement: HIP events on the context's stream around the three launches behind gyp_track_block(_dev) on the
  * throughput path (banks of more than one channel per CU): enable != 0 arms it; out3 (may be NULL) receives the durations of the
- * last call in ms: {track_block_kernel, dll_exact kernel, dll_scan_kernel}.  bench.py's per-kernel roofline uses it. */
+ * last call in ms: {track_block_kernel, dll_exact kernel, dll_scan_kernel} -- zeros when that call ran on the speculative path
+ * (lightly loaded banks), which has no such split.  bench.py's per-kernel roofline uses it. */
 int gyp_debug_track_timing(gyp_ctx* ctx, int enable, float* out3);
 /* Debug / telemetry (either tracking path): repairs_out[n_chan] = milliseconds of the last gyp_track_block(_dev) call in which
  * the exactly re-integrated code loop (dll_scan_kernel) had int(self.phase) differ from the tracking kernel's provisional one
