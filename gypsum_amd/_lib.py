@@ -61,7 +61,7 @@ RECORD_SIZES = {"gyp_bit_event": BIT_EVENT.itemsize, "gyp_bits_state": BITS_STAT
 GYP_VERSION = 200
 
 EXPORTS = (
-    "gyp_version gyp_create gyp_destroy gyp_last_error gyp_device_name gyp_set_stream gyp_sync gyp_timer_start "
+    "gyp_version gyp_create gyp_destroy gyp_last_error gyp_device_name gyp_set_stream gyp_sync gyp_wait_for gyp_timer_start "
     "gyp_timer_stop gyp_set_stream_format gyp_prn_chips gyp_prn_spectrum_lane_layout gyp_malloc gyp_free "
     "gyp_memcpy_h2d gyp_memcpy_d2h gyp_cell_strength gyp_correlate_cells_dev gyp_correlate_cells gyp_correlate_grid_dev "
     "gyp_correlate_grid gyp_acquire_dev gyp_params_default gyp_set_params gyp_get_params gyp_search_level_dev gyp_search_level "
@@ -105,6 +105,7 @@ def load() -> C.CDLL:
         "gyp_device_name": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "gyp_set_stream": (C.c_int, [vp, vp]),
         "gyp_sync": (C.c_int, [vp]),
+        "gyp_wait_for": (C.c_int, [vp, vp]),
         "gyp_timer_start": (C.c_int, [vp]),
         "gyp_timer_stop": (C.c_int, [vp, C.POINTER(C.c_float)]),
         "gyp_set_stream_format": (C.c_int, [vp, i64, i32]),

@@ -144,6 +144,7 @@ struct gyp_ctx {
     // (the GYP_* environment switches are read ONCE, in gyp_create: no getenv on a hot entry point)
     long long* d_prof = nullptr; // debug: per-phase cycle counters of track_block workgroup 0
     // gyp_debug_track_timing: HIP events around the three launches of the throughput tracking path (tracking kernel, exact sums, scan)
+    hipEvent_t ev_order = nullptr;   // gyp_wait_for(waiter, this): recorded on this context's stream
     bool time_track = false;
     bool track_timed = false;   // the events below have been recorded since timing was switched on (the speculative path records none)
     hipEvent_t ev_track[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -361,6 +362,7 @@ void gyp_destroy(gyp_ctx* ctx) {
     if (ctx->d_chipf) (void)hipFree(ctx->d_chipf);
     if (ctx->d_prof) (void)hipFree(ctx->d_prof);
     for (int i = 0; i < 4; ++i) if (ctx->ev_track[i]) (void)hipEventDestroy(ctx->ev_track[i]);
+    if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
     if (ctx->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->comm);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -385,6 +387,15 @@ int gyp_set_stream(gyp_ctx* ctx, void* hip_stream) {
 int gyp_sync(gyp_ctx* ctx) {
     if (!ctx) return GYP_E_BAD_ARG;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GYP_OK;
+}
+
+int gyp_wait_for(gyp_ctx* ctx, gyp_ctx* other) {
+    if (!ctx || !other) return GYP_E_BAD_ARG;
+    if (ctx == other) return GYP_OK;
+    if (!other->ev_order) HIP_TRY(ctx, hipEventCreateWithFlags(&other->ev_order, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(other->ev_order, other->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, other->ev_order, 0));
     return GYP_OK;
 }
 

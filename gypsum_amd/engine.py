@@ -95,6 +95,10 @@ class GypsumEngine:
     def sync(self) -> None:
         self._check(self.lib.gyp_sync(self.ctx))
 
+    def wait_for(self, other: "GypsumEngine") -> None:
+        """Work enqueued on this engine from now on waits for everything `other` has enqueued so far (gyp_wait_for)."""
+        self._check(self.lib.gyp_wait_for(self.ctx, other.ctx))
+
     def timer_start(self) -> None:
         self._check(self.lib.gyp_timer_start(self.ctx))
 

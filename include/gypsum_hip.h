@@ -59,6 +59,11 @@ int gyp_device_name(gyp_ctx* ctx, char* out, int cap);
 /* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. NULL restores it. */
 int gyp_set_stream(gyp_ctx* ctx, void* hip_stream);
 int gyp_sync(gyp_ctx* ctx);
+/* Two contexts on one device = two HIP streams that run side by side (a receiver's satellite scans beside its tracking:
+ * receiver.py:151-161 scans every 10 s while the trackers keep running).  gyp_wait_for makes everything enqueued on
+ * `ctx` AFTER this call wait for everything enqueued on `other` BEFORE it (hipEventRecord + hipStreamWaitEvent); the host
+ * does not block.  Device buffers are valid in every context of the process. */
+int gyp_wait_for(gyp_ctx* ctx, gyp_ctx* other);
 /* hipEvent pair on the context's stream: the kernels' device time, as bench.py reports it. */
 int gyp_timer_start(gyp_ctx* ctx);
 int gyp_timer_stop(gyp_ctx* ctx, float* elapsed_ms);

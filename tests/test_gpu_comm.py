@@ -99,3 +99,29 @@ def test_bench_line_through_rccl_on_one_rank():
     line = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
     assert line["collective"]["uses_rccl"] == 1 and "fallback" not in line["collective"]
     assert line["value"] > 0
+
+
+def test_wait_for_orders_two_contexts():
+    """gyp_wait_for: work enqueued on one context after the call sees what another context had enqueued before it (two HIP
+    streams, no host synchronisation in between)."""
+    from gypsum_amd._lib import SYNTH_SAT
+
+    fs, n, T = 8_184_000, 8184, 400
+    a, b = GypsumEngine(0), GypsumEngine(0)
+    a.set_stream_format(fs, n)
+    b.set_stream_format(fs, n)
+    sats = np.zeros((1, 1), dtype=SYNTH_SAT)
+    sats[0, 0] = (3, 100, 1000.0, 0.5, 0.005, 0)
+    ref = a.alloc(T * n * 8)
+    a.synth_iq(ref, 1, T * n, T, sats, 0.03, 11)
+    want = ref.download(np.float32, 2 * T * n)
+    for rep in range(3):
+        buf = a.alloc(T * n * 8)
+        a.synth_iq(buf, 1, T * n, T, sats, 0.03, 11)          # ~milliseconds of device work on a's stream
+        b.wait_for(a)
+        got = np.zeros(2 * T * n, dtype=np.float32)
+        b._check(b.lib.gyp_memcpy_d2h(b.ctx, _lib.ptr(got), buf.ptr, got.nbytes))  # on b's stream: must see a's finished buffer
+        assert np.array_equal(got, want), rep
+    b.wait_for(b)                                            # a context waiting for itself is a no-op
+    a.close()
+    b.close()
