@@ -81,88 +81,6 @@ __host__ __device__ constexpr int bitrev5(int v) {
     return ((v & 1) << 4) | ((v & 2) << 2) | (v & 4) | ((v & 8) >> 2) | ((v & 16) >> 4);
 }
 
-// cos/sin(2*pi*t/32), t = 0..15 (t is a compile-time constant after unrolling)
-__device__ __forceinline__ constexpr float cos32(int t) {
-    switch (t) {
-        case 0: return 1.0f;
-        case 1: return 0.98078528040323044913f;
-        case 2: return 0.92387953251128675613f;
-        case 3: return 0.83146961230254523708f;
-        case 4: return 0.70710678118654752440f;
-        case 5: return 0.55557023301960222474f;
-        case 6: return 0.38268343236508977173f;
-        case 7: return 0.19509032201612826785f;
-        case 8: return 0.0f;
-        case 9: return -0.19509032201612826785f;
-        case 10: return -0.38268343236508977173f;
-        case 11: return -0.55557023301960222474f;
-        case 12: return -0.70710678118654752440f;
-        case 13: return -0.83146961230254523708f;
-        case 14: return -0.92387953251128675613f;
-        default: return -0.98078528040323044913f;
-    }
-}
-__device__ __forceinline__ constexpr float sin32(int t) { return t <= 8 ? cos32(8 - t) : cos32(t - 8); }
-
-// v * exp(DIR * 2*pi*i * t / 32), DIR = -1 forward, +1 inverse
-template <int DIR>
-__device__ __forceinline__ cf twiddle32(cf v, int t) {
-    constexpr float h = 0.70710678118654752440f;
-    if (t == 0) return v;
-    if (t == 8) return DIR < 0 ? make_float2(v.y, -v.x) : make_float2(-v.y, v.x);
-    if (t == 4) return DIR < 0 ? make_float2((v.x + v.y) * h, (v.y - v.x) * h) : make_float2((v.x - v.y) * h, (v.x + v.y) * h);
-    if (t == 12) return DIR < 0 ? make_float2((v.y - v.x) * h, -(v.x + v.y) * h) : make_float2(-(v.x + v.y) * h, (v.x - v.y) * h);
-    const float c = cos32(t), s = sin32(t);
-    return DIR < 0 ? make_float2(fmaf(v.x, c, v.y * s), fmaf(v.y, c, -v.x * s))
-                   : make_float2(fmaf(v.x, c, -v.y * s), fmaf(v.y, c, v.x * s));
-}
-
-// 32-point DFT, decimation in frequency: natural-order input, X[k] lands in x[bitrev5(k)].
-template <int DIR>
-__device__ __forceinline__ void fft32_dif(cf (&x)[32]) {
-#pragma unroll
-    for (int s = 0; s < 5; ++s) {
-        const int half = 16 >> s;
-#pragma unroll
-        for (int g = 0; g < 32; g += 2 * half) {
-#pragma unroll
-            for (int j = 0; j < half; ++j) {
-                const cf a = x[g + j], b = x[g + j + half];
-                x[g + j] = cadd(a, b);
-                x[g + j + half] = twiddle32<DIR>(csub(a, b), j << s);
-            }
-        }
-    }
-}
-
-// 32-point DFT, decimation in time: input element k expected in x[bitrev5(k)], natural-order output.
-template <int DIR>
-__device__ __forceinline__ void fft32_dit(cf (&x)[32]) {
-#pragma unroll
-    for (int s = 0; s < 5; ++s) {
-        const int half = 1 << s;
-#pragma unroll
-        for (int g = 0; g < 32; g += 2 * half) {
-#pragma unroll
-            for (int j = 0; j < half; ++j) {
-                const cf a = x[g + j];
-                const cf b = twiddle32<DIR>(x[g + j + half], j << (4 - s));
-                x[g + j] = cadd(a, b);
-                x[g + j + half] = csub(a, b);
-            }
-        }
-    }
-}
-
-#ifdef GYP_OLD_FFT32   // A/B switch: the hand-rolled radix-2 loops of r01/r02 instead of the generated codelets
-__device__ __forceinline__ void fft32_fwd_nat_br_(cf (&x)[32]) { fft32_dif<-1>(x); }
-__device__ __forceinline__ void fft32_inv_br_nat_(cf (&x)[32]) { fft32_dit<+1>(x); }
-__device__ __forceinline__ void fft32_inv_nat_br_(cf (&x)[32]) { fft32_dif<+1>(x); }
-#define fft32_fwd_nat_br fft32_fwd_nat_br_
-#define fft32_inv_br_nat fft32_inv_br_nat_
-#define fft32_inv_nat_br fft32_inv_nat_br_
-#endif
-
 // All 64 lanes of this wavefront have issued their LDS writes; make them visible to the reads that follow.
 // LDS operations of one wavefront execute in order, so only the compiler needs restraining.
 __device__ __forceinline__ void wave_lds_fence() {

@@ -2620,11 +2620,8 @@ __device__ __forceinline__ double2 cpow_km1(double2 w) {   // w^(K-1), K <= 8
     for (int i = 0; i < K - 1; ++i) r = cmul64(r, w);
     return r;
 }
-#ifndef GYP_EXACT_OCC
-#define GYP_EXACT_OCC 4
-#endif
 template <int K>
-__global__ __launch_bounds__(256, GYP_EXACT_OCC) void dll_exact_wave_kernel(DllExactParams p) {
+__global__ __launch_bounds__(256, 4) void dll_exact_wave_kernel(DllExactParams p) {
     static_assert(K <= 8, "a window's samples in registers");
     constexpr int N = K * kChips;
     const int lane = threadIdx.x & 63;
@@ -2857,11 +2854,7 @@ __global__ __launch_bounds__(kScanThreads) void dll_scan_kernel(DllScanParams p)
             }
         }
         // write-back: the record's discriminator and code phase
-#ifdef GYP_SCAN_NOWB
-        if (false) {
-#else
         if (p.rec_out) {
-#endif
             for (int i = tid; i < len; i += kScanThreads) {
                 gyp_track_rec* rec = p.rec_out + row + c0 + i;
                 rec->code_phase = s_cpout[i];
