@@ -27,8 +27,8 @@ for step in "$@"; do
       timeout 600 python bench.py --no-cpu-baseline --no-extras > $O/bench_fast.json 2> $O/bench_fast.err; echo "benchfast rc=$?"; head -c 4000 $O/bench_fast.json; echo ;;
     kt)
       timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_cfg3 -o bench -- python bench.py --no-cpu-baseline --no-extras > $O/kt_cfg3.log 2>&1
-      rm -f $O/kt_cfg3/*/bench_kernel_trace.csv $O/kt_cfg3/*/bench_agent_info.csv
-      head -12 $O/kt_cfg3/*/bench_kernel_stats.csv | cut -c1-200 ;;
+      rm -f $O/kt_cfg3/bench_kernel_trace.csv $O/kt_cfg3/*/bench_kernel_trace.csv $O/kt_cfg3/bench_agent_info.csv
+      head -12 $O/kt_cfg3/bench_kernel_stats.csv | cut -c1-200 ;;
     pmc)
       B="python bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1"
       for c in FETCH_SIZE WRITE_SIZE; do

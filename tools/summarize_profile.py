@@ -45,6 +45,10 @@ for f in (src / "kt_cfg3").rglob("*kernel_stats.csv"):
 # calibration factors: bytes moved per counted byte, for the tracking kernel's read / write patterns
 factor = {"read_contiguous": 2.0, "read_staging": 2.0, "read_windows": 1.0, "write_records": 1.0, "write_contiguous": 1.0}
 cal = src / "fetch_calibration.txt"
+if not cal.exists():      # a visit without the calibration step: the most recent committed calibration
+    older = sorted(dst.glob("*_fetch_calibration.txt"), key=lambda f: f.stat().st_mtime)
+    cal = older[-1] if older else cal
+summary["calibration_file"] = cal.name if cal.exists() else None
 if cal.exists():
     for line in cal.read_text().splitlines():
         m = re.match(r"(\w+)\s+\w+: counted .* multiply the counter by ([0-9.]+)", line)
