@@ -381,8 +381,8 @@ def run_cfg3(eng, comm, args, rng, eng_scan=None) -> dict:
     # --- per-kernel device time (HIP events on the engine's stream), outside the timed region
     reps = max(2, min(args.steps, 5))
     trk_ms = acq_ms = 0.0
-    k3 = np.zeros(3)                     # {track_block_kernel, dll_exact kernel, dll_scan_kernel}: HIP events around each launch
-    t3 = np.zeros(3, dtype=np.float32)
+    k3 = np.zeros(4)                     # {track_block_kernel, dll_exact kernel, dll_scan_kernel} ms + tracking-kernel launches per call
+    t3 = np.zeros(4, dtype=np.float32)
     eng._check(eng.lib.gyp_debug_track_timing(eng.ctx, 1, None))
     for i in range(reps):
         eng.timer_start()
@@ -400,6 +400,8 @@ def run_cfg3(eng, comm, args, rng, eng_scan=None) -> dict:
     k3 /= reps
     if not k3[0] > 0:                    # (a lightly loaded bank takes the speculative path: no per-kernel split there)
         k3[0] = trk_ms
+    n_launch = max(1, int(round(k3[3])))  # the library cuts long blocks into launches of <= 250 ms (a launch boundary re-aligns the
+                                          # channels of a stream, whose workgroups otherwise drift out of each other's L2 reach)
     # the same scans with gyp_params::acq_reuse_level_records = 0 (every bin of every level correlated again, as the reference does
     # with its cache lookup switched off, acquisition.py:204): bit-identical results, reported beside the default
     eng.set_params(acq_reuse_level_records=0.0)
@@ -430,7 +432,10 @@ def run_cfg3(eng, comm, args, rng, eng_scan=None) -> dict:
                    "parallelism": f"streams sharded over {comm.world} GPU(s), one ncclAllGather of acquisition records per step "
                                   f"issued by the library (gyp_allgather_dev)"},
         "samples_per_step": B * T * n, "elapsed": elapsed, "fs": fs, "streams_total": B * comm.world,
-        "dominant": {"kernel": "track_block_kernel<8, false, 0>", "ms": float(k3[0]), "flops": f_trk * B * T, "bytes": (8 * n + 64 * C_) * B * T},
+        # per LAUNCH, like the rocprofv3 summary under profiles/ (a step's tracking is n_launch launches of T / n_launch ms each)
+        "dominant": {"kernel": "track_block_kernel<8, false, 0>", "ms": float(k3[0]) / n_launch, "flops": f_trk * B * T / n_launch,
+                     "bytes": (8 * n + 64 * C_) * B * T / n_launch, "launches_per_step": n_launch,
+                     "unit_per_launch": f"{B * C_} channels x {T // n_launch} ms"},
         "extra": {"scan_stream": "second HIP stream: a step's scans run beside its tracking (ms_per_step < acquire + track, which are "
                                  "each measured alone below; --overlap-scan)" if eng_scan is not None else "the tracking's own stream (serial)",
                   "acquire_ms_per_step": round(acq_ms, 3), "track_ms_per_step": round(trk_ms, 3),
@@ -925,6 +930,9 @@ def main() -> None:
             "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "algorithmic_bytes_per_launch": dom["bytes"], "kernel_ms_per_launch": round(dom["ms"], 4),
+                         **({"launches_per_step": dom["launches_per_step"], "unit_per_launch": dom["unit_per_launch"]}
+                            if "launches_per_step" in dom else {}),
                          "traffic": traffic,
                          "traffic_source": "profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload "
                                            "(tools/gpu_visit.sh pmc), counters corrected by the factors tools/fetch_calib.hip measured for "

@@ -119,6 +119,7 @@ struct gyp_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cus = 256;
     bool no_pipe = false;      // GYP_NO_PIPE=1: A/B switch back to the two-workgroups-per-CU cells kernel
+    int track_chunk_ms = 250;     // GYP_TRACK_CHUNK_MS: the throughput tracking kernel's launch length (0: whole blocks)
     bool no_shared_fwd = false;   // GYP_NO_SHARED_FWD=1: A/B switch: flat grids transform every cell's rows themselves again
     std::string err;
     // stream format
@@ -146,7 +147,8 @@ struct gyp_ctx {
     // gyp_debug_track_timing: HIP events around the three launches of the throughput tracking path (tracking kernel, exact sums, scan)
     hipEvent_t ev_order = nullptr;   // gyp_wait_for(waiter, this): recorded on this context's stream
     bool time_track = false;
-    bool track_timed = false;   // the events below have been recorded since timing was switched on (the speculative path records none)
+    bool track_timed = false;
+    int track_launches = 0;     // launches of the tracking kernel behind the last timed call   // the events below have been recorded since timing was switched on (the speculative path records none)
     hipEvent_t ev_track[4] = {nullptr, nullptr, nullptr, nullptr};
     // growable scratch for the host-buffer entry points and the acquisition driver
     static constexpr int kScratchSlots = 10;
@@ -331,6 +333,7 @@ int gyp_create(int device_ordinal, gyp_ctx** out) {
     ctx->n_cus = prop.multiProcessorCount;
     ctx->no_pipe = std::getenv("GYP_NO_PIPE") != nullptr;
     ctx->no_shared_fwd = std::getenv("GYP_NO_SHARED_FWD") != nullptr;
+    if (const char* e = std::getenv("GYP_TRACK_CHUNK_MS")) ctx->track_chunk_ms = std::atoi(e);
     ctx->no_spec = std::getenv("GYP_NO_SPEC") != nullptr;
     ctx->spec_debug = std::getenv("GYP_SPEC_DEBUG") != nullptr;
     if (const char* b = std::getenv("GYP_DLL_PROV_BIAS")) ctx->dll_prov_bias = std::atof(b);
@@ -1196,7 +1199,19 @@ static int track_block_throughput(gyp_bank* bank, TrackBlockParams p, const int3
     p.from_sub = from_sub; p.exact_hist = exact_hist; p.sub_len = sub_len;
     const bool timed = ctx->time_track && !only_if;
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_track[0], ctx->stream));
-    if ((rc = launch_track_block(ctx, p, 0))) return rc;
+    // The channels of a stream are independent workgroups that read the same samples; nothing keeps them within an L2's worth
+    // (~11 ms of an XCD's resident streams) of each other, and over a 1000-ms launch they drift apart: FETCH_SIZE per
+    // millisecond is 1.24x the algorithmic bytes for launches of <= 250 ms and 2.6x for 1000 ms (profiles/r03_drift.txt).  A
+    // launch boundary is a rendezvous: long blocks go through in chunks (the loop state travels in ChanState anyway, and a
+    // block gives the same records however it is cut).
+    const int chunk = (only_if || ctx->track_chunk_ms <= 0) ? p.n_ms : ctx->track_chunk_ms;
+    ctx->track_launches = (p.n_ms + chunk - 1) / chunk;
+    for (int b0 = 0; b0 < p.n_ms; b0 += chunk) {
+        TrackBlockParams q = p;
+        q.ms_begin = b0; q.ms_end = std::min(p.n_ms, b0 + chunk);
+        if (b0 > 0) q.exact0 = nullptr;          // the code loop's state before the BLOCK is what dll_scan_kernel starts from
+        if ((rc = launch_track_block(ctx, q, 0))) return rc;
+    }
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_track[1], ctx->stream));
     DllExactParams x = dll_exact_params(bank, p);
     x.only_if = only_if; x.from_sub = from_sub; x.sub_len = sub_len;
@@ -1579,18 +1594,19 @@ int gyp_debug_track_profile(gyp_ctx* ctx, int enable, long long* out8) {
     return GYP_OK;
 }
 
-int gyp_debug_track_timing(gyp_ctx* ctx, int enable, float* out3) {
+int gyp_debug_track_timing(gyp_ctx* ctx, int enable, float* out4) {
     if (!ctx) return GYP_E_BAD_ARG;
     if (enable && !ctx->ev_track[0])
         for (int i = 0; i < 4; ++i) HIP_TRY(ctx, hipEventCreate(&ctx->ev_track[i]));
-    if (out3) {
-        out3[0] = out3[1] = out3[2] = 0.0f;   // (a bank on the speculative path: no per-kernel split, zeros)
+    if (out4) {
+        out4[0] = out4[1] = out4[2] = out4[3] = 0.0f;   // (a bank on the speculative path: no per-kernel split, zeros)
         if (ctx->time_track && ctx->track_timed) {
             HIP_TRY(ctx, hipEventSynchronize(ctx->ev_track[3]));
-            for (int i = 0; i < 3; ++i) HIP_TRY(ctx, hipEventElapsedTime(out3 + i, ctx->ev_track[i], ctx->ev_track[i + 1]));
+            for (int i = 0; i < 3; ++i) HIP_TRY(ctx, hipEventElapsedTime(out4 + i, ctx->ev_track[i], ctx->ev_track[i + 1]));
+            out4[3] = (float)ctx->track_launches;
         }
     }
-    if (out3 || !enable || !ctx->time_track) ctx->track_timed = false;   // a reading belongs to the one call before it
+    if (out4 || !enable || !ctx->time_track) ctx->track_timed = false;   // a reading belongs to the one call before it
     ctx->time_track = enable != 0;
     return GYP_OK;
 }

@@ -496,11 +496,12 @@ int gyp_debug_track_profile(gyp_ctx* ctx, int enable, long long* out16);
  * (previous peak lag - 4 .. + 3), 8 zeros, the sample-energy estimate, code_phase mod N, the window centre, 0.  bad_out (may be NULL): per
  * channel, 1 if the verify pass sent the channel back through the transform kernel.  Synchronises the stream. */
 int gyp_debug_spec_read(gyp_bank* bank, float* out, int32_t n_floats, int32_t* bad_out);
-/* Debug / measurement: HIP events on the context's stream around the three launches behind gyp_track_block(_dev) on the
- * throughput path (banks of more than one channel per CU): enable != 0 arms it; out3 (may be NULL) receives the durations of the
- * last call in ms: {track_block_kernel, dll_exact kernel, dll_scan_kernel} -- zeros when that call ran on the speculative path
- * (lightly loaded banks), which has no such split.  bench.py's per-kernel roofline uses it. */
-int gyp_debug_track_timing(gyp_ctx* ctx, int enable, float* out3);
+/* Debug / measurement: HIP events on the context's stream around the three stages behind gyp_track_block(_dev) on the
+ * throughput path (banks of more than one channel per CU): enable != 0 arms it; out4 (may be NULL) receives, for the last
+ * call, {ms in track_block_kernel (all its launches), ms in the dll_exact kernel, ms in dll_scan_kernel, number of
+ * track_block_kernel launches: blocks longer than 250 ms go through in chunks, GYP_TRACK_CHUNK_MS} -- zeros when that call
+ * ran on the speculative path (lightly loaded banks), which has no such split.  bench.py's per-kernel roofline uses it. */
+int gyp_debug_track_timing(gyp_ctx* ctx, int enable, float* out4);
 /* Debug / telemetry (either tracking path): repairs_out[n_chan] = milliseconds of the last gyp_track_block(_dev) call in which
  * the exactly re-integrated code loop (dll_scan_kernel) had int(self.phase) differ from the tracking kernel's provisional one
  * and formed that millisecond's float64 sums again for the right lag.  Synchronises the stream. */
