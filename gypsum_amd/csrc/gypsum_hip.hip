@@ -119,7 +119,7 @@ struct gyp_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cus = 256;
     bool no_pipe = false;      // GYP_NO_PIPE=1: A/B switch back to the two-workgroups-per-CU cells kernel
-    int track_chunk_ms = 250;     // GYP_TRACK_CHUNK_MS: the throughput tracking kernel's launch length (0: whole blocks)
+    int track_chunk_ms = 500;     // GYP_TRACK_CHUNK_MS: the throughput tracking kernel's launch length (0: whole blocks)
     bool no_shared_fwd = false;   // GYP_NO_SHARED_FWD=1: A/B switch: flat grids transform every cell's rows themselves again
     std::string err;
     // stream format
@@ -1202,8 +1202,9 @@ static int track_block_throughput(gyp_bank* bank, TrackBlockParams p, const int3
     // The channels of a stream are independent workgroups that read the same samples; nothing keeps them within an L2's worth
     // (~11 ms of an XCD's resident streams) of each other, and over a 1000-ms launch they drift apart: FETCH_SIZE per
     // millisecond is 1.24x the algorithmic bytes for launches of <= 250 ms and 2.6x for 1000 ms (profiles/r03_drift.txt).  A
-    // launch boundary is a rendezvous: long blocks go through in chunks (the loop state travels in ChanState anyway, and a
-    // block gives the same records however it is cut).
+    // launch boundary is a rendezvous: long blocks go through in chunks of 500 ms (the loop state travels in ChanState anyway,
+    // and a block gives the same records however it is cut).  Shorter chunks buy little more traffic and cost a host-fed
+    // pipeline its overlap: the chip drains at every boundary and the upload stream's widen kernel takes it whole.
     const int chunk = (only_if || ctx->track_chunk_ms <= 0) ? p.n_ms : ctx->track_chunk_ms;
     ctx->track_launches = (p.n_ms + chunk - 1) / chunk;
     for (int b0 = 0; b0 < p.n_ms; b0 += chunk) {

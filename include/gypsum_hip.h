@@ -499,7 +499,7 @@ int gyp_debug_spec_read(gyp_bank* bank, float* out, int32_t n_floats, int32_t* b
 /* Debug / measurement: HIP events on the context's stream around the three stages behind gyp_track_block(_dev) on the
  * throughput path (banks of more than one channel per CU): enable != 0 arms it; out4 (may be NULL) receives, for the last
  * call, {ms in track_block_kernel (all its launches), ms in the dll_exact kernel, ms in dll_scan_kernel, number of
- * track_block_kernel launches: blocks longer than 250 ms go through in chunks, GYP_TRACK_CHUNK_MS} -- zeros when that call
+ * track_block_kernel launches: blocks longer than 500 ms go through in chunks, GYP_TRACK_CHUNK_MS} -- zeros when that call
  * ran on the speculative path (lightly loaded banks), which has no such split.  bench.py's per-kernel roofline uses it. */
 int gyp_debug_track_timing(gyp_ctx* ctx, int enable, float* out4);
 /* Debug / telemetry (either tracking path): repairs_out[n_chan] = milliseconds of the last gyp_track_block(_dev) call in which
