@@ -34,7 +34,7 @@ def test_block_path_keeps_the_trailing_prompt_profiles(fs, bias):
     first, cuts = 9, ((60, 45) if n > 8184 else (130, 90))
     n_ms = first + sum(cuts)
     iq, inits = _scene_and_inits(fs, n, n_ms, 2, 31337 + n)
-    env = {"GYP_DLL_PROV_BIAS": bias} if bias else {}
+    env = {"GYP_DLL_PROV_BIAS": bias, "GYP_TRACK_CHUNK_MS": 50} if bias else {}   # (and launch boundaries inside the kept rows)
     eng = _engine_with_env(fs, n, **env)
     depth = 100
     bank = eng.create_bank(inits)
