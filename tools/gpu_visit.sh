@@ -39,8 +39,8 @@ for step in "$@"; do
       rm -f $O/pmc_*/*/bench_agent_info.csv
       ls $O ;;
     surveys)
-      timeout 1500 python tools/big_survey.py ${SURVEY_SCENES:-500} - 8184000 800000 > $O/survey_spec.txt 2>&1; tail -4 $O/survey_spec.txt
-      timeout 1500 python tools/big_survey.py ${SURVEY_SCENES:-500} GYP_NO_SPEC 8184000 900000 > $O/survey_nospec.txt 2>&1; tail -4 $O/survey_nospec.txt ;;
+      timeout 1500 python tools/big_survey.py ${SURVEY_SCENES:-500} - 8184000 ${SURVEY_SEED_A:-800000} > $O/survey_spec.txt 2>&1; tail -4 $O/survey_spec.txt
+      timeout 1500 python tools/big_survey.py ${SURVEY_SCENES:-500} GYP_NO_SPEC 8184000 ${SURVEY_SEED_B:-900000} > $O/survey_nospec.txt 2>&1; tail -4 $O/survey_nospec.txt ;;
     phases)
       timeout 300 python tools/gpu_profile_probe.py --full > $O/phases_mode0.txt 2>&1; cat $O/phases_mode0.txt ;;
     acqtl)
