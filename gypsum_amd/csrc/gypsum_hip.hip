@@ -146,6 +146,9 @@ struct gyp_ctx {
     long long* d_prof = nullptr; // debug: per-phase cycle counters of track_block workgroup 0
     // gyp_debug_track_timing: HIP events around the three launches of the throughput tracking path (tracking kernel, exact sums, scan)
     hipEvent_t ev_order = nullptr;   // gyp_wait_for(waiter, this): recorded on this context's stream
+    gyp_ctx* helper = nullptr;       // gyp_acquire_dev: the second half of a multi-stream scan runs here (own stream, scratch, tables)
+    bool is_helper = false;
+    bool no_acq_split = false;       // GYP_NO_ACQ_SPLIT=1: A/B switch
     bool time_track = false;
     bool track_timed = false;
     int track_launches = 0;     // launches of the tracking kernel behind the last timed call   // the events below have been recorded since timing was switched on (the speculative path records none)
@@ -333,6 +336,7 @@ int gyp_create(int device_ordinal, gyp_ctx** out) {
     ctx->n_cus = prop.multiProcessorCount;
     ctx->no_pipe = std::getenv("GYP_NO_PIPE") != nullptr;
     ctx->no_shared_fwd = std::getenv("GYP_NO_SHARED_FWD") != nullptr;
+    ctx->no_acq_split = std::getenv("GYP_NO_ACQ_SPLIT") != nullptr;
     if (const char* e = std::getenv("GYP_TRACK_CHUNK_MS")) ctx->track_chunk_ms = std::atoi(e);
     ctx->no_spec = std::getenv("GYP_NO_SPEC") != nullptr;
     ctx->spec_debug = std::getenv("GYP_SPEC_DEBUG") != nullptr;
@@ -352,6 +356,7 @@ int gyp_create(int device_ordinal, gyp_ctx** out) {
 
 void gyp_destroy(gyp_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->helper) { gyp_destroy(ctx->helper); ctx->helper = nullptr; }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < gyp_ctx::kScratchSlots; ++i)
@@ -858,17 +863,8 @@ static int acquire_search(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, 
         return fail(ctx, GYP_E_BAD_ARG, "gyp_acquire_dev / gyp_search_level_dev: bad argument");
     for (int i = 0; i < n_sats; ++i)
         if (sat_ids_host[i] < 1 || sat_ids_host[i] > 32) return fail(ctx, GYP_E_BAD_ARG, "satellite id out of range");
+    if (n_sats > 32) return fail(ctx, GYP_E_BAD_ARG, "at most 32 satellites per search");
     const int n_states = n_streams * n_sats;
-    std::vector<AcqSearchState> init((size_t)n_states);
-    for (int s = 0; s < n_streams; ++s)
-        for (int i = 0; i < n_sats; ++i) {
-            AcqSearchState& a = init[(size_t)s * n_sats + i];
-            std::memset(&a, 0, sizeof(a));
-            a.stream = s;
-            a.sat_id = sat_ids_host[i];
-            a.center = center0;   // acquisition.py:78
-            a.spread = spread0;   // acquisition.py:79
-        }
     int rc;
     const size_t n_cells = (size_t)n_states * kMaxBins;
     if ((rc = ensure_scratch(ctx, 4, (size_t)n_states * sizeof(AcqSearchState)))) return rc;
@@ -896,10 +892,12 @@ static int acquire_search(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, 
     AcqSearchState* d_states = (AcqSearchState*)ctx->scratch[4];
     gyp_cell_desc* d_cells = (gyp_cell_desc*)ctx->scratch[1];
     gyp_cell* d_out = (gyp_cell*)ctx->scratch[2];
-    // the descriptors of a previous host-form call may still be in flight on this stream: ordering is by stream
-    HIP_TRY(ctx, hipMemcpyAsync(d_states, init.data(), init.size() * sizeof(AcqSearchState), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `init` is a local
     const int tpb = 64, nblk = (n_states + tpb - 1) / tpb;
+    {
+        AcqSatList sl;
+        for (int i = 0; i < 32; ++i) sl.id[i] = i < n_sats ? sat_ids_host[i] : 0;
+        hipLaunchKernelGGL(acq_init_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, n_sats, sl, center0, spread0);   // acquisition.py:78-79
+    }
     for (double spread = spread0; single_level ? spread == spread0 : spread >= ctx->params.acq_min_spread_hz; spread /= 2.0) {  // acquisition.py:81,89
         hipLaunchKernelGGL(acq_plan_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_cells, d_reuse, ctx->params.acq_bins_per_spread,
                            ctx->params.acq_reuse_level_records != 0.0 ? 1 : 0);
@@ -949,11 +947,42 @@ static int acquire_search(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, 
 }
 
 
+// A scan is ten levels of one big correlation launch each plus eight small bookkeeping launches (the tie-breaks, the reductions:
+// ~3 ms of a 13-stream scan during which the chip is almost empty, profiles/r03y_acq_timeline.txt) and the big launches end in
+// a ragged last round of workgroups.  Streams are searched independently of each other, so a scan of several streams goes
+// through in TWO halves on two HIP streams -- the second on a helper context of its own (its own scratch and tables): one
+// half's big launch fills the chip while the other half is in its small ones.  Same results bit for bit.
+static gyp_ctx* acquire_helper(gyp_ctx* ctx) {
+    if (ctx->is_helper || ctx->no_acq_split) return nullptr;
+    if (!ctx->helper) {
+        gyp_ctx* h = nullptr;
+        if (gyp_create(ctx->device, &h) != GYP_OK) return nullptr;
+        h->is_helper = true;
+        ctx->helper = h;
+    }
+    gyp_ctx* h = ctx->helper;
+    if (h->fs != ctx->fs || h->n != ctx->n)
+        if (gyp_set_stream_format(h, ctx->fs, ctx->n) != GYP_OK) return nullptr;
+    h->params = ctx->params;
+    return h;
+}
+
 int gyp_acquire_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_t stream_stride_samples,
                     int32_t n_ms, const int32_t* sat_ids_host, int32_t n_sats, gyp_acq_result* out_dev) {
     if (!ctx) return GYP_E_BAD_ARG;
-    return acquire_search(ctx, iq_dev, n_streams, stream_stride_samples, n_ms, sat_ids_host, n_sats, 0.0, ctx->params.acq_initial_spread_hz,
-                          false, out_dev);
+    gyp_ctx* h = (n_streams >= 4 && ctx->k && iq_dev && out_dev && n_sats > 0) ? acquire_helper(ctx) : nullptr;
+    if (!h)
+        return acquire_search(ctx, iq_dev, n_streams, stream_stride_samples, n_ms, sat_ids_host, n_sats, 0.0,
+                              ctx->params.acq_initial_spread_hz, false, out_dev);
+    const int n_a = (n_streams + 1) / 2;
+    int rc;
+    if ((rc = gyp_wait_for(h, ctx))) return rc;     // the samples may still be on their way on this context's stream
+    if ((rc = acquire_search(ctx, iq_dev, n_a, stream_stride_samples, n_ms, sat_ids_host, n_sats, 0.0, ctx->params.acq_initial_spread_hz,
+                             false, out_dev))) return rc;
+    if ((rc = acquire_search(h, iq_dev + (int64_t)n_a * stream_stride_samples * 2, n_streams - n_a, stream_stride_samples, n_ms, sat_ids_host,
+                             n_sats, 0.0, ctx->params.acq_initial_spread_hz, false, out_dev + (size_t)n_a * n_sats)))
+        return fail(ctx, rc, std::string("second half of the scan: ") + h->err);
+    return gyp_wait_for(ctx, h);                    // whatever follows on this context's stream sees both halves
 }
 
 int gyp_search_level_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_t stream_stride_samples, int32_t n_ms,

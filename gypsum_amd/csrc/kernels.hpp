@@ -2923,6 +2923,20 @@ struct AcqSearchState {
     int32_t pending, cand_doppler, best_is_exact, pad2;
 };
 
+// The search states at acquisition.py:78-79: centre and spread of the first level, nothing found yet.  (On the device: the entry
+// points stay asynchronous -- a host-built table would have to be waited for.)
+struct AcqSatList { int32_t id[32]; };
+__global__ void acq_init_kernel(AcqSearchState* states, int n_states, int n_sats, AcqSatList sats, double center, double spread) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_states) return;
+    AcqSearchState a = {};
+    a.stream = i / n_sats;
+    a.sat_id = sats.id[i % n_sats];
+    a.center = center;
+    a.spread = spread;
+    states[i] = a;
+}
+
 // Fill the descriptors of the current level: range(int(c-s), int(c+s), int(s/10)), padded to kMaxBins.
 // With gyp_params::acq_reuse_level_records a bin the previous level already evaluated (every other bin of levels 2, 3, 8
 // and 10 with the reference's spreads) is not correlated again: `reuse` says which of the previous level's records

@@ -211,7 +211,10 @@ typedef struct gyp_acq_result {
 /* acquisition.py:70-152 _attempt_acquisition_for_satellite_id for every (stream, satellite): the 10-level
  * coarse-to-fine Doppler search (spread 7000 Hz halving while >= 10, bins range(int(c-s), int(c+s), int(s/10)),
  * non-coherent over the n_ms blocks), then the coherent pass for the carrier phase.  The threshold of
- * acquisition.py:65 is left to the caller.  out: n_streams x n_sats records, stream-major, sat order as given. */
+ * acquisition.py:65 is left to the caller.  out: n_streams x n_sats records, stream-major, sat order as given (at most 32
+ * satellites per call).  The _dev form only enqueues work (it never waits for the stream); a scan of four or more streams
+ * runs as two halves on two HIP streams of the library's own, joined before the call returns control of the context's
+ * stream to whatever the caller enqueues next -- same records bit for bit. */
 int gyp_acquire_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_t stream_stride_samples,
                     int32_t n_ms, const int32_t* sat_ids_host, int32_t n_sats, gyp_acq_result* out_dev);
 int gyp_acquire(gyp_ctx* ctx, const float* iq_host, int32_t n_streams, int32_t n_ms,
