@@ -146,7 +146,9 @@ struct gyp_ctx {
     long long* d_prof = nullptr; // debug: per-phase cycle counters of track_block workgroup 0
     // gyp_debug_track_timing: HIP events around the three launches of the throughput tracking path (tracking kernel, exact sums, scan)
     hipEvent_t ev_order = nullptr;   // gyp_wait_for(waiter, this): recorded on this context's stream
-    gyp_ctx* helper = nullptr;       // gyp_acquire_dev: the second half of a multi-stream scan runs here (own stream, scratch, tables)
+    static constexpr int kMaxAcqLanes = 4;
+    gyp_ctx* helper[kMaxAcqLanes - 1] = {};   // gyp_acquire_dev: the other parts of a multi-stream scan run here (own stream, scratch, tables)
+    int acq_lanes = 2;               // GYP_ACQ_LANES
     bool is_helper = false;
     bool no_acq_split = false;       // GYP_NO_ACQ_SPLIT=1: A/B switch
     bool time_track = false;
@@ -337,6 +339,7 @@ int gyp_create(int device_ordinal, gyp_ctx** out) {
     ctx->no_pipe = std::getenv("GYP_NO_PIPE") != nullptr;
     ctx->no_shared_fwd = std::getenv("GYP_NO_SHARED_FWD") != nullptr;
     ctx->no_acq_split = std::getenv("GYP_NO_ACQ_SPLIT") != nullptr;
+    if (const char* e = std::getenv("GYP_ACQ_LANES")) ctx->acq_lanes = std::max(1, std::min(gyp_ctx::kMaxAcqLanes, std::atoi(e)));
     if (const char* e = std::getenv("GYP_TRACK_CHUNK_MS")) ctx->track_chunk_ms = std::atoi(e);
     ctx->no_spec = std::getenv("GYP_NO_SPEC") != nullptr;
     ctx->spec_debug = std::getenv("GYP_SPEC_DEBUG") != nullptr;
@@ -356,7 +359,7 @@ int gyp_create(int device_ordinal, gyp_ctx** out) {
 
 void gyp_destroy(gyp_ctx* ctx) {
     if (!ctx) return;
-    if (ctx->helper) { gyp_destroy(ctx->helper); ctx->helper = nullptr; }
+    for (auto& h : ctx->helper) if (h) { gyp_destroy(h); h = nullptr; }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < gyp_ctx::kScratchSlots; ++i)
@@ -950,17 +953,17 @@ static int acquire_search(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, 
 // A scan is ten levels of one big correlation launch each plus eight small bookkeeping launches (the tie-breaks, the reductions:
 // ~3 ms of a 13-stream scan during which the chip is almost empty, profiles/r03y_acq_timeline.txt) and the big launches end in
 // a ragged last round of workgroups.  Streams are searched independently of each other, so a scan of several streams goes
-// through in TWO halves on two HIP streams -- the second on a helper context of its own (its own scratch and tables): one
-// half's big launch fills the chip while the other half is in its small ones.  Same results bit for bit.
-static gyp_ctx* acquire_helper(gyp_ctx* ctx) {
+// through in parts on several HIP streams -- the others on helper contexts of their own (own scratch and tables): one part's
+// big launch fills the chip while another part is in its small ones.  Same results bit for bit.
+static gyp_ctx* acquire_helper(gyp_ctx* ctx, int which) {
     if (ctx->is_helper || ctx->no_acq_split) return nullptr;
-    if (!ctx->helper) {
+    if (!ctx->helper[which]) {
         gyp_ctx* h = nullptr;
         if (gyp_create(ctx->device, &h) != GYP_OK) return nullptr;
         h->is_helper = true;
-        ctx->helper = h;
+        ctx->helper[which] = h;
     }
-    gyp_ctx* h = ctx->helper;
+    gyp_ctx* h = ctx->helper[which];
     if (h->fs != ctx->fs || h->n != ctx->n)
         if (gyp_set_stream_format(h, ctx->fs, ctx->n) != GYP_OK) return nullptr;
     h->params = ctx->params;
@@ -970,19 +973,29 @@ static gyp_ctx* acquire_helper(gyp_ctx* ctx) {
 int gyp_acquire_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_t stream_stride_samples,
                     int32_t n_ms, const int32_t* sat_ids_host, int32_t n_sats, gyp_acq_result* out_dev) {
     if (!ctx) return GYP_E_BAD_ARG;
-    gyp_ctx* h = (n_streams >= 4 && ctx->k && iq_dev && out_dev && n_sats > 0) ? acquire_helper(ctx) : nullptr;
-    if (!h)
+    int lanes = (ctx->k && iq_dev && out_dev && n_sats > 0 && !ctx->is_helper && !ctx->no_acq_split)
+                    ? std::max(1, std::min(ctx->acq_lanes, n_streams / 2)) : 1;
+    gyp_ctx* lane_ctx[gyp_ctx::kMaxAcqLanes] = {ctx};
+    for (int i = 1; i < lanes; ++i)
+        if (!(lane_ctx[i] = acquire_helper(ctx, i - 1))) { lanes = 1; break; }
+    if (lanes == 1)
         return acquire_search(ctx, iq_dev, n_streams, stream_stride_samples, n_ms, sat_ids_host, n_sats, 0.0,
                               ctx->params.acq_initial_spread_hz, false, out_dev);
-    const int n_a = (n_streams + 1) / 2;
     int rc;
-    if ((rc = gyp_wait_for(h, ctx))) return rc;     // the samples may still be on their way on this context's stream
-    if ((rc = acquire_search(ctx, iq_dev, n_a, stream_stride_samples, n_ms, sat_ids_host, n_sats, 0.0, ctx->params.acq_initial_spread_hz,
-                             false, out_dev))) return rc;
-    if ((rc = acquire_search(h, iq_dev + (int64_t)n_a * stream_stride_samples * 2, n_streams - n_a, stream_stride_samples, n_ms, sat_ids_host,
-                             n_sats, 0.0, ctx->params.acq_initial_spread_hz, false, out_dev + (size_t)n_a * n_sats)))
-        return fail(ctx, rc, std::string("second half of the scan: ") + h->err);
-    return gyp_wait_for(ctx, h);                    // whatever follows on this context's stream sees both halves
+    for (int i = 1; i < lanes; ++i)
+        if ((rc = gyp_wait_for(lane_ctx[i], ctx))) return rc;     // the samples may still be on their way on this context's stream
+    int s0 = 0;
+    for (int i = 0; i < lanes; ++i) {
+        const int cnt = (n_streams - s0) / (lanes - i);           // remaining streams spread evenly over the remaining lanes
+        gyp_ctx* c = lane_ctx[i];
+        if ((rc = acquire_search(c, iq_dev + (int64_t)s0 * stream_stride_samples * 2, cnt, stream_stride_samples, n_ms, sat_ids_host, n_sats,
+                                 0.0, ctx->params.acq_initial_spread_hz, false, out_dev + (size_t)s0 * n_sats)))
+            return c == ctx ? rc : fail(ctx, rc, std::string("part of the scan on a helper stream: ") + c->err);
+        s0 += cnt;
+    }
+    for (int i = 1; i < lanes; ++i)
+        if ((rc = gyp_wait_for(ctx, lane_ctx[i]))) return rc;     // whatever follows on this context's stream sees every part
+    return GYP_OK;
 }
 
 int gyp_search_level_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_t stream_stride_samples, int32_t n_ms,
