@@ -120,6 +120,7 @@ struct gyp_ctx {
     int n_cus = 256;
     bool no_pipe = false;      // GYP_NO_PIPE=1: A/B switch back to the two-workgroups-per-CU cells kernel
     int track_chunk_ms = 500;     // GYP_TRACK_CHUNK_MS: the throughput tracking kernel's launch length (0: whole blocks)
+    float symbol_tau = 1e-4f;     // GYP_SYMBOL_TAU: |Re peak| / |peak| below which the pseudosymbol is decided in float64 (test hook: 10 = always)
     bool no_shared_fwd = false;   // GYP_NO_SHARED_FWD=1: A/B switch: flat grids transform every cell's rows themselves again
     std::string err;
     // stream format
@@ -339,6 +340,7 @@ int gyp_create(int device_ordinal, gyp_ctx** out) {
     ctx->no_pipe = std::getenv("GYP_NO_PIPE") != nullptr;
     ctx->no_shared_fwd = std::getenv("GYP_NO_SHARED_FWD") != nullptr;
     ctx->no_acq_split = std::getenv("GYP_NO_ACQ_SPLIT") != nullptr;
+    if (const char* e = std::getenv("GYP_SYMBOL_TAU")) ctx->symbol_tau = (float)std::atof(e);
     if (const char* e = std::getenv("GYP_ACQ_LANES")) ctx->acq_lanes = std::max(1, std::min(gyp_ctx::kMaxAcqLanes, std::atoi(e)));
     if (const char* e = std::getenv("GYP_TRACK_CHUNK_MS")) ctx->track_chunk_ms = std::atoi(e);
     ctx->no_spec = std::getenv("GYP_NO_SPEC") != nullptr;
@@ -1225,6 +1227,7 @@ static DllScanParams dll_scan_params(gyp_bank* bank, const TrackBlockParams& p) 
     d.inv_fs = p.inv_fs; d.dll_gain = p.lp.dll_gain; d.dll_modulus = p.lp.dll_modulus; d.n_samples = p.lp.n_samples;
     d.first = 1; d.final = 1; d.from_sub = nullptr; d.sub_len = 0; d.hist_out = nullptr;
     d.prof_delta = p.prof_tail ? bank->d_prof_delta : nullptr; d.prof_from = p.prof_from; d.prof_depth = p.prof_depth;
+    d.symbol_tau = ctx->symbol_tau;
     return d;
 }
 

@@ -2720,6 +2720,11 @@ struct DllScanParams {
     int32_t first, final;
     int32_t* prof_delta;       // optional [n_chan][prof_depth], zeroed by the host: (exact - provisional) code phase of a repaired
     int32_t prof_from, prof_depth;   // millisecond, for the rows of TrackBlockParams::prof_tail
+    // The pseudosymbol is sign(Re peak) (tracker.py:316): a float32 peak whose real part is within symbol_tau of zero relative to
+    // its modulus (an unlocked channel rotating through +-90 degrees: ~1e-4 of ITS milliseconds) cannot decide it -- one
+    // mismatch in 3.6 M channel-ms at 4.092 Msps (profiles/r03_surveys.txt).  For those milliseconds the coherent prompt value
+    // at the arg-max lag is formed in float64 here, like a repair step, and the record's pseudosymbol rewritten.
+    float symbol_tau;
 };
 constexpr int kScanThreads = 256;
 constexpr int kScanChunk = 512;     // milliseconds staged in LDS at a time
@@ -2737,6 +2742,8 @@ __global__ __launch_bounds__(kScanThreads) void dll_scan_kernel(DllScanParams p)
     __shared__ float s_chipf[2048];         // this satellite's +-1 code twice over, fetched at the first repair
     __shared__ double s_a;
     __shared__ int s_s, s_pos, s_repairs;
+    __shared__ int s_nund;
+    __shared__ short s_und[kScanChunk];     // milliseconds of the chunk whose float32 peak cannot decide the pseudosymbol
     bool have_code = false;
     const int ch = blockIdx.x, tid = threadIdx.x;
     if (ch >= p.n_chan) return;
@@ -2759,8 +2766,43 @@ __global__ __launch_bounds__(kScanThreads) void dll_scan_kernel(DllScanParams p)
             s_cpin[i] = in->code_phase;
             s_disc[i] = key == kSpecKeyLost ? 0.0 : p.disc[row + c0 + i];
         }
-        if (tid == 0) s_pos = 0;
+        if (tid == 0) { s_pos = 0; s_nund = 0; }
         __syncthreads();
+        if (p.rec_out) {
+            for (int i = tid; i < len; i += kScanThreads) {
+                const gyp_track_rec* r = p.rec_out + row + c0 + i;
+                const float pr = r->peak_re, pi = r->peak_im;
+                if (s_key[i] != kSpecKeyLost && r->status != 2 && fabsf(pr) <= p.symbol_tau * __builtin_amdgcn_sqrtf(fmaf(pr, pr, pi * pi)))
+                    s_und[atomicAdd(&s_nund, 1)] = (short)i;
+            }
+            __syncthreads();
+            const int n_und = s_nund;
+            for (int u = 0; u < n_und; ++u) {   // uniform; rare (test hook GYP_SYMBOL_TAU = 10: every millisecond)
+                const int ms = c0 + s_und[u];
+                const SpecIn in = p.spec[row + ms];
+                const double du = in.doppler * p.inv_fs;
+                const double u0 = carrier_cycles(in.doppler, p.start_time[ms], in.carrier_phase);
+                if (!have_code) {
+                    for (int k = tid; k < 2048; k += kScanThreads) s_chipf[k] = chipf[k];
+                    have_code = true;
+                    __syncthreads();
+                }
+                int lag = mod_n(in.code_phase, N) + p.rec_out[row + ms].peak_offset;   // (before any repair moves the offset: same lag)
+                lag = lag >= N ? lag - N : lag;
+                double acc[6];
+                exact_epl_generic<K, kScanThreads>(stream + (int64_t)ms * N, u0, du, lag, s_chipf, tid, acc);
+                const double re = wave_sum_last(acc[0]);
+                if ((tid & 63) == 63) part[tid >> 6][0] = re;
+                __syncthreads();
+                if (tid == 0) {
+                    double t = part[0][0];
+#pragma unroll
+                    for (int w = 1; w < kScanThreads / 64; ++w) t += part[w][0];
+                    p.rec_out[row + ms].pseudosymbol = t > 0.0 ? 1 : (t < 0.0 ? -1 : 0);
+                }
+                __syncthreads();
+            }
+        }
         while (true) {   // uniform: every thread sees the same s_pos
             if (tid < 64) {   // wavefront 0 walks until the chunk ends or a millisecond needs its sums formed again
                 // Every lane carries the same values.  The common case -- processed, lags agree, accumulator in its usual range -- is

@@ -128,9 +128,13 @@ def test_forced_repairs_leave_records_and_state_exact(fs):
     # (GYP_TRACK_CHUNK_MS: the throughput kernel goes through a block in several launches -- 500 ms each by default, 37 here so
     # that launch boundaries fall inside these 400-ms blocks and inside runs of repaired milliseconds)
     runs = [("throughput", {"GYP_NO_SPEC": 1}), ("throughput, biased", {"GYP_NO_SPEC": 1, "GYP_DLL_PROV_BIAS": 20.0}),
-            ("throughput, biased, 37-ms launches", {"GYP_NO_SPEC": 1, "GYP_DLL_PROV_BIAS": 20.0, "GYP_TRACK_CHUNK_MS": 37})]
+            ("throughput, biased, 37-ms launches", {"GYP_NO_SPEC": 1, "GYP_DLL_PROV_BIAS": 20.0, "GYP_TRACK_CHUNK_MS": 37}),
+            # GYP_SYMBOL_TAU = 10: EVERY millisecond's pseudosymbol is rewritten from the float64 prompt value at the arg-max lag
+            # (by default only those whose float32 peak has |Re| < 1e-4 |peak|): a wrong lag or carrier there would show everywhere
+            ("throughput, float64 pseudosymbols", {"GYP_NO_SPEC": 1, "GYP_SYMBOL_TAU": 10.0, "GYP_DLL_PROV_BIAS": 20.0})]
     if n in (2046, 8184):
-        runs += [("speculative", {}), ("speculative, biased", {"GYP_DLL_PROV_BIAS": 20.0})]
+        runs += [("speculative", {}), ("speculative, biased", {"GYP_DLL_PROV_BIAS": 20.0}),
+                 ("speculative, float64 pseudosymbols", {"GYP_SYMBOL_TAU": 10.0})]
     states = []
     for label, env in runs:
         eng = _engine_with_env(fs, n, **env)
