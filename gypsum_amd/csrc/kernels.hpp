@@ -2721,9 +2721,11 @@ struct DllScanParams {
     int32_t* prof_delta;       // optional [n_chan][prof_depth], zeroed by the host: (exact - provisional) code phase of a repaired
     int32_t prof_from, prof_depth;   // millisecond, for the rows of TrackBlockParams::prof_tail
     // The pseudosymbol is sign(Re peak) (tracker.py:316): a float32 peak whose real part is within symbol_tau of zero relative to
-    // its modulus (an unlocked channel rotating through +-90 degrees: ~1e-4 of ITS milliseconds) cannot decide it -- one
-    // mismatch in 3.6 M channel-ms at 4.092 Msps (profiles/r03_surveys.txt).  For those milliseconds the coherent prompt value
-    // at the arg-max lag is formed in float64 here, like a repair step, and the record's pseudosymbol rewritten.
+    // its modulus (an unlocked channel rotating through +-90 degrees) cannot decide it by itself.  For those milliseconds the
+    // coherent prompt value at the arg-max lag is formed in float64 here, like a repair step, and the record's pseudosymbol
+    // rewritten.  (This removes the millisecond's own float32 rounding, ~1e-6 relative.  What it cannot remove is the carrier
+    // loop's accumulated float32 difference from the reference's state -- the loop runs on float32 peaks -- which in a channel that
+    // never locks can reach 1e-4 rad: one pseudosymbol in 3.6 M channel-ms at 4.092 Msps, profiles/r03_surveys.txt.)
     float symbol_tau;
 };
 constexpr int kScanThreads = 256;
