@@ -16,7 +16,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libgypsum_hip.so"
 SOURCES = [CSRC / "gypsum_hip.hip"]
-HEADERS = [CSRC / "corr_core.hpp", CSRC / "fft32_gen.hpp", CSRC / "kernels.hpp", CSRC / "bit_integrator.hpp", CSRC / "ingest.hpp",
+HEADERS = [CSRC / "corr_core.hpp", CSRC / "fft32_gen.hpp", *sorted(CSRC.glob("kernels*.hpp")), CSRC / "bit_integrator.hpp", CSRC / "ingest.hpp",
            CSRC.parents[1] / "include" / "gypsum_hip.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fno-slp-vectorize",
                "-Wno-unused-result"]

@@ -1,0 +1,431 @@
+// kernels_dll_exact.hpp -- the code loop re-integrated exactly behind the block tracking kernels.
+// A part of kernels.hpp (which lists every kernel); the parts build on each other in the order kernels.hpp includes them.
+#pragma once
+#include "kernels_track_block.hpp"
+
+namespace gyp {
+
+// ---------------------------------------------------------------------------------------------------------
+// The code loop, exactly.  Both block tracking kernels advance their code phase on a PROVISIONAL discriminator (float32
+// taps).  The code loop is a side chain -- nothing else of the tracker reads it -- so its exact trajectory is formed
+// afterwards from the hand-over records (SpecIn: the Doppler, carrier phase and code phase each millisecond ran with):
+//   dll_exact_wave_kernel / dll_exact_block_kernel   tracker.py:297 in float64 for every (channel, millisecond) at the lag the
+//                       tracking kernel used: raw float32 samples x float64 carrier, float64 sums; all of them in parallel;
+//   dll_scan_kernel     one workgroup per channel, the milliseconds in order: tracker.py:298-303 from those values.  Where
+//                       its int(self.phase) differs from the provisional one (the two accumulators straddle an integer: about
+//                       once per 1e6 channel-ms, for a few milliseconds each time) the millisecond's sums are formed on the
+//                       spot for the right lag (a "repair" step) and the record's code phase / peak offset corrected.
+// The exact state travels in DllExact from sub-block to sub-block and is written back into the channel state by the last scan
+// of a call, so the next call -- and its provisional loop -- starts from it.
+// ---------------------------------------------------------------------------------------------------------
+struct DllExactParams {
+    const cf* iq;
+    int64_t stream_stride;
+    int32_t n_ms, ms_begin, ms_end;
+    const double* start_time;
+    const ChanState* states;
+    int32_t n_chan;
+    const SpecIn* spec;
+    double* disc_out;          // [n_chan][n_ms]
+    const float* chipf;        // CodeTables::chipf
+    double inv_fs;
+    const int32_t* only_if;    // optional: only channels with only_if[ch] != 0 (the re-run of failed speculations) ...
+    const int32_t* from_sub;   // ... and of those only the milliseconds from sub-block from_sub[ch] on (sub_len milliseconds each)
+    int32_t sub_len;
+};
+
+// acc * w + x  (complex): one Horner step of sum_i x_i w^i
+__device__ __forceinline__ double2 horner64(double2 acc, double2 w, double2 x) {
+    return make_double2(fma(acc.x, w.x, fma(-acc.y, w.y, x.x)), fma(acc.x, w.y, fma(acc.y, w.x, x.y)));
+}
+__device__ __forceinline__ double2 cvt64(cf x) { return make_double2((double)x.x, (double)x.y); }
+// One wavefront per (channel, millisecond), any K <= 8.  With s = K q + r the samples are taken in REPLICA-aligned windows:
+// "virtual chip" m (m = -1 .. 1022) is the K samples n = K m + r + i, i < K -- exactly the samples that meet replica chip
+// j = (m - q) mod 1023 at lag s -- so no window is split between two code chips and nothing in the arithmetic depends on r
+// (it only moves the load address by r samples; the vector loads are 8-byte aligned).  The circular block is cut at its ends:
+// window -1 holds the first r samples (its i < K - r fall before the block: zero), window 1022 the last K - r; both meet
+// replica chip (1022 - q) mod 1023, and the carrier of sample n is exp(-2 pi i (u0 + du n)) for either.  1024 windows = 64
+// lanes x 16: lane l owns m = l + 64 c - 1 (consecutive lanes read consecutive 8K-byte pieces).  Per window
+//     h = sum_i x_i rho^i  (Horner, rho = exp(-2 pi i du)),   P += chip[j] h,
+//     E += (chip[j] - chip[j+1]) x_{K-1}  (lag s-1 sees the next replica chip at a window's last sample),
+//     L += (chip[j-1] - chip[j]) x_0      (lag s+1 the previous one at its first);
+// windows are folded last one first with the window-stride rotation S = rho^(64 K) (Horner again: acc = acc S + term), the
+// lane's anchor carrier (times rho^(K-1) for E) is applied once at the end, six DPP reductions finish the unit.  No LDS, no
+// barrier; ~46 float64 operations + 19 converts per window.
+template <int K, bool EDGE>
+__device__ __forceinline__ void exact_window(const cf* __restrict__ block, int m, int r, int q, const float* __restrict__ chipf,
+                                             double2 rho, double2 step, double2& sp, double2& se, double2& sl) {
+    constexpr int N = K * kChips;
+    const int n0 = K * m + r;                        // first sample of the window; [n0, n0 + K) leaves [0, N) only at m = -1 / 1022
+    cf x[K];
+    if constexpr (EDGE) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int n = n0 + i;
+            const cf v = block[min(max(n, 0), N - 1)];
+            const bool in = n >= 0 && n < N;
+            x[i] = make_float2(in ? v.x : 0.f, in ? v.y : 0.f);
+        }
+    } else {
+        typedef float4 __attribute__((aligned(8))) float4_a8;
+        typedef float2 __attribute__((aligned(8))) float2_a8;
+        const cf* src = block + n0;
+#pragma unroll
+        for (int i = 0; i + 1 < K; i += 2) {
+            const float4 v = *reinterpret_cast<const float4_a8*>(src + i);
+            x[i] = make_float2(v.x, v.y);
+            x[i + 1] = make_float2(v.z, v.w);
+        }
+        if (K & 1) x[K - 1] = *reinterpret_cast<const float2_a8*>(src + K - 1);
+    }
+    int j = m - q;
+    j = j < 0 ? j + kChips : j;                      // (m - q) mod 1023 for m >= 0; m = -1 -> (1022 - q) mod 1023 (q <= 1022)
+    j = j < 0 ? j + kChips : j;
+    const float* cp = chipf + j + kChips;
+    const float cm1 = cp[-1], c0 = cp[0], cp1 = cp[1];
+    const double dj = (double)c0, gl = (double)(cm1 - c0), ge = (double)(c0 - cp1);
+    double2 h = cvt64(x[K - 1]);
+#pragma unroll
+    for (int i = K - 2; i >= 0; --i) h = horner64(h, rho, cvt64(x[i]));
+    const double2 xe = cvt64(x[K - 1]), xl = cvt64(x[0]);
+    sp = horner64(sp, step, make_double2(dj * h.x, dj * h.y));
+    se = horner64(se, step, make_double2(ge * xe.x, ge * xe.y));
+    sl = horner64(sl, step, make_double2(gl * xl.x, gl * xl.y));
+}
+template <int K>
+__device__ __forceinline__ double2 cpow_km1(double2 w) {   // w^(K-1), K <= 8
+    double2 r = make_double2(1.0, 0.0);
+#pragma unroll
+    for (int i = 0; i < K - 1; ++i) r = cmul64(r, w);
+    return r;
+}
+template <int K>
+__global__ __launch_bounds__(256, 4) void dll_exact_wave_kernel(DllExactParams p) {
+    static_assert(K <= 8, "a window's samples in registers");
+    constexpr int N = K * kChips;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n_units = p.n_chan * (p.ms_end - p.ms_begin);
+    const int n_groups = (n_units + 3) >> 2;
+    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        // four consecutive units per workgroup, consecutive groups inside an XCD's slice: the channels of a stream-ms (shared IQ) meet in one L2
+        const int u = ((n_groups & 7) ? g : xcd_contiguous(g, n_groups)) * 4 + wave;
+        if (u >= n_units) continue;
+        const int ms = p.ms_begin + u / p.n_chan, ch = u % p.n_chan;
+        if (p.only_if && !p.only_if[ch]) continue;                // wave-uniform
+        if (p.from_sub && ms < p.from_sub[ch] * p.sub_len) continue;
+        const int64_t at = (int64_t)ch * p.n_ms + ms;
+        const SpecIn in = p.spec[at];
+        if (in.key == kSpecKeyLost) continue;                     // wave-uniform
+        const ChanState* st = p.states + ch;
+        const int sat = __builtin_amdgcn_readfirstlane(st->sat_id), stream = __builtin_amdgcn_readfirstlane(st->stream);
+        const cf* block = p.iq + (int64_t)stream * p.stream_stride + (int64_t)ms * N;
+        const float* chipf = p.chipf + (sat - 1) * 2048;
+        const double du = in.doppler * p.inv_fs;
+        const double u0 = carrier_cycles(in.doppler, p.start_time[ms], in.carrier_phase);
+        const int sN = __builtin_amdgcn_readfirstlane(mod_n(in.code_phase, N));
+        const int q = sN / K, r = sN % K;
+        const double2 rho = carrier64(du), step = carrier64(du * (double)(K * 64));
+        double2 sp = make_double2(0.0, 0.0), se = sp, sl = sp;
+        exact_window<K, true>(block, lane + 64 * 15 - 1, r, q, chipf, rho, step, sp, se, sl);     // holds window 1022 (lane 63)
+#pragma unroll 2
+        for (int c = 14; c >= 1; --c) exact_window<K, false>(block, lane + 64 * c - 1, r, q, chipf, rho, step, sp, se, sl);
+        exact_window<K, true>(block, lane - 1, r, q, chipf, rho, step, sp, se, sl);               // holds window -1 (lane 0)
+        const double2 anchor = carrier64(u0 + du * (double)(K * (lane - 1) + r));
+        const double2 pp = cmul64(sp, anchor), ee = cmul64(cmul64(se, cpow_km1<K>(rho)), anchor), ll = cmul64(sl, anchor);
+        double acc[6] = {pp.x, pp.y, ee.x, ee.y, ll.x, ll.y};
+#pragma unroll
+        for (int v = 0; v < 6; ++v) acc[v] = wave_sum_last(acc[v]);
+        if (lane == 63) p.disc_out[at] = dll_discriminator_exact(acc);
+    }
+}
+// Rates above 8 samples per chip (16.368 ... 49.104 Msps): one 256-thread workgroup per unit walks the block (exact_epl_generic).
+template <int K>
+__global__ __launch_bounds__(256) void dll_exact_block_kernel(DllExactParams p) {
+    constexpr int N = K * kChips;
+    __shared__ double part[4][6];
+    const int tid = threadIdx.x;
+    const int n_units = p.n_chan * (p.ms_end - p.ms_begin);
+    for (int v = blockIdx.x; v < n_units; v += gridDim.x) {
+        const int u = (n_units & 7) ? v : xcd_contiguous(v, n_units);
+        const int ms = p.ms_begin + u / p.n_chan, ch = u % p.n_chan;
+        if (p.only_if && !p.only_if[ch]) continue;                // uniform
+        if (p.from_sub && ms < p.from_sub[ch] * p.sub_len) continue;
+        const int64_t at = (int64_t)ch * p.n_ms + ms;
+        const SpecIn in = p.spec[at];
+        if (in.key == kSpecKeyLost) continue;                     // uniform
+        const ChanState* st = p.states + ch;
+        const cf* block = p.iq + (int64_t)st->stream * p.stream_stride + (int64_t)ms * N;
+        const double du = in.doppler * p.inv_fs;
+        const double u0 = carrier_cycles(in.doppler, p.start_time[ms], in.carrier_phase);
+        double acc[6];
+        exact_epl_generic<K, 256>(block, u0, du, mod_n(in.code_phase, N), p.chipf + (st->sat_id - 1) * 2048, tid, acc);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] = wave_sum_last(acc[k]);
+        __syncthreads();                       // the previous unit's reader is done with `part`
+        if ((tid & 63) == 63) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) part[tid >> 6][k] = acc[k];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double ex[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ex[k] = (part[0][k] + part[1][k]) + (part[2][k] + part[3][k]);
+            p.disc_out[at] = dll_discriminator_exact(ex);
+        }
+    }
+}
+
+struct DllScanParams {
+    const cf* iq;
+    int64_t stream_stride;
+    int32_t n_ms, ms_begin, ms_end;
+    const double* start_time;
+    ChanState* states;
+    const ChanState* ckpt;     // the states before the call, or null: the tracking kernel left them in `exact` (throughput path)
+    int32_t n_chan;
+    const SpecIn* spec;
+    const double* disc;
+    gyp_track_rec* rec_out;
+    DllExact* exact;
+    const int32_t* bad;        // optional per-channel flags of failed speculations ...
+    int32_t only_bad;          // ... 0: flagged channels are left alone (the re-run gives them everything); 1: ONLY flagged ones (after it)
+    const int32_t* from_sub;   // only_bad: the re-run started at sub-block from_sub[ch] (sub_len milliseconds each)
+    int32_t sub_len;
+    DllExact* hist_out;        // optional: the loop's state at the end of this launch's range is also left here (the next sub-block's checkpoint)
+    const float* chipf;
+    double inv_fs, dll_gain, dll_modulus, n_samples;
+    int32_t first, final;
+    int32_t* prof_delta;       // optional [n_chan][prof_depth], zeroed by the host: (exact - provisional) code phase of a repaired
+    int32_t prof_from, prof_depth;   // millisecond, for the rows of TrackBlockParams::prof_tail
+    // The pseudosymbol is sign(Re peak) (tracker.py:316): a float32 peak whose real part is within symbol_tau of zero relative to
+    // its modulus (an unlocked channel rotating through +-90 degrees) cannot decide it by itself.  For those milliseconds the
+    // coherent prompt value at the arg-max lag is formed in float64 here, like a repair step, and the record's pseudosymbol
+    // rewritten.  (This removes the millisecond's own float32 rounding, ~1e-6 relative.  What it cannot remove is the carrier
+    // loop's accumulated float32 difference from the reference's state -- the loop runs on float32 peaks -- which in a channel that
+    // never locks can reach 1e-4 rad: one pseudosymbol in 3.6 M channel-ms at 4.092 Msps, profiles/r03_surveys.txt.)
+    float symbol_tau;
+};
+constexpr int kScanThreads = 256;
+constexpr int kScanChunk = 512;     // milliseconds staged in LDS at a time
+constexpr int kSpecKeyRepaired = -3;
+template <int K>
+__global__ __launch_bounds__(kScanThreads) void dll_scan_kernel(DllScanParams p) {
+    constexpr int N = K * kChips;
+    // One chunk of the channel's hand-over data in LDS: loaded and written back by all threads (coalesced), walked by wavefront 0
+    // alone (every lane the same values: broadcast reads, no cross-lane traffic) -- the serial loop never touches global memory.
+    __shared__ double s_disc[kScanChunk];   // in: tracker.py:297 at the provisional lag; out: at the lag the exact loop ran with
+    __shared__ int s_cpin[kScanChunk];      // provisional code phase of the millisecond
+    __shared__ int s_cpout[kScanChunk];     // exact code phase after the update (the record's)
+    __shared__ int s_key[kScanChunk];       // SpecIn::key; kSpecKeyRepaired once the millisecond has been repaired
+    __shared__ double part[kScanThreads / 64][6];
+    __shared__ float s_chipf[2048];         // this satellite's +-1 code twice over, fetched at the first repair
+    __shared__ double s_a;
+    __shared__ int s_s, s_pos, s_repairs;
+    __shared__ int s_nund;
+    __shared__ short s_und[kScanChunk];     // milliseconds of the chunk whose float32 peak cannot decide the pseudosymbol
+    bool have_code = false;
+    const int ch = blockIdx.x, tid = threadIdx.x;
+    if (ch >= p.n_chan) return;
+    if (p.bad && (p.bad[ch] != 0) != (p.only_bad != 0)) return;
+    const ChanState* st = p.states + ch;
+    if (tid == 0) {
+        if (p.first && p.ckpt) { s_a = p.ckpt[ch].dll_phase; s_s = p.ckpt[ch].code_phase; s_repairs = 0; }
+        else { const DllExact x = p.exact[ch]; s_a = x.dll; s_s = x.code_phase; s_repairs = p.first ? 0 : x.repairs; }
+    }
+    const float* chipf = p.chipf + (st->sat_id - 1) * 2048;
+    const cf* stream = p.iq + (int64_t)st->stream * p.stream_stride;
+    const int64_t row = (int64_t)ch * p.n_ms;
+    const int ms_first = (p.only_bad && p.from_sub) ? max(p.ms_begin, min(p.from_sub[ch], (p.n_ms - 1) / max(p.sub_len, 1)) * p.sub_len) : p.ms_begin;
+    for (int c0 = ms_first; c0 < p.ms_end; c0 += kScanChunk) {
+        const int len = min(kScanChunk, p.ms_end - c0);
+        for (int i = tid; i < len; i += kScanThreads) {
+            const SpecIn* in = p.spec + row + c0 + i;
+            const int key = in->key;
+            s_key[i] = key;
+            s_cpin[i] = in->code_phase;
+            s_disc[i] = key == kSpecKeyLost ? 0.0 : p.disc[row + c0 + i];
+        }
+        if (tid == 0) { s_pos = 0; s_nund = 0; }
+        __syncthreads();
+        if (p.rec_out) {
+            for (int i = tid; i < len; i += kScanThreads) {
+                const gyp_track_rec* r = p.rec_out + row + c0 + i;
+                const float pr = r->peak_re, pi = r->peak_im;
+                if (s_key[i] != kSpecKeyLost && r->status != 2 && fabsf(pr) <= p.symbol_tau * __builtin_amdgcn_sqrtf(fmaf(pr, pr, pi * pi)))
+                    s_und[atomicAdd(&s_nund, 1)] = (short)i;
+            }
+            __syncthreads();
+            const int n_und = s_nund;
+            for (int u = 0; u < n_und; ++u) {   // uniform; rare (test hook GYP_SYMBOL_TAU = 10: every millisecond)
+                const int ms = c0 + s_und[u];
+                const SpecIn in = p.spec[row + ms];
+                const double du = in.doppler * p.inv_fs;
+                const double u0 = carrier_cycles(in.doppler, p.start_time[ms], in.carrier_phase);
+                if (!have_code) {
+                    for (int k = tid; k < 2048; k += kScanThreads) s_chipf[k] = chipf[k];
+                    have_code = true;
+                    __syncthreads();
+                }
+                int lag = mod_n(in.code_phase, N) + p.rec_out[row + ms].peak_offset;   // (before any repair moves the offset: same lag)
+                lag = lag >= N ? lag - N : lag;
+                double acc[6];
+                exact_epl_generic<K, kScanThreads>(stream + (int64_t)ms * N, u0, du, lag, s_chipf, tid, acc);
+                const double re = wave_sum_last(acc[0]);
+                if ((tid & 63) == 63) part[tid >> 6][0] = re;
+                __syncthreads();
+                if (tid == 0) {
+                    double t = part[0][0];
+#pragma unroll
+                    for (int w = 1; w < kScanThreads / 64; ++w) t += part[w][0];
+                    p.rec_out[row + ms].pseudosymbol = t > 0.0 ? 1 : (t < 0.0 ? -1 : 0);
+                }
+                __syncthreads();
+            }
+        }
+        while (true) {   // uniform: every thread sees the same s_pos
+            if (tid < 64) {   // wavefront 0 walks until the chunk ends or a millisecond needs its sums formed again
+                // Every lane carries the same values.  The common case -- processed, lags agree, accumulator in its usual range -- is
+                // straight-line vector code behind ONE scalar branch per millisecond (each vector-to-scalar hand-over costs the
+                // pipeline's depth), with the next millisecond's hand-over values already requested from LDS.
+                double a = s_a;
+                int s = s_s, i = __builtin_amdgcn_readfirstlane(s_pos);   // (i: scalar loop control)
+                bool stop = false;
+                int key_n = 0, cp_n = 0;
+                double d_n = 0.0;
+                if (i < len) { key_n = s_key[i]; cp_n = s_cpin[i]; d_n = s_disc[i]; }
+                while (i < len && !stop) {   // uniform
+                    const int key = key_n, cp = cp_n;
+                    const double d = d_n;
+                    if (i + 1 < len) { key_n = s_key[i + 1]; cp_n = s_cpin[i + 1]; d_n = s_disc[i + 1]; }
+                    const double dll = __dadd_rn(a, __dmul_rn(d, p.dll_gain));   // tracker.py:298: product and sum rounded separately, as Python does
+                    const double whole = trunc(dll);
+                    // (bitwise, not short-circuit: one predicate, no branch per clause)
+                    const int usual = (int)(key != kSpecKeyLost) & ((int)(key == kSpecKeyRepaired) | (int)(s == cp)) &
+                                      (int)(fabs(whole) < 2147483648.0) & (int)(dll > -p.dll_modulus) & (int)(dll < 2.0 * p.dll_modulus);
+                    if (__builtin_amdgcn_readfirstlane(usual)) {
+                        double r = dll >= p.dll_modulus ? dll - p.dll_modulus : dll;   // pymod_uniform's fast range
+                        r += (r != 0.0 && r < 0.0) ? p.dll_modulus : 0.0;
+                        r += r < 0.0 ? p.dll_modulus : 0.0;
+                        a = r;
+                        s = (int)whole;
+                        if (tid == 0) s_cpout[i] = s;
+                        ++i;
+                        continue;
+                    }
+                    if (uniform(key == kSpecKeyLost)) {                   // not processed: the loop state stands (the status-2 record carries it)
+                        if (tid == 0) s_cpout[i] = s;
+                        ++i;
+                        continue;
+                    }
+                    if (uniform(key != kSpecKeyRepaired && s != cp)) { stop = true; break; }
+                    double r = pymod_uniform(dll, p.dll_modulus);         // the accumulator outside its usual range
+                    r += r < 0.0 ? p.dll_modulus : 0.0;
+                    a = r;
+                    s = uniform(fabs(whole) < 2147483648.0) ? (int)whole : code_phase_beyond_int32(whole, p.n_samples);
+                    if (tid == 0) s_cpout[i] = s;
+                    ++i;
+                }
+                if (tid == 0) { s_a = a; s_s = s; s_pos = i; }
+            }
+            __syncthreads();
+            const int pos = s_pos;
+            if (pos >= len) break;
+            {   // repair: this millisecond's float64 sums for the lag the exact loop is at
+                const int ms = c0 + pos;
+                const SpecIn in = p.spec[row + ms];
+                const double du = in.doppler * p.inv_fs;
+                const double u0 = carrier_cycles(in.doppler, p.start_time[ms], in.carrier_phase);
+                if (!have_code) {   // uniform
+                    for (int k = tid; k < 2048; k += kScanThreads) s_chipf[k] = chipf[k];
+                    have_code = true;
+                    __syncthreads();
+                }
+                double acc[6];
+                exact_epl_generic<K, kScanThreads>(stream + (int64_t)ms * N, u0, du, mod_n(s_s, N), s_chipf, tid, acc);
+#pragma unroll
+                for (int v = 0; v < 6; ++v) acc[v] = wave_sum_last(acc[v]);
+                if ((tid & 63) == 63) {
+#pragma unroll
+                    for (int v = 0; v < 6; ++v) part[tid >> 6][v] = acc[v];
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    double ex[6];
+#pragma unroll
+                    for (int v = 0; v < 6; ++v) {
+                        double t = part[0][v];
+#pragma unroll
+                        for (int w = 1; w < kScanThreads / 64; ++w) t += part[w][v];
+                        ex[v] = t;
+                    }
+                    s_disc[pos] = dll_discriminator_exact(ex);
+                    s_key[pos] = kSpecKeyRepaired;
+                    if (p.rec_out) {   // the arg-max LAG stands; its index in the profile of the PRN rolled by s moves with s
+                        gyp_track_rec* rec = p.rec_out + row + ms;
+                        int lag = rec->peak_offset + mod_n(in.code_phase, N);
+                        lag = lag >= N ? lag - N : lag;
+                        const int k2 = lag - mod_n(s_s, N);
+                        rec->peak_offset = k2 < 0 ? k2 + N : k2;
+                    }
+                    if (p.prof_delta && ms >= p.prof_from)
+                        p.prof_delta[(int64_t)ch * p.prof_depth + (ms - p.prof_from)] = mod_n(s_s, N) - mod_n(in.code_phase, N);
+                    ++s_repairs;
+                }
+                __syncthreads();
+            }
+        }
+        // write-back: the record's discriminator and code phase
+        if (p.rec_out) {
+            for (int i = tid; i < len; i += kScanThreads) {
+                gyp_track_rec* rec = p.rec_out + row + c0 + i;
+                rec->code_phase = s_cpout[i];
+                if (s_key[i] != kSpecKeyLost) rec->discriminator = (float)s_disc[i];
+            }
+        }
+        __syncthreads();   // the arrays are reused by the next chunk
+    }
+    if (tid == 0) {
+        DllExact x; x.dll = s_a; x.code_phase = s_s; x.repairs = s_repairs;
+        p.exact[ch] = x;
+        if (p.hist_out) p.hist_out[ch] = x;
+        if (p.final) { p.states[ch].dll_phase = s_a; p.states[ch].code_phase = s_s; }
+    }
+}
+
+__global__ void bank_reset_kernel(ChanState* states, const gyp_chan_init* inits, int n_chan) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_chan) return;
+    ChanState* s = states + i;
+    const gyp_chan_init in = inits[i];
+    s->stream = in.stream; s->sat_id = in.sat_id;
+    s->doppler = in.doppler_hz; s->carrier_phase = in.carrier_phase;
+    s->dll_phase = (double)in.code_phase;   // tracker.py:224
+    s->last_watchdog_time = 0.0;
+    s->n_steps = 0;
+    s->code_phase = in.code_phase;
+    s->lost = 0;
+    s->win_centre1 = 0; s->pad0 = 0;
+    s->sums = LockSums{};
+}
+
+// acquisition.py:180-189 on a flat grid's records: per (stream, satellite) the FIRST bin holding the largest profile
+// maximum, with that profile's arg-max and strength (utils.py:111-116, float64 from the reduced record).
+__global__ void grid_best_bin_kernel(const gyp_cell* __restrict__ cells, int n_rows, int n_bins, int n_per_ms, gyp_best_bin* out) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    const gyp_cell* c = cells + (int64_t)row * n_bins;
+    int best = 0;
+    float pk = c[0].peak;
+    for (int b = 1; b < n_bins; ++b)
+        if (c[b].peak > pk) { pk = c[b].peak; best = b; }
+    const gyp_cell w = c[best];
+    gyp_best_bin o;
+    o.bin = best; o.argmax = w.argmax; o.peak = w.peak; o.reserved = 0;
+    const double p = (double)w.peak;
+    o.strength = p / ((w.sum - (double)w.n_max * p) / (double)(n_per_ms - w.n_max));
+    out[row] = o;
+}
+
+}  // namespace gyp
