@@ -29,16 +29,27 @@ def find_hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm); libgypsum_hip has no CPU fallback")
 
 
-STAMP = CSRC / "libgypsum_hip.so.rates"   # "full", or the rate list of a development build (tools/dev_build.sh)
+STAMP = CSRC / "libgypsum_hip.so.rates"   # "full <sha256 of sources + flags>", or the rate list of a development build (tools/dev_build.sh)
+
+
+def source_hash() -> str:
+    """sha256 over the compile flags and the CONTENT of every source and header: "stale" means the content changed (a fresh
+    checkout or a copy to another box changes modification times, not this)."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    for p in sorted(SOURCES + HEADERS):
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    return h.hexdigest()
 
 
 def is_stale() -> bool:
-    if not LIB.exists():
+    if not LIB.exists() or not STAMP.exists():
         return True
-    if not STAMP.exists() or STAMP.read_text().strip() != "full":   # a K = 8-only development build must not ship
-        return True
-    t = LIB.stat().st_mtime
-    return any(p.stat().st_mtime > t for p in SOURCES + HEADERS)
+    stamp = STAMP.read_text().split()
+    # a K = 8-only development build must not ship; a full build is current exactly when it was made from these sources
+    return len(stamp) != 2 or stamp[0] != "full" or stamp[1] != source_hash()
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
@@ -47,8 +58,9 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     cmd = [find_hipcc(), *HIPCC_FLAGS, *[str(s) for s in SOURCES], "-o", str(LIB)]
     if verbose:
         print("[gypsum_amd.build]", " ".join(cmd), flush=True)
+    digest = source_hash()   # of what is about to be compiled
     subprocess.run(cmd, check=True, cwd=str(CSRC))
-    STAMP.write_text("full\n")
+    STAMP.write_text(f"full {digest}\n")
     return LIB
 
 

@@ -118,10 +118,10 @@ struct gyp_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cus = 256;
-    bool no_pipe = false;      // GYP_NO_PIPE=1: A/B switch back to the two-workgroups-per-CU cells kernel
-    int track_chunk_ms = 500;     // GYP_TRACK_CHUNK_MS: the throughput tracking kernel's launch length (0: whole blocks)
-    float symbol_tau = 1e-4f;     // GYP_SYMBOL_TAU: |Re peak| / |peak| below which the pseudosymbol is decided in float64 (test hook: 10 = always)
-    bool no_shared_fwd = false;   // GYP_NO_SHARED_FWD=1: A/B switch: flat grids transform every cell's rows themselves again
+    bool no_pipe = false;      // gyp_debug_set("no_pipe"): A/B switch back to the two-workgroups-per-CU cells kernel
+    int track_chunk_ms = 500;     // gyp_debug_set("track_chunk_ms"): the throughput tracking kernel's launch length (0: whole blocks)
+    float symbol_tau = 1e-4f;     // gyp_debug_set("symbol_tau"): |Re peak| / |peak| below which the pseudosymbol is decided in float64 (test hook: 10 = always)
+    bool no_shared_fwd = false;   // gyp_debug_set("no_shared_fwd"): A/B switch: flat grids transform every cell's rows themselves again
     std::string err;
     // stream format
     int64_t fs = 0;
@@ -138,20 +138,21 @@ struct gyp_ctx {
     void* comm = nullptr;
     int comm_rank = 0, comm_world = 1;
     gyp_params params;
-    bool no_spec = false;        // GYP_NO_SPEC=1: A/B switch: lightly loaded banks use the throughput kernel too
-    int spec_fail_at = -1;       // GYP_SPEC_FAIL_AT=ms (test hook): channel 0's verification is made to fail at that millisecond of a block
-    bool spec_debug = false;     // GYP_SPEC_DEBUG=1: per-ms window dump of the speculative tracker (gyp_debug_spec_read)
-    double dll_prov_bias = 0.0;  // GYP_DLL_PROV_BIAS=x (test hook): added to the speculative kernel's PROVISIONAL discriminator, so
+    bool spec_redo = true;       // gyp_debug_set("spec_redo"): 0 = A/B switch back to re-running a failed speculation on the throughput kernel
+    int exact_prefetch = 0;      // gyp_debug_set("exact_prefetch"): A/B switch of dll_exact_wave_kernel's software prefetch depth
+    bool no_spec = false;        // gyp_debug_set("no_spec"): A/B switch: lightly loaded banks use the throughput kernel too
+    int spec_fail_at = -1;       // gyp_debug_set("spec_fail_at", ms) (test hook): channel 0's verification is made to fail at that millisecond of a block
+    bool spec_debug = false;     // gyp_debug_set("spec_debug"): per-ms window dump of the speculative tracker (gyp_debug_spec_read)
+    double dll_prov_bias = 0.0;  // gyp_debug_set("dll_prov_bias", x) (test hook): added to the speculative kernel's PROVISIONAL discriminator, so
                                  // that dll_scan_kernel's repair path runs; results must not depend on it
-    // (the GYP_* environment switches are read ONCE, in gyp_create: no getenv on a hot entry point)
     long long* d_prof = nullptr; // debug: per-phase cycle counters of track_block workgroup 0
     // gyp_debug_track_timing: HIP events around the three launches of the throughput tracking path (tracking kernel, exact sums, scan)
     hipEvent_t ev_order = nullptr;   // gyp_wait_for(waiter, this): recorded on this context's stream
     static constexpr int kMaxAcqLanes = 4;
     gyp_ctx* helper[kMaxAcqLanes - 1] = {};   // gyp_acquire_dev: the other parts of a multi-stream scan run here (own stream, scratch, tables)
-    int acq_lanes = 2;               // GYP_ACQ_LANES
+    int acq_lanes = 2;               // gyp_debug_set("acq_lanes")
     bool is_helper = false;
-    bool no_acq_split = false;       // GYP_NO_ACQ_SPLIT=1: A/B switch
+    bool no_acq_split = false;       // gyp_debug_set("no_acq_split"): A/B switch
     bool time_track = false;
     bool track_timed = false;
     int track_launches = 0;     // launches of the tracking kernel behind the last timed call   // the events below have been recorded since timing was switched on (the speculative path records none)
@@ -177,7 +178,15 @@ struct gyp_bank {
     size_t spec_cap = 0;         // in records
     int32_t* d_bad = nullptr;
     int32_t* d_bad_from = nullptr;   // per channel: first verify sub-block that failed
-    DllExact* d_hist = nullptr;      // [kMaxSub][n_chan] the exact code loop at the sub-block starts
+    DllExact* d_hist = nullptr;      // [ckpt_cap + 1][n_chan] the exact code loop at the sub-block starts
+    int ckpt_cap = 0;                // sub-blocks d_ckpt / d_hist have room for (sized by the n_sub in use, grown on demand)
+    // round protocol of the speculative tracker (SpecCtl, kernels_track_block.hpp)
+    SpecCtl* d_ctl = nullptr;        // [n_chan]
+    int32_t* d_trk = nullptr;        // [rounds_cap][n_chan]
+    int32_t* d_fail = nullptr;       // [rounds_cap][n_chan]
+    int rounds_cap = 0;
+    int32_t* d_redo_stats = nullptr; // [4] of the last block: sub-blocks, rounds, sub-block re-dos, channels finished by the transform kernel
+    hipEvent_t ev_vring[3] = {nullptr, nullptr, nullptr};
     float* d_dbg = nullptr;      // GYP_SPEC_DEBUG: per-ms window dump of the last block
     size_t dbg_cap = 0;
     hipStream_t verify_stream = nullptr;
@@ -337,18 +346,9 @@ int gyp_create(int device_ordinal, gyp_ctx** out) {
     gyp_ctx* ctx = new gyp_ctx();
     ctx->device = device_ordinal;
     ctx->n_cus = prop.multiProcessorCount;
-    ctx->no_pipe = std::getenv("GYP_NO_PIPE") != nullptr;
-    ctx->no_shared_fwd = std::getenv("GYP_NO_SHARED_FWD") != nullptr;
-    ctx->no_acq_split = std::getenv("GYP_NO_ACQ_SPLIT") != nullptr;
-    if (const char* e = std::getenv("GYP_SYMBOL_TAU")) ctx->symbol_tau = (float)std::atof(e);
-    if (const char* e = std::getenv("GYP_ACQ_LANES")) ctx->acq_lanes = std::max(1, std::min(gyp_ctx::kMaxAcqLanes, std::atoi(e)));
-    if (const char* e = std::getenv("GYP_TRACK_CHUNK_MS")) ctx->track_chunk_ms = std::atoi(e);
-    ctx->no_spec = std::getenv("GYP_NO_SPEC") != nullptr;
-    ctx->spec_debug = std::getenv("GYP_SPEC_DEBUG") != nullptr;
-    if (const char* b = std::getenv("GYP_DLL_PROV_BIAS")) ctx->dll_prov_bias = std::atof(b);
-    if (const char* b = std::getenv("GYP_SPEC_FAIL_AT")) ctx->spec_fail_at = std::atoi(b);
+    // (no GYP_* environment variable is read here or anywhere else in the library except GYP_RCCL_LIB, a deployment's library path:
+    // the A/B switches and test hooks below are set through gyp_debug_set by whoever wants them)
     gyp_params_default(&ctx->params);
-    if (const char* kv = std::getenv("GYP_SPEC_KAPPA")) ctx->params.spec_confidence_kappa = std::atof(kv);
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         delete ctx;
@@ -608,8 +608,17 @@ static int launch_track_block(gyp_ctx* ctx, const TrackBlockParams& p, int mode)
     return (p.prof || p.prof_tail) ? launch_track_block_t<true>(ctx, p, mode) : launch_track_block_t<false>(ctx, p, mode);
 }
 static int launch_track_verify(gyp_ctx* ctx, const TrackVerifyParams& p, hipStream_t stream) {
-    const int n_units = p.n_chan * (p.ms_end - p.ms_begin);
-    const int grid = std::max(8, std::min(n_units, ctx->n_cus * blocks_per_cu(ctx->k)) & ~7);
+    const int n_units = p.n_chan * (p.trk_round ? p.sub_len : p.ms_end - p.ms_begin);
+    int grid = std::max(8, std::min(n_units, ctx->n_cus * blocks_per_cu(ctx->k)) & ~7);
+    if (p.trk_round && ctx->k == 8) {
+        // Round protocol: this launch runs beside the NEXT round's tracking launch, whose workgroups (one per channel, 97 KB of LDS)
+        // fit no CU that already holds one of these (78 KB): a verify launch that fills the chip first makes the tracking launch wait
+        // for it to drain, every round (0.3 us per ms-step of a 12-channel bank).  One workgroup per CU on all but the CUs the channels
+        // need (workgroup b goes to XCD b % 8; inside an XCD the dispatcher fills the emptiest CU first) leaves those CUs empty.
+        const int per_xcd = ctx->n_cus / 8, need = (p.n_chan + 7) / 8 + 1;
+        grid = 8 * std::max(4, per_xcd - need);
+        grid = std::max(8, std::min(grid, n_units & ~7));
+    }
     if (ctx->k == 2) {
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(track_verify_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds_bytes<2>()));
@@ -632,7 +641,9 @@ static int launch_dll_exact(gyp_ctx* ctx, const DllExactParams& p, hipStream_t s
     case K:                                                                                                                    \
         if constexpr (K <= 8) {                                                                                                \
             const int grid = std::max(1, std::min((n_units + 3) / 4, ctx->n_cus * 8));                                         \
-            hipLaunchKernelGGL(dll_exact_wave_kernel<(K <= 8 ? K : 8)>, dim3(grid), dim3(256), 0, stream, p);                   \
+            constexpr int KK = K <= 8 ? K : 8;                                                                                 \
+            if (ctx->exact_prefetch == 1) hipLaunchKernelGGL((dll_exact_wave_kernel<KK, 1, 4>), dim3(grid), dim3(256), 0, stream, p); \
+            else hipLaunchKernelGGL((dll_exact_wave_kernel<KK, 0, 4>), dim3(grid), dim3(256), 0, stream, p);                     \
         } else {                                                                                                               \
             const int grid = std::max(1, std::min(n_units, ctx->n_cus * 8));                                                   \
             hipLaunchKernelGGL(dll_exact_block_kernel<K>, dim3(grid), dim3(256), 0, stream, p);                                 \
@@ -969,6 +980,9 @@ static gyp_ctx* acquire_helper(gyp_ctx* ctx, int which) {
     if (h->fs != ctx->fs || h->n != ctx->n)
         if (gyp_set_stream_format(h, ctx->fs, ctx->n) != GYP_OK) return nullptr;
     h->params = ctx->params;
+    // the helper runs under the caller's switches (it never read an environment of its own)
+    h->no_pipe = ctx->no_pipe; h->no_shared_fwd = ctx->no_shared_fwd; h->symbol_tau = ctx->symbol_tau;
+    h->track_chunk_ms = ctx->track_chunk_ms; h->no_spec = ctx->no_spec;
     return h;
 }
 
@@ -983,21 +997,29 @@ int gyp_acquire_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_
     if (lanes == 1)
         return acquire_search(ctx, iq_dev, n_streams, stream_stride_samples, n_ms, sat_ids_host, n_sats, 0.0,
                               ctx->params.acq_initial_spread_hz, false, out_dev);
-    int rc;
-    for (int i = 1; i < lanes; ++i)
-        if ((rc = gyp_wait_for(lane_ctx[i], ctx))) return rc;     // the samples may still be on their way on this context's stream
-    int s0 = 0;
-    for (int i = 0; i < lanes; ++i) {
+    int rc = GYP_OK;
+    std::string why;
+    // (a failure of gyp_wait_for(helper, ctx) leaves its text in the helper: everything is reported through the caller's context)
+    for (int i = 1; i < lanes && !rc; ++i)
+        if ((rc = gyp_wait_for(lane_ctx[i], ctx))) why = "gyp_acquire_dev: ordering a helper stream behind the caller's: " + lane_ctx[i]->err;   // the samples may still be on their way on this context's stream
+    int s0 = 0, enqueued = 0;
+    for (int i = 0; i < lanes && !rc; ++i) {
         const int cnt = (n_streams - s0) / (lanes - i);           // remaining streams spread evenly over the remaining lanes
         gyp_ctx* c = lane_ctx[i];
-        if ((rc = acquire_search(c, iq_dev + (int64_t)s0 * stream_stride_samples * 2, cnt, stream_stride_samples, n_ms, sat_ids_host, n_sats,
-                                 0.0, ctx->params.acq_initial_spread_hz, false, out_dev + (size_t)s0 * n_sats)))
-            return c == ctx ? rc : fail(ctx, rc, std::string("part of the scan on a helper stream: ") + c->err);
+        rc = acquire_search(c, iq_dev + (int64_t)s0 * stream_stride_samples * 2, cnt, stream_stride_samples, n_ms, sat_ids_host, n_sats,
+                            0.0, ctx->params.acq_initial_spread_hz, false, out_dev + (size_t)s0 * n_sats);
+        if (rc) why = c == ctx ? ctx->err : std::string("part of the scan on a helper stream: ") + c->err;
+        enqueued = i + 1;   // (a part that failed half way may have launches in flight too)
         s0 += cnt;
     }
-    for (int i = 1; i < lanes; ++i)
-        if ((rc = gyp_wait_for(ctx, lane_ctx[i]))) return rc;     // whatever follows on this context's stream sees every part
-    return GYP_OK;
+    // Join every helper that may have work in flight -- ALSO on failure: the caller is entitled to free or overwrite iq_dev /
+    // out_dev as soon as its own stream has passed this point, error or not.
+    for (int i = 1; i < std::max(enqueued, rc ? lanes : 0); ++i) {
+        const int rj = gyp_wait_for(ctx, lane_ctx[i]);            // whatever follows on this context's stream sees every part
+        if (rj && !rc) { rc = rj; why = "gyp_acquire_dev: joining a helper stream: " + ctx->err; }
+        if (rj) (void)hipStreamSynchronize(lane_ctx[i]->stream);  // the event path failed: wait for the helper on the host instead
+    }
+    return rc ? fail(ctx, rc, why) : GYP_OK;
 }
 
 int gyp_search_level_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_t stream_stride_samples, int32_t n_ms,
@@ -1148,6 +1170,11 @@ void gyp_bank_destroy(gyp_bank* bank) {
     if (bank->d_bad) (void)hipFree(bank->d_bad);
     if (bank->d_bad_from) (void)hipFree(bank->d_bad_from);
     if (bank->d_hist) (void)hipFree(bank->d_hist);
+    if (bank->d_ctl) (void)hipFree(bank->d_ctl);
+    if (bank->d_trk) (void)hipFree(bank->d_trk);
+    if (bank->d_fail) (void)hipFree(bank->d_fail);
+    if (bank->d_redo_stats) (void)hipFree(bank->d_redo_stats);
+    for (auto& e : bank->ev_vring) if (e) (void)hipEventDestroy(e);
     if (bank->d_dbg) (void)hipFree(bank->d_dbg);
     if (bank->d_prof_tail) (void)hipFree(bank->d_prof_tail);
     if (bank->d_prof_delta) (void)hipFree(bank->d_prof_delta);
@@ -1215,7 +1242,7 @@ static DllExactParams dll_exact_params(gyp_bank* bank, const TrackBlockParams& p
     DllExactParams x;
     x.iq = p.iq; x.stream_stride = p.stream_stride; x.n_ms = p.n_ms; x.ms_begin = 0; x.ms_end = p.n_ms; x.start_time = p.start_time;
     x.states = bank->d_states; x.n_chan = bank->n_chan; x.spec = bank->d_spec; x.disc_out = bank->d_disc; x.chipf = ctx->d_chipf;
-    x.inv_fs = p.inv_fs; x.only_if = nullptr; x.from_sub = nullptr; x.sub_len = 0;
+    x.inv_fs = p.inv_fs; x.only_if = nullptr; x.from_sub = nullptr; x.sub_len = 0; x.trk_round = nullptr;
     return x;
 }
 static DllScanParams dll_scan_params(gyp_bank* bank, const TrackBlockParams& p) {
@@ -1228,6 +1255,7 @@ static DllScanParams dll_scan_params(gyp_bank* bank, const TrackBlockParams& p) 
     d.first = 1; d.final = 1; d.from_sub = nullptr; d.sub_len = 0; d.hist_out = nullptr;
     d.prof_delta = p.prof_tail ? bank->d_prof_delta : nullptr; d.prof_from = p.prof_from; d.prof_depth = p.prof_depth;
     d.symbol_tau = ctx->symbol_tau;
+    d.trk_round = nullptr; d.hist = nullptr;
     return d;
 }
 
@@ -1275,23 +1303,57 @@ static int track_block_throughput(gyp_bank* bank, TrackBlockParams p, const int3
 // stream while the next sub-block is being tracked, and its code loop is re-integrated there (dll_exact + dll_scan); channels
 // that failed verification are re-run from the checkpoint by the transform kernel.  Everything is enqueued; nothing
 // synchronises with the host.
-static constexpr int kMaxSub = 16;
-static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
+// Sub-blocks of a speculative block: the last sub-block's verification trails the tracking, and a failed verification costs a
+// sub-block (more, shorter ones for long blocks); each round re-reads the channel state and the tables (~20 us).
+static constexpr int kMaxSub = 20;
+static int spec_sub_blocks(int n_ms) { return n_ms >= 4096 ? kMaxSub : (n_ms >= 256 ? 4 : 1); }
+static int ensure_spec_buffers(gyp_bank* bank, int n_sub, int rounds) {
     gyp_ctx* ctx = bank->ctx;
-    const size_t n_rec = (size_t)bank->n_chan * p.n_ms;
-    int rc;
-    if (!bank->d_ckpt) {
-        HIP_TRY(ctx, hipMalloc((void**)&bank->d_ckpt, (size_t)kMaxSub * bank->n_chan * sizeof(ChanState)));
+    if (!bank->verify_stream) {
         HIP_TRY(ctx, hipMalloc((void**)&bank->d_bad, (size_t)bank->n_chan * sizeof(int32_t)));
         HIP_TRY(ctx, hipMalloc((void**)&bank->d_bad_from, (size_t)bank->n_chan * sizeof(int32_t)));
-        HIP_TRY(ctx, hipMalloc((void**)&bank->d_hist, (size_t)kMaxSub * bank->n_chan * sizeof(DllExact)));
+        HIP_TRY(ctx, hipMalloc((void**)&bank->d_ctl, (size_t)bank->n_chan * sizeof(SpecCtl)));
+        HIP_TRY(ctx, hipMalloc((void**)&bank->d_redo_stats, 4 * sizeof(int32_t)));
+        HIP_TRY(ctx, hipMemset(bank->d_redo_stats, 0, 4 * sizeof(int32_t)));
         HIP_TRY(ctx, hipStreamCreateWithFlags(&bank->verify_stream, hipStreamNonBlocking));
         HIP_TRY(ctx, hipEventCreateWithFlags(&bank->ev_spec, hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&bank->ev_verify, hipEventDisableTiming));
+        for (auto& e : bank->ev_vring) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    if ((rc = ensure_dll_buffers(bank, n_rec))) return rc;
-    HIP_TRY(ctx, hipMemsetAsync(bank->d_bad, 0, (size_t)bank->n_chan * sizeof(int32_t), ctx->stream));
-    HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)bank->d_bad_from, 0x7fffffff, (size_t)bank->n_chan, ctx->stream));
+    if (bank->ckpt_cap < n_sub) {   // state checkpoints (18 KB per channel and sub-block): as many as this block uses
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(bank->verify_stream));
+        if (bank->d_ckpt) { HIP_TRY(ctx, hipFree(bank->d_ckpt)); bank->d_ckpt = nullptr; }
+        if (bank->d_hist) { HIP_TRY(ctx, hipFree(bank->d_hist)); bank->d_hist = nullptr; }
+        bank->ckpt_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&bank->d_ckpt, (size_t)n_sub * bank->n_chan * sizeof(ChanState)));
+        HIP_TRY(ctx, hipMalloc((void**)&bank->d_hist, (size_t)(n_sub + 1) * bank->n_chan * sizeof(DllExact)));
+        bank->ckpt_cap = n_sub;
+    }
+    if (bank->rounds_cap < rounds) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(bank->verify_stream));
+        if (bank->d_trk) { HIP_TRY(ctx, hipFree(bank->d_trk)); bank->d_trk = nullptr; }
+        if (bank->d_fail) { HIP_TRY(ctx, hipFree(bank->d_fail)); bank->d_fail = nullptr; }
+        bank->rounds_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&bank->d_trk, (size_t)rounds * bank->n_chan * sizeof(int32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&bank->d_fail, (size_t)rounds * bank->n_chan * sizeof(int32_t)));
+        bank->rounds_cap = rounds;
+    }
+    return GYP_OK;
+}
+static TrackVerifyParams verify_params(gyp_bank* bank, const TrackBlockParams& p) {
+    gyp_ctx* ctx = bank->ctx;
+    TrackVerifyParams v;
+    v.iq = p.iq; v.stream_stride = p.stream_stride; v.n_ms = p.n_ms; v.ms_begin = 0; v.ms_end = p.n_ms; v.start_time = p.start_time;
+    v.states = bank->d_states; v.n_chan = bank->n_chan; v.spec = bank->d_spec; v.rec_out = p.rec_out; v.bad = bank->d_bad;
+    v.bad_from = bank->d_bad_from; v.sub_index = 0; v.force_fail_ms = ctx->spec_fail_at;
+    v.replica_table = ctx->d_replicas; v.tw_tables = ctx->d_tw; v.inv_fs = p.inv_fs; v.tie_tol = 4e-6f;
+    v.trk_round = nullptr; v.fail_round = nullptr; v.sub_len = 0;
+    return v;
+}
+static int spec_prepare(gyp_bank* bank, TrackBlockParams& p, size_t n_rec) {
+    gyp_ctx* ctx = bank->ctx;
     p.spec_out = bank->d_spec;
     p.exact0 = nullptr;
     p.from_sub = nullptr; p.exact_hist = nullptr; p.sub_len = 0;
@@ -1304,18 +1366,27 @@ static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
         }
         p.dbg = bank->d_dbg;
     }
-    TrackVerifyParams v;
-    v.iq = p.iq; v.stream_stride = p.stream_stride; v.n_ms = p.n_ms; v.start_time = p.start_time;
-    v.states = bank->d_states; v.n_chan = bank->n_chan; v.spec = bank->d_spec; v.rec_out = p.rec_out; v.bad = bank->d_bad;
-    v.bad_from = bank->d_bad_from; v.force_fail_ms = ctx->spec_fail_at;
-    v.replica_table = ctx->d_replicas; v.tw_tables = ctx->d_tw; v.inv_fs = p.inv_fs; v.tie_tol = 4e-6f;
+    return GYP_OK;
+}
+
+// r03 form (blocks of one sub-block, or gyp_debug_set "spec_redo" 0): every sub-block's verification trails its tracking on the
+// verify stream; channels that failed one are re-run from that sub-block's checkpoint by the TRANSFORM kernel afterwards.
+static int track_block_speculative_rerun(gyp_bank* bank, TrackBlockParams p) {
+    gyp_ctx* ctx = bank->ctx;
+    const size_t n_rec = (size_t)bank->n_chan * p.n_ms;
+    int rc;
+    const int n_sub = spec_sub_blocks(p.n_ms);
+    if ((rc = ensure_spec_buffers(bank, n_sub, 1))) return rc;
+    if ((rc = ensure_dll_buffers(bank, n_rec))) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(bank->d_bad, 0, (size_t)bank->n_chan * sizeof(int32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)bank->d_bad_from, 0x7fffffff, (size_t)bank->n_chan, ctx->stream));
+    const int32_t st0[4] = {n_sub, n_sub, 0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(bank->d_redo_stats, st0, sizeof(st0), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = spec_prepare(bank, p, n_rec))) return rc;
+    TrackVerifyParams v = verify_params(bank, p);
     DllExactParams x = dll_exact_params(bank, p);
     DllScanParams d = dll_scan_params(bank, p);
     d.ckpt = bank->d_ckpt; d.bad = bank->d_bad; d.only_bad = 0;
-    // the last sub-block's verification trails the tracking (1.9 ms for 2500 ms x 12 channels): more, shorter sub-blocks
-    // for long blocks (each launch re-reads the channel state and the tables: ~20 us).  Every sub-block starts from a checkpoint
-    // of the channel states (18 KB per channel) so that a failed verification costs a re-run from that sub-block, not the block.
-    const int n_sub = p.n_ms >= 4096 ? kMaxSub : (p.n_ms >= 256 ? 4 : 1);
     const int sub = (p.n_ms + n_sub - 1) / n_sub;
     int j = 0;
     for (int b0 = 0; b0 < p.n_ms; b0 += sub, ++j) {
@@ -1341,6 +1412,67 @@ static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
     // channels whose window maximum was not the global one somewhere (any count is handled): again from the checkpoint of the
     // sub-block in which that happened, through the transform kernel, their code loop re-integrated behind it
     p.dbg = nullptr;
+    return track_block_throughput(bank, p, bank->d_bad, bank->d_ckpt, bank->d_bad_from, bank->d_hist, sub);
+}
+
+// Speculative block tracking (8.184 / 2.046 Msps, at most one channel per CU) under the round protocol (SpecCtl,
+// kernels_track_block.hpp): round R's tracking launch on the context's stream, its verify / exact-sums / scan launches on the
+// verify stream behind it, launch R + 2 waiting for the verify kernels of round R.  Everything is enqueued; nothing
+// synchronises with the host.
+static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
+    gyp_ctx* ctx = bank->ctx;
+    const int n_sub = spec_sub_blocks(p.n_ms);
+    if (n_sub == 1 || !ctx->spec_redo) return track_block_speculative_rerun(bank, p);
+    const size_t n_rec = (size_t)bank->n_chan * p.n_ms;
+    const int sub = (p.n_ms + n_sub - 1) / n_sub;
+    const int n_sub_used = (p.n_ms + sub - 1) / sub;
+    // a re-do costs its channel two rounds: room for three of them behind the last sub-block, then the transform kernel takes over
+    const int rounds = n_sub_used + 2 + (n_sub_used >= kMaxSub ? 6 : 2);
+    int rc;
+    if ((rc = ensure_spec_buffers(bank, n_sub_used, rounds))) return rc;
+    if ((rc = ensure_dll_buffers(bank, n_rec))) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(bank->d_ctl, 0, (size_t)bank->n_chan * sizeof(SpecCtl), ctx->stream));   // cursor 0, nothing forced (rb_round 0 only ever matters for R = 1, which consults nothing)
+    HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)bank->d_fail, 0x7fffffff, (size_t)rounds * bank->n_chan, ctx->stream));
+    HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)bank->d_trk, 0xffffffff, (size_t)rounds * bank->n_chan, ctx->stream));
+    const int32_t st0[4] = {n_sub_used, rounds, 0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(bank->d_redo_stats, st0, sizeof(st0), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = spec_prepare(bank, p, n_rec))) return rc;
+    p.ctl = bank->d_ctl; p.trk = bank->d_trk; p.fail = bank->d_fail; p.ckpt = bank->d_ckpt;
+    p.n_sub = n_sub_used; p.sub_len = sub; p.exact_hist = bank->d_hist;
+    p.ms_begin = 0; p.ms_end = p.n_ms;
+    TrackVerifyParams v = verify_params(bank, p);
+    v.bad = nullptr; v.bad_from = nullptr; v.sub_len = sub;
+    DllExactParams x = dll_exact_params(bank, p);
+    x.sub_len = sub;
+    DllScanParams d = dll_scan_params(bank, p);
+    d.ckpt = bank->d_ckpt; d.bad = nullptr; d.only_bad = 0; d.first = 0; d.final = 0; d.hist_out = nullptr;
+    d.sub_len = sub; d.hist = bank->d_hist;
+    for (int R = 0; R < rounds; ++R) {
+        if (R >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, bank->ev_vring[(R - 2) % 3], 0));   // round R - 2's reports are in
+        p.round = R;
+        if ((rc = launch_track_block(ctx, p, 2))) return rc;
+        HIP_TRY(ctx, hipEventRecord(bank->ev_spec, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(bank->verify_stream, bank->ev_spec, 0));
+        v.trk_round = bank->d_trk + (size_t)R * bank->n_chan;
+        v.fail_round = bank->d_fail + (size_t)R * bank->n_chan;
+        if ((rc = launch_track_verify(ctx, v, bank->verify_stream))) return rc;
+        x.trk_round = v.trk_round;
+        if ((rc = launch_dll_exact(ctx, x, bank->verify_stream))) return rc;
+        d.trk_round = v.trk_round;
+        if ((rc = launch_dll_scan(ctx, d, bank->verify_stream))) return rc;
+        HIP_TRY(ctx, hipEventRecord(bank->ev_vring[R % 3], bank->verify_stream));
+    }
+    HIP_TRY(ctx, hipEventRecord(bank->ev_verify, bank->verify_stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, bank->ev_verify, 0));
+    SpecFinalizeParams f;
+    f.ctl = bank->d_ctl; f.trk = bank->d_trk; f.fail = bank->d_fail; f.states = bank->d_states; f.ckpt = bank->d_ckpt; f.hist = bank->d_hist;
+    f.exact = bank->d_dllx; f.bad = bank->d_bad; f.bad_from = bank->d_bad_from; f.stats = bank->d_redo_stats;
+    f.n_chan = bank->n_chan; f.n_sub = n_sub_used; f.rounds = rounds;
+    hipLaunchKernelGGL(spec_finalize_kernel, dim3((unsigned)bank->n_chan), dim3(256), 0, ctx->stream, f);
+    HIP_TRY(ctx, hipGetLastError());
+    // channels the rounds did not finish (out of forced-transform slots or of rounds): the transform kernel, from their last good checkpoint
+    p.dbg = nullptr;
+    p.ctl = nullptr; p.trk = nullptr; p.fail = nullptr; p.ckpt = nullptr; p.n_sub = 0; p.round = 0;
     return track_block_throughput(bank, p, bank->d_bad, bank->d_ckpt, bank->d_bad_from, bank->d_hist, sub);
 }
 
@@ -1388,6 +1520,7 @@ int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stri
     p.from_sub = nullptr; p.exact_hist = nullptr; p.sub_len = 0;
     p.dbg = nullptr;
     p.prof_tail = nullptr; p.prof_from = 0; p.prof_depth = 0;
+    p.ctl = nullptr; p.trk = nullptr; p.fail = nullptr; p.ckpt = nullptr; p.round = 0; p.n_sub = 0;
     if (bank->prof_depth > 0) {   // profiles kept: the transform kernel forms every millisecond's full profile anyway
         bank->prof_rows = std::min(bank->prof_depth, (int)n_ms);
         p.prof_tail = bank->d_prof_tail; p.prof_from = n_ms - bank->prof_rows; p.prof_depth = bank->prof_depth;
@@ -1558,13 +1691,23 @@ int gyp_debug_spec_read(gyp_bank* bank, float* out, int32_t n_floats, int32_t* b
     return GYP_OK;
 }
 
+int gyp_debug_spec_redo_read(gyp_bank* bank, int32_t* out4) {
+    if (!bank || !out4) return GYP_E_BAD_ARG;
+    gyp_ctx* ctx = bank->ctx;
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    if (!bank->d_redo_stats) return GYP_OK;   // the bank has not tracked a block on the speculative path
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out4, bank->d_redo_stats, 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return GYP_OK;
+}
+
 int gyp_debug_dll_read(gyp_bank* bank, int32_t* repairs_out) {
     if (!bank || !repairs_out) return GYP_E_BAD_ARG;
     gyp_ctx* ctx = bank->ctx;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<DllExact> x((size_t)bank->n_chan);
     for (int i = 0; i < bank->n_chan; ++i) repairs_out[i] = 0;
-    if (!bank->d_dllx) return GYP_OK;          // the bank never took the speculative path
+    if (!bank->d_dllx) return GYP_OK;          // the bank has not tracked a block yet
     HIP_TRY(ctx, hipMemcpy(x.data(), bank->d_dllx, x.size() * sizeof(DllExact), hipMemcpyDeviceToHost));
     for (int i = 0; i < bank->n_chan; ++i) repairs_out[i] = x[i].repairs;
     return GYP_OK;
@@ -1623,6 +1766,56 @@ int gyp_synth_iq_dev(gyp_ctx* ctx, float* out_dev, int32_t n_streams, int64_t st
     hipLaunchKernelGGL(synth_iq_kernel, dim3((ctx->n + 255) / 256, n_ms, n_streams), dim3(256), 0, ctx->stream, p);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // sats_host may be a temporary; scratch[1] is reused by other calls
+    return GYP_OK;
+}
+
+// A/B switches and test hooks of a context, by name.  The library reads no environment variable for them (a stray variable in
+// a deployment must not change the speed path): whoever wants one says so through this call.  Values are range-checked.
+namespace {
+struct DebugKnob { const char* name; double lo, hi; bool integral; };
+const DebugKnob kDebugKnobs[] = {
+    {"no_pipe", 0, 1, true}, {"no_shared_fwd", 0, 1, true}, {"no_acq_split", 0, 1, true}, {"no_spec", 0, 1, true},
+    {"spec_debug", 0, 1, true}, {"acq_lanes", 1, gyp_ctx::kMaxAcqLanes, true}, {"track_chunk_ms", 0, 1e6, true},
+    {"symbol_tau", 0, 100, false}, {"dll_prov_bias", -1e6, 1e6, false}, {"spec_fail_at", -1, 2147483647.0, true},
+    {"spec_redo", 0, 1, true}, {"exact_prefetch", 0, 1, true},
+};
+}  // namespace
+static int debug_apply(gyp_ctx* ctx, const char* name, double v, bool set, double* out) {
+    auto is = [&](const char* n) { return std::strcmp(name, n) == 0; };
+#define GYP_KNOB_BOOL(N, FIELD) if (is(N)) { if (set) ctx->FIELD = v != 0.0; else *out = ctx->FIELD ? 1.0 : 0.0; return GYP_OK; }
+#define GYP_KNOB_NUM(N, FIELD, T) if (is(N)) { if (set) ctx->FIELD = (T)v; else *out = (double)ctx->FIELD; return GYP_OK; }
+    GYP_KNOB_BOOL("no_pipe", no_pipe)
+    GYP_KNOB_BOOL("no_shared_fwd", no_shared_fwd)
+    GYP_KNOB_BOOL("no_acq_split", no_acq_split)
+    GYP_KNOB_BOOL("no_spec", no_spec)
+    GYP_KNOB_BOOL("spec_debug", spec_debug)
+    GYP_KNOB_BOOL("spec_redo", spec_redo)
+    GYP_KNOB_NUM("acq_lanes", acq_lanes, int)
+    GYP_KNOB_NUM("track_chunk_ms", track_chunk_ms, int)
+    GYP_KNOB_NUM("symbol_tau", symbol_tau, float)
+    GYP_KNOB_NUM("dll_prov_bias", dll_prov_bias, double)
+    GYP_KNOB_NUM("spec_fail_at", spec_fail_at, int)
+    GYP_KNOB_NUM("exact_prefetch", exact_prefetch, int)
+#undef GYP_KNOB_BOOL
+#undef GYP_KNOB_NUM
+    return GYP_E_BAD_ARG;
+}
+int gyp_debug_set(gyp_ctx* ctx, const char* name, double value) {
+    if (!ctx || !name) return GYP_E_BAD_ARG;
+    for (const DebugKnob& k : kDebugKnobs) {
+        if (std::strcmp(name, k.name) != 0) continue;
+        if (!std::isfinite(value) || value < k.lo || value > k.hi || (k.integral && value != std::floor(value)))
+            return fail(ctx, GYP_E_BAD_ARG, std::string("gyp_debug_set: ") + name + " must be " + (k.integral ? "an integer " : "") + "in [" +
+                                                std::to_string(k.lo) + ", " + std::to_string(k.hi) + "]");
+        if (std::strcmp(name, "track_chunk_ms") == 0 && value != 0.0 && value < 20.0)
+            return fail(ctx, GYP_E_BAD_ARG, "gyp_debug_set: track_chunk_ms must be 0 (whole blocks) or at least 20");
+        return debug_apply(ctx, name, value, true, nullptr);
+    }
+    return fail(ctx, GYP_E_BAD_ARG, std::string("gyp_debug_set: no such switch: ") + name);
+}
+int gyp_debug_get(gyp_ctx* ctx, const char* name, double* out) {
+    if (!ctx || !name || !out) return GYP_E_BAD_ARG;
+    if (debug_apply(ctx, name, 0.0, false, out) != GYP_OK) return fail(ctx, GYP_E_BAD_ARG, std::string("gyp_debug_get: no such switch: ") + name);
     return GYP_OK;
 }
 

@@ -41,8 +41,8 @@ __global__ void acq_init_kernel(AcqSearchState* states, int n_states, int n_sats
 // With gyp_params::acq_reuse_level_records a bin the previous level already evaluated (every other bin of levels 2, 3, 8
 // and 10 with the reference's spreads) is not correlated again: `reuse` says which of the previous level's records
 // acq_reuse_kernel copies into the slot.  The reference keeps a cache for exactly this (acquisition.py:200-219) but has its
-// lookup switched off and recomputes -- the default here too; the records are pure functions of (data, satellite, bin), so
-// the reuse changes nothing but the time.
+// lookup switched off and recomputes; the records are pure functions of (data, satellite, bin), so the reuse -- the default
+// here since r03, acq_reuse_level_records = 0 correlates every bin again as the reference does -- changes nothing but the time.
 __global__ void acq_plan_kernel(AcqSearchState* states, int n_states, gyp_cell_desc* cells, int32_t* reuse, double bins_per_spread,
                                 int reuse_records) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

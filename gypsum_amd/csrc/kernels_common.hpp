@@ -110,6 +110,9 @@ struct RedScratch {
     LoopConst kc;
     struct CostasCand { double nf, nphi; cf rot1; cf step; double pad; } cc[3];   // step: the carrier over 4096 samples (second chip of a thread)
     int cand_sel, rec_sel, pad2[2];
+    // speculative tracker under the round protocol (SpecCtl, kernels_track_block.hpp): what this channel does in this launch
+    int32_t ctl_sub, ctl_restore, ctl_nforce, ctl_pad;
+    int32_t force_ms[8];   // milliseconds of the block that take the transform path whatever the window says (a verification failed there)
 };
 static_assert(sizeof(RedScratch) <= kRedBytes, "reduction scratch too large");
 

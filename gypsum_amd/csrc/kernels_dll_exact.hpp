@@ -32,6 +32,7 @@ struct DllExactParams {
     const int32_t* only_if;    // optional: only channels with only_if[ch] != 0 (the re-run of failed speculations) ...
     const int32_t* from_sub;   // ... and of those only the milliseconds from sub-block from_sub[ch] on (sub_len milliseconds each)
     int32_t sub_len;
+    const int32_t* trk_round;  // round protocol (SpecCtl): channel ch's milliseconds are sub-block trk_round[ch] (-1: none); null: [ms_begin, ms_end)
 };
 
 // acc * w + x  (complex): one Horner step of sum_i x_i w^i
@@ -99,19 +100,78 @@ __device__ __forceinline__ double2 cpow_km1(double2 w) {   // w^(K-1), K <= 8
     for (int i = 0; i < K - 1; ++i) r = cmul64(r, w);
     return r;
 }
+// exact_window in two halves for the software-prefetched form of the kernel: the window's samples and its three code chips are
+// REQUESTED (load) one or two windows before they are folded into the sums (fold).
 template <int K>
-__global__ __launch_bounds__(256, 4) void dll_exact_wave_kernel(DllExactParams p) {
+struct ExactWin {
+    cf x[K];
+    float cm1, c0, cp1;
+};
+template <int K, bool EDGE>
+__device__ __forceinline__ void exact_window_load(const cf* __restrict__ block, int m, int r, int q, const float* __restrict__ chipf, ExactWin<K>& w) {
+    constexpr int N = K * kChips;
+    const int n0 = K * m + r;
+    if constexpr (EDGE) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int n = n0 + i;
+            const cf v = block[min(max(n, 0), N - 1)];
+            const bool in = n >= 0 && n < N;
+            w.x[i] = make_float2(in ? v.x : 0.f, in ? v.y : 0.f);
+        }
+    } else {
+        typedef float4 __attribute__((aligned(8))) float4_a8;
+        typedef float2 __attribute__((aligned(8))) float2_a8;
+        const cf* src = block + n0;
+#pragma unroll
+        for (int i = 0; i + 1 < K; i += 2) {
+            const float4 v = *reinterpret_cast<const float4_a8*>(src + i);
+            w.x[i] = make_float2(v.x, v.y);
+            w.x[i + 1] = make_float2(v.z, v.w);
+        }
+        if (K & 1) w.x[K - 1] = *reinterpret_cast<const float2_a8*>(src + K - 1);
+    }
+    int j = m - q;
+    j = j < 0 ? j + kChips : j;
+    j = j < 0 ? j + kChips : j;
+    const float* cp = chipf + j + kChips;
+    w.cm1 = cp[-1]; w.c0 = cp[0]; w.cp1 = cp[1];
+}
+template <int K>
+__device__ __forceinline__ void exact_window_fold(const ExactWin<K>& w, double2 rho, double2 step, double2& sp, double2& se, double2& sl) {
+    const double dj = (double)w.c0, gl = (double)(w.cm1 - w.c0), ge = (double)(w.c0 - w.cp1);
+    double2 h = cvt64(w.x[K - 1]);
+#pragma unroll
+    for (int i = K - 2; i >= 0; --i) h = horner64(h, rho, cvt64(w.x[i]));
+    const double2 xe = cvt64(w.x[K - 1]), xl = cvt64(w.x[0]);
+    sp = horner64(sp, step, make_double2(dj * h.x, dj * h.y));
+    se = horner64(se, step, make_double2(ge * xe.x, ge * xe.y));
+    sl = horner64(sl, step, make_double2(gl * xl.x, gl * xl.y));
+}
+// PF: software prefetch depth in windows (0: the windows are loaded where they are folded, two at a time by unrolling; 1, 2: the
+// loads of window c - PF are issued before window c is folded -- 16 more sample registers per step of depth at K = 8).
+// Measured at the headline batch (profiles/r04_exact_ab.txt): PF 0 at 5 wavefronts per SIMD 8.13-8.22 ms per 1536 channels x
+// 1000 ms; PF 1 (128 VGPRs, 4 per SIMD) 10.27; PF 2 10.32; PF 0 squeezed to 6 per SIMD (80 VGPRs, 7 spills) 9.72; PF 1 at 5 per
+// SIMD (20 spills) 10.49.  The waits VERDICT r03 pointed at are covered best by the fifth wavefront: PF 0 stays the default.
+template <int K, int PF, int MINW = 4>
+__global__ __launch_bounds__(256, MINW) void dll_exact_wave_kernel(DllExactParams p) {
     static_assert(K <= 8, "a window's samples in registers");
     constexpr int N = K * kChips;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int n_units = p.n_chan * (p.ms_end - p.ms_begin);
+    const int n_units = p.n_chan * (p.trk_round ? p.sub_len : p.ms_end - p.ms_begin);
     const int n_groups = (n_units + 3) >> 2;
     for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
         // four consecutive units per workgroup, consecutive groups inside an XCD's slice: the channels of a stream-ms (shared IQ) meet in one L2
         const int u = ((n_groups & 7) ? g : xcd_contiguous(g, n_groups)) * 4 + wave;
         if (u >= n_units) continue;
-        const int ms = p.ms_begin + u / p.n_chan, ch = u % p.n_chan;
+        int ms = p.ms_begin + u / p.n_chan;
+        const int ch = u % p.n_chan;
+        if (p.trk_round) {                                        // wave-uniform
+            const int sub = p.trk_round[ch];
+            ms = sub * p.sub_len + u / p.n_chan;
+            if (sub < 0 || ms >= p.n_ms) continue;
+        }
         if (p.only_if && !p.only_if[ch]) continue;                // wave-uniform
         if (p.from_sub && ms < p.from_sub[ch] * p.sub_len) continue;
         const int64_t at = (int64_t)ch * p.n_ms + ms;
@@ -125,14 +185,34 @@ __global__ __launch_bounds__(256, 4) void dll_exact_wave_kernel(DllExactParams p
         const double u0 = carrier_cycles(in.doppler, p.start_time[ms], in.carrier_phase);
         const int sN = __builtin_amdgcn_readfirstlane(mod_n(in.code_phase, N));
         const int q = sN / K, r = sN % K;
-        const double2 rho = carrier64(du), step = carrier64(du * (double)(K * 64));
         double2 sp = make_double2(0.0, 0.0), se = sp, sl = sp;
-        exact_window<K, true>(block, lane + 64 * 15 - 1, r, q, chipf, rho, step, sp, se, sl);     // holds window 1022 (lane 63)
+        if constexpr (PF == 0) {
+            const double2 rho = carrier64(du), step = carrier64(du * (double)(K * 64));
+            exact_window<K, true>(block, lane + 64 * 15 - 1, r, q, chipf, rho, step, sp, se, sl);     // holds window 1022 (lane 63)
 #pragma unroll 2
-        for (int c = 14; c >= 1; --c) exact_window<K, false>(block, lane + 64 * c - 1, r, q, chipf, rho, step, sp, se, sl);
-        exact_window<K, true>(block, lane - 1, r, q, chipf, rho, step, sp, se, sl);               // holds window -1 (lane 0)
+            for (int c = 14; c >= 1; --c) exact_window<K, false>(block, lane + 64 * c - 1, r, q, chipf, rho, step, sp, se, sl);
+            exact_window<K, true>(block, lane - 1, r, q, chipf, rho, step, sp, se, sl);               // holds window -1 (lane 0)
+        } else {
+            // windows 15 (edge), 14 .. 1, 0 (edge), each requested PF windows before it is folded; the carriers are formed under
+            // the first requests
+            ExactWin<K> w[PF + 1];
+            exact_window_load<K, true>(block, lane + 64 * 15 - 1, r, q, chipf, w[0]);
+            if constexpr (PF == 2) exact_window_load<K, false>(block, lane + 64 * 14 - 1, r, q, chipf, w[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const double2 rho = carrier64(du), step = carrier64(du * (double)(K * 64));
+#pragma unroll
+            for (int c = 15; c >= 0; --c) {
+                const int cn = c - PF;                                      // the window requested now
+                if (cn >= 1) exact_window_load<K, false>(block, lane + 64 * cn - 1, r, q, chipf, w[(15 - cn) % (PF + 1)]);
+                else if (cn == 0) exact_window_load<K, true>(block, lane - 1, r, q, chipf, w[(15 - cn) % (PF + 1)]);
+                __builtin_amdgcn_sched_barrier(0);
+                exact_window_fold<K>(w[(15 - c) % (PF + 1)], rho, step, sp, se, sl);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const double2 rho_a = carrier64(du);
         const double2 anchor = carrier64(u0 + du * (double)(K * (lane - 1) + r));
-        const double2 pp = cmul64(sp, anchor), ee = cmul64(cmul64(se, cpow_km1<K>(rho)), anchor), ll = cmul64(sl, anchor);
+        const double2 pp = cmul64(sp, anchor), ee = cmul64(cmul64(se, cpow_km1<K>(rho_a)), anchor), ll = cmul64(sl, anchor);
         double acc[6] = {pp.x, pp.y, ee.x, ee.y, ll.x, ll.y};
 #pragma unroll
         for (int v = 0; v < 6; ++v) acc[v] = wave_sum_last(acc[v]);
@@ -145,10 +225,16 @@ __global__ __launch_bounds__(256) void dll_exact_block_kernel(DllExactParams p) 
     constexpr int N = K * kChips;
     __shared__ double part[4][6];
     const int tid = threadIdx.x;
-    const int n_units = p.n_chan * (p.ms_end - p.ms_begin);
+    const int n_units = p.n_chan * (p.trk_round ? p.sub_len : p.ms_end - p.ms_begin);
     for (int v = blockIdx.x; v < n_units; v += gridDim.x) {
         const int u = (n_units & 7) ? v : xcd_contiguous(v, n_units);
-        const int ms = p.ms_begin + u / p.n_chan, ch = u % p.n_chan;
+        int ms = p.ms_begin + u / p.n_chan;
+        const int ch = u % p.n_chan;
+        if (p.trk_round) {                                        // uniform
+            const int sub = p.trk_round[ch];
+            ms = sub * p.sub_len + u / p.n_chan;
+            if (sub < 0 || ms >= p.n_ms) continue;
+        }
         if (p.only_if && !p.only_if[ch]) continue;                // uniform
         if (p.from_sub && ms < p.from_sub[ch] * p.sub_len) continue;
         const int64_t at = (int64_t)ch * p.n_ms + ms;
@@ -206,6 +292,10 @@ struct DllScanParams {
     // loop's accumulated float32 difference from the reference's state -- the loop runs on float32 peaks -- which in a channel that
     // never locks can reach 1e-4 rad: one pseudosymbol in 3.6 M channel-ms at 4.092 Msps, profiles/r03_surveys.txt.)
     float symbol_tau;
+    // round protocol (SpecCtl): channel ch scans sub-block trk_round[ch] (-1: nothing) from the loop state hist[sub][ch]
+    // (sub == 0: the channel's checkpoint ckpt[ch]) and leaves hist[sub + 1][ch]; `first` / `final` / ms_begin / ms_end are not used
+    const int32_t* trk_round;
+    DllExact* hist;
 };
 constexpr int kScanThreads = 256;
 constexpr int kScanChunk = 512;     // milliseconds staged in LDS at a time
@@ -230,16 +320,26 @@ __global__ __launch_bounds__(kScanThreads) void dll_scan_kernel(DllScanParams p)
     if (ch >= p.n_chan) return;
     if (p.bad && (p.bad[ch] != 0) != (p.only_bad != 0)) return;
     const ChanState* st = p.states + ch;
+    int range_lo = p.ms_begin, range_hi = p.ms_end, sub_here = -1;
+    if (p.trk_round) {   // uniform
+        sub_here = p.trk_round[ch];
+        if (sub_here < 0) return;
+        range_lo = sub_here * p.sub_len;
+        range_hi = min(p.n_ms, range_lo + p.sub_len);
+    }
     if (tid == 0) {
-        if (p.first && p.ckpt) { s_a = p.ckpt[ch].dll_phase; s_s = p.ckpt[ch].code_phase; s_repairs = 0; }
+        if (p.trk_round) {
+            if (sub_here == 0) { s_a = p.ckpt[ch].dll_phase; s_s = p.ckpt[ch].code_phase; s_repairs = 0; }
+            else { const DllExact x = p.hist[(size_t)sub_here * p.n_chan + ch]; s_a = x.dll; s_s = x.code_phase; s_repairs = x.repairs; }
+        } else if (p.first && p.ckpt) { s_a = p.ckpt[ch].dll_phase; s_s = p.ckpt[ch].code_phase; s_repairs = 0; }
         else { const DllExact x = p.exact[ch]; s_a = x.dll; s_s = x.code_phase; s_repairs = p.first ? 0 : x.repairs; }
     }
     const float* chipf = p.chipf + (st->sat_id - 1) * 2048;
     const cf* stream = p.iq + (int64_t)st->stream * p.stream_stride;
     const int64_t row = (int64_t)ch * p.n_ms;
-    const int ms_first = (p.only_bad && p.from_sub) ? max(p.ms_begin, min(p.from_sub[ch], (p.n_ms - 1) / max(p.sub_len, 1)) * p.sub_len) : p.ms_begin;
-    for (int c0 = ms_first; c0 < p.ms_end; c0 += kScanChunk) {
-        const int len = min(kScanChunk, p.ms_end - c0);
+    const int ms_first = (p.only_bad && p.from_sub) ? max(p.ms_begin, min(p.from_sub[ch], (p.n_ms - 1) / max(p.sub_len, 1)) * p.sub_len) : range_lo;
+    for (int c0 = ms_first; c0 < range_hi; c0 += kScanChunk) {
+        const int len = min(kScanChunk, range_hi - c0);
         for (int i = tid; i < len; i += kScanThreads) {
             const SpecIn* in = p.spec + row + c0 + i;
             const int key = in->key;
@@ -388,9 +488,64 @@ __global__ __launch_bounds__(kScanThreads) void dll_scan_kernel(DllScanParams p)
     }
     if (tid == 0) {
         DllExact x; x.dll = s_a; x.code_phase = s_s; x.repairs = s_repairs;
-        p.exact[ch] = x;
-        if (p.hist_out) p.hist_out[ch] = x;
-        if (p.final) { p.states[ch].dll_phase = s_a; p.states[ch].code_phase = s_s; }
+        if (p.trk_round) {
+            p.hist[(size_t)(sub_here + 1) * p.n_chan + ch] = x;   // (spec_finalize_kernel writes the state back when the block has held)
+        } else {
+            p.exact[ch] = x;
+            if (p.hist_out) p.hist_out[ch] = x;
+            if (p.final) { p.states[ch].dll_phase = s_a; p.states[ch].code_phase = s_s; }
+        }
+    }
+}
+
+// End of a block under the round protocol (one workgroup per channel, main stream, behind the last verify kernels): the reports of
+// the last two rounds are consulted the way the tracking kernel would in two more rounds.  A channel whose every sub-block has
+// held takes the exact code loop's final state; any other one is handed to the transform kernel (bad / bad_from), which restarts
+// from ckpt[bad_from] -- where the channel never started that sub-block, its present state IS that checkpoint.
+struct SpecFinalizeParams {
+    SpecCtl* ctl;
+    const int32_t* trk;
+    const int32_t* fail;
+    ChanState* states;
+    ChanState* ckpt;
+    const DllExact* hist;
+    DllExact* exact;
+    int32_t* bad;
+    int32_t* bad_from;
+    int32_t* stats;      // [4] += {-, -, sub-block re-dos, channels handed to the transform kernel}
+    int32_t n_chan, n_sub, rounds;
+};
+__global__ __launch_bounds__(256) void spec_finalize_kernel(SpecFinalizeParams p) {
+    const int ch = blockIdx.x;
+    if (ch >= p.n_chan) return;
+    __shared__ int s_copy_to;
+    if (threadIdx.x == 0) {
+        SpecCtl c = p.ctl[ch];
+        for (int R = p.rounds; R < p.rounds + 2; ++R) {
+            if (c.dead || R < 2 || c.rb_round == R - 1) continue;
+            const int s = p.trk[(size_t)(R - 2) * p.n_chan + ch];
+            if (s >= 0 && p.fail[(size_t)(R - 2) * p.n_chan + ch] != kNoFail) { c.dead = 1; c.cursor = s; }
+        }
+        const bool ok = !c.dead && c.cursor >= p.n_sub;
+        p.bad[ch] = ok ? 0 : 1;
+        p.bad_from[ch] = ok ? kNoFail : c.cursor;
+        s_copy_to = -1;
+        if (ok) {
+            const DllExact x = p.hist[(size_t)p.n_sub * p.n_chan + ch];
+            p.states[ch].dll_phase = x.dll; p.states[ch].code_phase = x.code_phase;
+            p.exact[ch] = x;
+        } else {
+            atomicAdd(p.stats + 3, 1);
+            if (!c.dead) s_copy_to = c.cursor;   // ran out of rounds in front of a sub-block it never started
+        }
+        if (c.redos) atomicAdd(p.stats + 2, c.redos);
+        p.ctl[ch] = c;
+    }
+    __syncthreads();
+    if (s_copy_to >= 0) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(p.states + ch);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(p.ckpt + (size_t)s_copy_to * p.n_chan + ch);
+        for (int i = threadIdx.x; i < (int)(sizeof(ChanState) / 4); i += blockDim.x) dst[i] = src[i];
     }
 }
 

@@ -192,6 +192,29 @@ struct DllExact {
     int32_t repairs;       // repair steps so far in this call (telemetry)
 };
 
+// The speculative tracker's round protocol (gyp_track_block_dev on lightly loaded banks, blocks of more than one sub-block).
+// A block is cut into n_sub sub-blocks of sub_len milliseconds.  The host enqueues T = n_sub + a few rounds; in round R the
+// tracking kernel (main stream) advances every channel through ITS next sub-block, and the verify / exact-sums / scan kernels
+// (verify stream) check that sub-block while round R + 1 is being tracked.  Launch R of the tracking kernel waits for the verify
+// kernels of round R - 2, so a channel learns in round R whether the sub-block it tracked in round R - 2 held: if not, it goes
+// back to that sub-block's checkpoint (taken by the kernel itself when the sub-block was started), puts the millisecond whose
+// window did not hold the arg-max on its forced-transform list and tracks the sub-block again -- at the speculative kernel's
+// speed, not the transform kernel's -- losing two rounds.  What it tracked in round R - 1 is stale then: that round's report
+// is ignored (rb_round).  A channel that runs out of forced-transform slots or of rounds is finished by the transform kernel
+// from its last good checkpoint (`dead` / cursor < n_sub -> bad, bad_from), as every failure was in r03.
+constexpr int kMaxForce = 8;
+struct SpecCtl {
+    int32_t cursor;      // the next sub-block this channel has to track (n_sub: all tracked)
+    int32_t rb_round;    // round of the last roll-back (-1: none)
+    int32_t n_force;
+    int32_t dead;        // out of forced-transform slots: cursor is the sub-block the transform kernel restarts from
+    int32_t redos;       // telemetry
+    int32_t pad[3];
+    int32_t force_ms[kMaxForce];
+};
+static_assert(sizeof(SpecCtl) == 64, "SpecCtl layout");
+constexpr int32_t kNoFail = 0x7fffffff;
+
 struct TrackBlockParams {
     const cf* iq;
     int64_t stream_stride;
@@ -228,7 +251,35 @@ struct TrackBlockParams {
     // provisional one: dll_scan_kernel notes the difference to the exact one in DllScanParams::prof_delta where they differ)
     float* prof_tail;
     int32_t prof_from, prof_depth;
+    // round protocol (MODE 2 only; null: the launch covers [ms_begin, ms_end) for every channel)
+    SpecCtl* ctl;              // [n_chan]
+    int32_t* trk;              // [rounds][n_chan] sub-block tracked by each channel in each round (-1: none)
+    const int32_t* fail;       // [rounds][n_chan] first millisecond whose verification failed (kNoFail: none), by track_verify_kernel
+    ChanState* ckpt;           // [n_sub][n_chan] state at the start of each sub-block
+    int32_t round, n_sub;
 };
+
+// Thread 0 of a channel's workgroup, at the start of round p.round: consult the report of round - 2, decide what to track.
+__device__ __forceinline__ void spec_ctl_begin(const TrackBlockParams& p, int ch, RedScratch* red) {
+    SpecCtl c = p.ctl[ch];
+    int restore = 0;
+    const int R = p.round;
+    if (!c.dead && R >= 2 && c.rb_round != R - 1) {
+        const int s = p.trk[(size_t)(R - 2) * p.n_chan + ch];
+        const int x = s >= 0 ? p.fail[(size_t)(R - 2) * p.n_chan + ch] : kNoFail;
+        if (x != kNoFail) {
+            if (c.n_force < kMaxForce) { c.force_ms[c.n_force++] = x; c.cursor = s; c.rb_round = R; ++c.redos; restore = 1; }
+            else { c.dead = 1; c.cursor = s; }
+        }
+    }
+    const int sub = (!c.dead && c.cursor < p.n_sub) ? c.cursor : -1;
+    p.trk[(size_t)R * p.n_chan + ch] = sub;
+    if (sub >= 0) c.cursor = sub + 1;
+    p.ctl[ch] = c;
+    red->ctl_sub = sub; red->ctl_restore = restore; red->ctl_nforce = c.n_force;
+#pragma unroll
+    for (int i = 0; i < kMaxForce; ++i) red->force_ms[i] = c.force_ms[i];
+}
 
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory queue (s_waitcnt
 // vmcnt(0)), which in the latency-bound tracking loop means waiting for prefetches and record stores nobody reads here.
@@ -801,7 +852,32 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
     const int ch = xcd_contiguous(blockIdx.x, p.n_chan);
     if (p.only_if && !p.only_if[ch]) return;
     ChanState* st = p.states + ch;
-    int ms_first = p.ms_begin;
+    int ms_first = p.ms_begin, ms_last = p.ms_end;   // this channel's range in this launch
+    int n_force = 0;
+    if constexpr (SPEC) {
+        if (p.ctl) {   // (uniform) round protocol: see SpecCtl
+            if (threadIdx.x == 0) spec_ctl_begin(p, ch, sm.red);
+            __syncthreads();
+            const int sub = sm.red->ctl_sub, restore = sm.red->ctl_restore;
+            if (sub < 0) return;
+            n_force = __builtin_amdgcn_readfirstlane(sm.red->ctl_nforce);
+            ms_first = sub * p.sub_len;
+            ms_last = min(p.n_ms, ms_first + p.sub_len);
+            // the sub-block's checkpoint: taken now, or -- a verification failed in here two rounds ago -- gone back to
+            ChanState* ck = p.ckpt + (size_t)sub * p.n_chan + ch;
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(restore ? ck : st);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(restore ? st : ck);
+            for (int i = threadIdx.x; i < (int)(sizeof(ChanState) / 4); i += kThreadsHere) dst[i] = src[i];
+            __threadfence();
+            __syncthreads();
+            if (restore && sub > 0 && p.exact_hist && threadIdx.x == 0) {   // (the checkpoint carries the provisional code loop)
+                const DllExact x = p.exact_hist[(size_t)sub * p.n_chan + ch];
+                st->dll_phase = x.dll; st->code_phase = x.code_phase;
+            }
+            __threadfence();
+            __syncthreads();
+        }
+    }
     if (p.restore_from) {   // re-run of a channel whose speculation failed verification: back to the checkpoint before the failure
         const int j = p.from_sub ? min(p.from_sub[ch], (p.n_ms - 1) / max(p.sub_len, 1)) : 0;
         ms_first = p.from_sub ? j * p.sub_len : p.ms_begin;
@@ -844,7 +920,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
         sm.red->cc[0].step = carrier_from_cycles_fast(st->doppler * p.inv_fs * (double)(K * kSpecThreads));
         sm.red->cand_sel = 0; sm.red->rec_sel = 0;
         sm.red->defer = 0;
-        if (SPEC && p.ms_begin < p.ms_end) sm.red->t0_next = p.start_time[p.ms_begin];
+        if (SPEC && ms_first < ms_last) sm.red->t0_next = p.start_time[ms_first];
     }
     __syncthreads();
     if (p.exact0 && threadIdx.x == 0) {
@@ -870,15 +946,15 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
     float touch = 0.f;
     typename PreSamples<K>::type pre;
     if constexpr (PRE) {
-        if (ms_first < p.ms_end && !sm.red->istate[1]) stage_fetch_own<K>(stream + (int64_t)ms_first * N, pre, launder(threadIdx.x));
+        if (ms_first < ms_last && !sm.red->istate[1]) stage_fetch_own<K>(stream + (int64_t)ms_first * N, pre, launder(threadIdx.x));
     }
     if constexpr (LAT) {
-        if (p.ms_begin < p.ms_end) stage_fetch_own<K>(stream + (int64_t)p.ms_begin * N, smp, launder(threadIdx.x));
+        if (ms_first < ms_last) stage_fetch_own<K>(stream + (int64_t)ms_first * N, smp, launder(threadIdx.x));
     }
     WinCache wcache;
     wcache.q = -1; wcache.qe = -1; wcache.ql = -1;
     bool have_prev = false;   // speculative mode: the previous millisecond's record (and possibly its histories) await completion
-    for (int ms = ms_first; ms < p.ms_end; ++ms) {   // (ms_first == p.ms_begin except in a re-run from a later checkpoint)
+    for (int ms = ms_first; ms < ms_last; ++ms) {   // ([ms_first, ms_last) == [p.ms_begin, p.ms_end) except in a re-run from a later checkpoint and under the round protocol)
         gyp_track_rec* rec = p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + ms : nullptr;
         // (speculative mode: a load issued here would be waited for -- a few hundred cycles -- by the first carrier of the
         // wipe-off; wavefront 5 fetched the value into LDS during the previous millisecond's loop updates)
@@ -966,7 +1042,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
                     if (have_prev) rec_flush_spec(sm.red, rec ? rec - 1 : nullptr, lane);
                 }
                 // the raw samples are consumed: request the next millisecond now, the loads fly under the window sums
-                if (ms + 1 < p.ms_end) stage_fetch_own<K>(stream + (int64_t)(ms + 1) * N, smp, launder(threadIdx.x));
+                if (ms + 1 < ms_last) stage_fetch_own<K>(stream + (int64_t)(ms + 1) * N, smp, launder(threadIdx.x));
                 if (prof) t_b = (long long)__builtin_readcyclecounter();
                 const int centre = sm.red->istate[2];
                 spec_window<K>(sm, sl, centre, sN, tid, wcache);   // (incl. this wavefront's share of the float64 boundary sums)
@@ -989,7 +1065,12 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
                 wbest = wbest < 0 ? wbest + N : (wbest >= N ? wbest - N : wbest);
                 const float2 eq = *reinterpret_cast<const float2*>(sl.fin + 8);
                 const float energy = (float)(K >= 2 ? K / 2 : 1) * (eq.x + eq.y);   // every (K / 2)-th sample was summed
-                const bool fast = wbest != 0 && wbest != 2 * kSpecHalf - 1 && b.v >= p.spec_kappa * energy;
+                bool forced = false;   // a verification failed at this millisecond in an earlier pass over the sub-block (uniform, rare)
+                if (n_force) {
+                    const RedScratch* rf = launder_lds(sm.red);
+                    for (int i = 0; i < n_force; ++i) forced = forced || rf->force_ms[i] == ms;
+                }
+                const bool fast = !forced && wbest != 0 && wbest != 2 * kSpecHalf - 1 && b.v >= p.spec_kappa * energy;
                 if (prof) { t_c = (long long)__builtin_readcyclecounter(); tp[5] += fast ? 0 : 1; }
                 if (p.dbg && wave == 0 && lane < 20) {
                     float* o = p.dbg + ((int64_t)ch * p.n_ms + ms) * 20;
@@ -1053,7 +1134,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
             const LoopConst* kc = &launder_lds(sm.red)->kc;
             if (wave == 0) spec_lock_verdict<K>(kc->lp, kc->inv_fs, st, sm.red, t0, lane, m.peak, f, phi);
             if (wave == 4) spec_record_fields<K>(sm.red, m, lane);
-            if (wave == 5 && ms + 1 < p.ms_end) {
+            if (wave == 5 && ms + 1 < ms_last) {
                 const double tn = p.start_time[launder(ms + 1)];
                 if (lane == 0) launder_lds(sm.red)->t0_next = tn;
             }
@@ -1077,10 +1158,10 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
             if (wave == (kW >= 2 ? 1 : 0)) dll_update(red, m.disc, lane, red->kc.lp);
             if (wave == (kW >= 3 ? 2 : 0)) spec_record_fields<K>(red, m, lane);
             if constexpr (PRE) {   // (wavefront 0 gets here behind its update; a channel the watchdog has just dropped asks for samples nobody uses)
-                if (ms + 1 < p.ms_end) stage_fetch_own<K>(stream + (int64_t)(ms + 1) * N, pre, launder(threadIdx.x));
+                if (ms + 1 < ms_last) stage_fetch_own<K>(stream + (int64_t)(ms + 1) * N, pre, launder(threadIdx.x));
             }
             if constexpr (TOUCH) {
-                if (ms + 1 < p.ms_end) {
+                if (ms + 1 < ms_last) {
                     const cf* nb = stream + (int64_t)(ms + 1) * N;
                     const int t_ = launder(threadIdx.x);
                     touch = nb[K * t_].x + nb[K * min(t_ + Geom<K>::kThreads, kChips - 1)].x;
@@ -1101,9 +1182,9 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
     }
     if (SPEC && have_prev) {   // the last millisecond's deferred part
         if (wave == 0) spec_error_side(st, sm.red, 0.0, lane, sm.red->kc.lp);
-        if (wave == 1) rec_flush_spec(sm.red, p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + (p.ms_end - 1) : nullptr, lane);
+        if (wave == 1) rec_flush_spec(sm.red, p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + (ms_last - 1) : nullptr, lane);
     }
-    if (!SPEC && have_prev && wave == (Geom<K>::W >= 2 ? 1 : 0)) rec_flush(sm.red, p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + (p.ms_end - 1) : nullptr, lane);
+    if (!SPEC && have_prev && wave == (Geom<K>::W >= 2 ? 1 : 0)) rec_flush(sm.red, p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + (ms_last - 1) : nullptr, lane);
     if (threadIdx.x == 0) {
         st->doppler = SPEC ? sm.red->cc[sm.red->cand_sel].nf : sm.red->dstate[0];
         st->carrier_phase = SPEC ? sm.red->cc[sm.red->cand_sel].nphi : sm.red->dstate[1];
@@ -1139,7 +1220,12 @@ struct TrackVerifyParams {
     const cf* tw_tables;
     double inv_fs;
     float tie_tol;
-    int32_t force_fail_ms;     // test hook (GYP_SPEC_FAIL_AT): channel 0's verification "fails" at this millisecond; < 0: off
+    int32_t force_fail_ms;     // test hook (gyp_debug_set "spec_fail_at"): channel 0's verification "fails" at this millisecond; < 0: off
+    // round protocol (SpecCtl): channel ch's range is sub-block trk_round[ch] (sub_len milliseconds; -1: nothing to verify) and a
+    // failure is reported as the first failing millisecond in fail_round[ch]; null: [ms_begin, ms_end) of every channel, bad / bad_from
+    const int32_t* trk_round;
+    int32_t* fail_round;
+    int32_t sub_len;
 };
 
 template <int K>
@@ -1148,10 +1234,16 @@ __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void 
     constexpr int N = K * kChips;
     const Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
     __syncthreads();
-    const int n_units = p.n_chan * (p.ms_end - p.ms_begin);
+    const int n_units = p.n_chan * (p.trk_round ? p.sub_len : p.ms_end - p.ms_begin);
     for (int v = blockIdx.x; v < n_units; v += gridDim.x) {
         const int u = xcd_contiguous(v, n_units);
-        const int ms = p.ms_begin + u / p.n_chan, ch = u % p.n_chan;   // the channels of a millisecond are neighbours: shared IQ
+        int ms = p.ms_begin + u / p.n_chan;
+        const int ch = u % p.n_chan;   // the channels of a millisecond are neighbours: shared IQ
+        if (p.trk_round) {             // (uniform per unit)
+            const int sub = p.trk_round[ch];
+            ms = sub * p.sub_len + u / p.n_chan;
+            if (sub < 0 || ms >= p.n_ms) continue;
+        }
         const SpecIn in = p.spec[(int64_t)ch * p.n_ms + ms];
         if (in.key < 0) continue;                                 // uniform: transform path in the tracking kernel, or not processed
         const ChanState* st = p.states + ch;
@@ -1168,7 +1260,10 @@ __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void 
                 const float vp = fmaf(r.probe.x, r.probe.x, r.probe.y * r.probe.y), vm = r.best.v * r.best.v;
                 failed = failed || !(vp >= vm * (1.0f - p.tie_tol));
             }
-            if (failed) { p.bad[ch] = 1; atomicMin(p.bad_from + ch, p.sub_index); }
+            if (failed) {
+                if (p.fail_round) atomicMin(p.fail_round + ch, ms);
+                else { p.bad[ch] = 1; atomicMin(p.bad_from + ch, p.sub_index); }
+            }
             if (p.rec_out) {
                 const float mean_excl = (float)((r.sum - (double)r.n_max * (double)r.best.v) / (double)(N - r.n_max));
                 p.rec_out[(int64_t)ch * p.n_ms + ms].strength = r.best.v / mean_excl;

@@ -7,6 +7,7 @@ fails if the library or a gfx950 device is missing.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
@@ -67,6 +68,34 @@ class GypsumEngine:
         self.device = device
         self.fs: Optional[int] = None
         self.n: Optional[int] = None
+        self._apply_test_hooks()
+
+    # The library itself reads no GYP_* environment variable.  Test and A/B runs that want to flip a switch of every engine a
+    # process creates (tests/, tools/) export GYP_TEST_HOOKS=1 next to the switch; without it the variables below do nothing.
+    _ENV_HOOKS = {"GYP_NO_PIPE": "no_pipe", "GYP_NO_SHARED_FWD": "no_shared_fwd", "GYP_NO_ACQ_SPLIT": "no_acq_split",
+                  "GYP_NO_SPEC": "no_spec", "GYP_SPEC_DEBUG": "spec_debug", "GYP_ACQ_LANES": "acq_lanes",
+                  "GYP_TRACK_CHUNK_MS": "track_chunk_ms", "GYP_SYMBOL_TAU": "symbol_tau", "GYP_DLL_PROV_BIAS": "dll_prov_bias",
+                  "GYP_SPEC_FAIL_AT": "spec_fail_at", "GYP_SPEC_REDO": "spec_redo", "GYP_EXACT_PREFETCH": "exact_prefetch"}
+
+    def _apply_test_hooks(self) -> None:
+        if os.environ.get("GYP_TEST_HOOKS") != "1":
+            return
+        for env, name in self._ENV_HOOKS.items():
+            v = os.environ.get(env)
+            if v is None:
+                continue
+            self.debug_set(name, float(v) if v.strip() else 1.0)   # a malformed value raises here instead of being read as 0
+        if os.environ.get("GYP_SPEC_KAPPA") is not None:
+            self.set_params(spec_confidence_kappa=float(os.environ["GYP_SPEC_KAPPA"]))
+
+    def debug_set(self, name: str, value: float) -> None:
+        """A/B switches and test hooks of the context (gyp_debug_set; names and ranges in include/gypsum_hip.h)."""
+        self._check(self.lib.gyp_debug_set(self.ctx, name.encode(), float(value)))
+
+    def debug_get(self, name: str) -> float:
+        v = C.c_double()
+        self._check(self.lib.gyp_debug_get(self.ctx, name.encode(), C.byref(v)))
+        return float(v.value)
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc: int) -> None:
@@ -345,7 +374,7 @@ class ChannelBank:
 
     def dll_repairs(self) -> np.ndarray:
         """Per channel: milliseconds of the last block in which the exactly re-integrated code loop differed from the
-        speculative kernel's provisional one and repaired it (gyp_debug_dll_read); zeros on the throughput kernel."""
+        tracking kernel's provisional one and repaired it (gyp_debug_dll_read); either tracking path counts them."""
         out = np.zeros(self.n_chan, dtype=np.int32)
         self.engine._check(self.engine.lib.gyp_debug_dll_read(self.handle, _lib.ptr(out)))
         return out

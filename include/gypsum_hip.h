@@ -28,9 +28,10 @@
 extern "C" {
 #endif
 
-/* 200: gyp_chan_out carries the float64 early/late pair (80 bytes), gyp_track_rec::path_info, gyp_debug_track_profile writes
+/* 201: gyp_debug_set / gyp_debug_get / gyp_debug_spec_redo_read added (the library no longer reads GYP_* environment switches).
+ * 200: gyp_chan_out carries the float64 early/late pair (80 bytes), gyp_track_rec::path_info, gyp_debug_track_profile writes
  * 16 values, gyp_params grew; a binding written against another value must not load the library (gypsum_amd/_lib.py checks). */
-#define GYP_VERSION 200 /* 0.2.0 */
+#define GYP_VERSION 201 /* 0.2.1 */
 
 enum {
     GYP_OK = 0,
@@ -486,6 +487,24 @@ int gyp_ingest_next_dev(gyp_ingest* ing, const float** iq_dev_out, int64_t* firs
  * (antenna_sample_provider.py:88-89), bit-identical to Python's round(). */
 int gyp_ingest_times(const gyp_ingest* ing, int64_t first_ms, int32_t n_ms, double* start_out, double* end_out);
 
+/* A/B switches and test hooks of a context, by name.  The library reads NO environment variable for them (only GYP_RCCL_LIB,
+ * a deployment's library path): a stray variable must not change the speed path.  Names, value ranges (checked; GYP_E_BAD_ARG
+ * with a message otherwise) and defaults:
+ *   "no_pipe" 0/1 (0)           the two-workgroups-per-CU cells kernel instead of the pipelined one; no speculative tracker
+ *   "no_shared_fwd" 0/1 (0)     flat grids transform every cell's rows themselves
+ *   "no_acq_split" 0/1 (0)      a multi-stream scan runs on the caller's stream alone
+ *   "acq_lanes" 1..4 (2)        parts a multi-stream scan is split into
+ *   "no_spec" 0/1 (0)           lightly loaded banks use the throughput kernel too
+ *   "spec_redo" 0/1 (1)         0: a failed speculation is re-run on the throughput kernel (r03 behaviour)
+ *   "spec_debug" 0/1 (0)        per-ms window dump for gyp_debug_spec_read
+ *   "track_chunk_ms" 0 | >= 20 (500)   launch length of the throughput tracking kernel (0: whole blocks)
+ *   "exact_prefetch" 0/1 (0)    dll_exact_wave_kernel with its next window software-prefetched (A/B: measured slower, profiles/r04_exact_ab.txt)
+ *   "symbol_tau" 0..100 (1e-4)  |Re peak| / |peak| below which dll_scan_kernel decides the pseudosymbol in float64 (test: 10 = always)
+ *   "dll_prov_bias" (0)         test hook: added to the PROVISIONAL discriminator so that the repair path runs; results must not change
+ *   "spec_fail_at" >= -1 (-1)   test hook: channel 0's verification is made to fail at that millisecond of a block
+ * Helper contexts of a split scan inherit the caller's values. */
+int gyp_debug_set(gyp_ctx* ctx, const char* name, double value);
+int gyp_debug_get(gyp_ctx* ctx, const char* name, double* value_out);
 /* Debug: per-phase shader-cycle counters of workgroup 0 of gyp_track_block_dev (correlate, reduce, loop update,
  * barrier, ms count) or, for the pipelined 8.184 Msps non-coherent cells kernel behind gyp_correlate_cells_dev /
  * gyp_acquire_dev, (stage, row load + forward, spectrum + prefetch, inverse + accumulate, barrier, iterations).
@@ -494,21 +513,26 @@ int gyp_ingest_times(const gyp_ingest* ing, int64_t first_ms, int32_t n_ms, doub
  * stamp-to-stamp cycles (state read, sample requests, staging, boundary sums, barrier, window, barrier, decision,
  * transform path if taken, loop update). */
 int gyp_debug_track_profile(gyp_ctx* ctx, int enable, long long* out16);
-/* Debug (speculative block tracker: 8.184 / 2.046 Msps banks of at most one channel per CU): with GYP_SPEC_DEBUG set in the
- * environment the last gyp_track_block(_dev) call leaves, per (channel, ms), 20 floats: |c0|^2 at the 8 window lags
+/* Debug (speculative block tracker: 8.184 / 2.046 Msps banks of at most one channel per CU): after
+ * gyp_debug_set(ctx, "spec_debug", 1) the last gyp_track_block(_dev) call leaves, per (channel, ms), 20 floats: |c0|^2 at the 8 window lags
  * (previous peak lag - 4 .. + 3), 8 zeros, the sample-energy estimate, code_phase mod N, the window centre, 0.  bad_out (may be NULL): per
  * channel, 1 if the verify pass sent the channel back through the transform kernel.  Synchronises the stream. */
 int gyp_debug_spec_read(gyp_bank* bank, float* out, int32_t n_floats, int32_t* bad_out);
 /* Debug / measurement: HIP events on the context's stream around the three stages behind gyp_track_block(_dev) on the
  * throughput path (banks of more than one channel per CU): enable != 0 arms it; out4 (may be NULL) receives, for the last
  * call, {ms in track_block_kernel (all its launches), ms in the dll_exact kernel, ms in dll_scan_kernel, number of
- * track_block_kernel launches: blocks longer than 500 ms go through in chunks, GYP_TRACK_CHUNK_MS} -- zeros when that call
+ * track_block_kernel launches: blocks longer than 500 ms go through in chunks, gyp_debug_set "track_chunk_ms"} -- zeros when that call
  * ran on the speculative path (lightly loaded banks), which has no such split.  bench.py's per-kernel roofline uses it. */
 int gyp_debug_track_timing(gyp_ctx* ctx, int enable, float* out4);
 /* Debug / telemetry (either tracking path): repairs_out[n_chan] = milliseconds of the last gyp_track_block(_dev) call in which
  * the exactly re-integrated code loop (dll_scan_kernel) had int(self.phase) differ from the tracking kernel's provisional one
  * and formed that millisecond's float64 sums again for the right lag.  Synchronises the stream. */
 int gyp_debug_dll_read(gyp_bank* bank, int32_t* repairs_out);
+/* Debug / telemetry (speculative block tracker): out4 = {sub-blocks of the last gyp_track_block(_dev) call, rounds enqueued for it,
+ * sub-blocks tracked AGAIN from their checkpoint because a millisecond's window had not held the profile's arg-max (the failed
+ * millisecond then takes the transform path), channels finished by the transform kernel instead (out of forced-transform slots or
+ * of rounds; every failure went this way up to ABI 200)}.  Zeros if the bank never took the speculative path.  Synchronises the stream. */
+int gyp_debug_spec_redo_read(gyp_bank* bank, int32_t* out4);
 /* Debug: time `iters` forward+inverse wavefront transform pairs per wavefront, `wgs` workgroups of `waves_per_wg`
  * wavefronts (LDS-resident data, no global traffic): the floor the correlator kernels are measured against. */
 int gyp_debug_fft_bench(gyp_ctx* ctx, int waves_per_wg, int wgs, int iters, float* ms_out);

@@ -10,6 +10,9 @@ if str(REPO) not in sys.path:
 if str(REPO / "tests") not in sys.path:
     sys.path.insert(0, str(REPO / "tests"))
 os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+# tests flip the library's A/B switches and test hooks through GYP_* variables: GypsumEngine forwards them (gyp_debug_set) only
+# under this opt-in -- the library itself reads no environment
+os.environ.setdefault("GYP_TEST_HOOKS", "1")
 
 
 def pytest_configure(config):

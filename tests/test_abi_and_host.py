@@ -194,3 +194,32 @@ def test_comm_entry_points_report_a_missing_librccl_instead_of_crashing(tmp_path
     assert r.returncode == 0, r.stderr[-2000:]
     rc, msg = r.stdout.strip().split(" ", 1)
     assert int(rc) == -8 and msg.startswith("librccl not found"), r.stdout
+
+
+def test_build_stamp_follows_content_not_mtimes(lib, monkeypatch):
+    """`build()` keeps the in-tree library exactly when its stamp carries the sha256 of the present sources and
+    flags -- touching a header (a fresh checkout, the copy to the GPU box) must not recompile, changing content or flags must."""
+    import os
+    from gypsum_amd import build
+    assert not build.is_stale()
+    hdr = build.HEADERS[0]
+    st = hdr.stat()
+    try:
+        os.utime(hdr, (st.st_atime + 3600, st.st_mtime + 3600))
+        assert not build.is_stale()
+    finally:
+        os.utime(hdr, (st.st_atime, st.st_mtime))
+    monkeypatch.setattr(build, "HIPCC_FLAGS", build.HIPCC_FLAGS + ["-DSOMETHING_ELSE"])
+    assert build.is_stale()
+
+
+def test_the_library_reads_no_switch_from_the_environment(lib):
+    """ADVICE r03 / VERDICT r03 item 8: GYP_SPEC_FAIL_AT, GYP_DLL_PROV_BIAS, GYP_SYMBOL_TAU & co. used to be process-global environment
+    switches of the shipped library; they are gyp_debug_set names now.  The only getenv left is the RCCL library path."""
+    src = (REPO / "gypsum_amd" / "csrc" / "gypsum_hip.hip").read_text()
+    names = set(re.findall(r'getenv\("(\w+)"\)', src))
+    for hpp in (REPO / "gypsum_amd" / "csrc").glob("*.hpp"):
+        names |= set(re.findall(r'getenv\("(\w+)"\)', hpp.read_text()))
+    assert names == {"GYP_RCCL_LIB"}, names
+    # and without a context the entry point refuses instead of crashing
+    assert lib.gyp_debug_set(None, b"no_spec", 1.0) == _lib.GYP_E_BAD_ARG

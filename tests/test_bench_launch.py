@@ -27,6 +27,17 @@ def test_gpus_2_self_spawns_and_rendezvous():
     assert line["master"].startswith("127.0.0.1:")
 
 
+def test_gpus_8_self_spawns_and_gathers_per_rank_figures():
+    """The driver's 8-GPU form on CPU ranks: eight processes, one rendezvous, the per-rank figures of the N > 1 line
+    (Comm.gather_floats: per-rank ms_per_step / kernel time) arrive in rank order, one JSON line."""
+    r = _run(["--gpus", "8", "--rendezvous-only"], timeout=420)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["max_rank_seen"] == 7 and line["ranks_gathered"] == list(range(8))
+
+
 def test_launched_by_torchrun_style_environment_too():
     """The driver's other form: WORLD_SIZE etc. already set by torch.distributed.run -> no second level of spawning."""
     import socket

@@ -211,27 +211,132 @@ def test_failed_speculation_is_recovered_bit_for_bit():
             assert np.array_equal(rec_s[i][f], rec_t[i][f]), (i, f)
 
 
-def test_a_failed_verification_reruns_from_its_sub_block_only():
-    """Blocks of the speculative tracker are verified in sub-blocks, each starting from a checkpoint: a verification failure
-    in sub-block j (forced here for channel 0 at ms 250 of a 400-ms block = 4 sub-blocks of 100) sends that channel back
-    through the transform kernel from ms 200 on -- not from ms 0 -- and every integer still equals the transform kernel's."""
+def _redo_stats(eng, bank_handle):
+    out = np.zeros(4, dtype=np.int32)
+    eng._check(eng.lib.gyp_debug_spec_redo_read(bank_handle, _lib.ptr(out)))
+    return {"sub_blocks": int(out[0]), "rounds": int(out[1]), "redos": int(out[2]), "to_transform_kernel": int(out[3])}
+
+
+def _bank_run_stats(eng, iq, inits, n, fs, n_ms, first_ms=9):
+    t0 = [orc.chunk_times(ms * n, n, fs)[0] for ms in range(first_ms, n_ms)]
+    bank = eng.create_bank(inits)
+    rec = bank.track_block(iq[first_ms * n:], 1, n_ms - first_ms, t0)
+    state = bank.state()
+    bad = np.zeros(len(inits), dtype=np.int32)
+    eng._check(eng.lib.gyp_debug_spec_read(bank.handle, None, 0, _lib.ptr(bad)))
+    stats = _redo_stats(eng, bank.handle)
+    bank.close()
+    return rec, state, bad, stats
+
+
+@pytest.mark.parametrize("redo", [1, 0])
+def test_a_failed_verification_costs_its_sub_block_only(redo):
+    """Blocks of the speculative tracker are verified in sub-blocks, each starting from a checkpoint.  A verification failure in
+    sub-block j (forced here for channel 0 at ms 250 of a 400-ms block = 4 sub-blocks of 100):
+      redo = 1 (default)  two rounds later the channel goes back to the checkpoint of sub-block 2, tracks it AGAIN on the
+                          speculative kernel with ms 250 on the transform path, and carries on: no channel meets the transform kernel;
+      redo = 0 (r03)      the channel is sent through the transform kernel from ms 200 on -- not from ms 0.
+    Either way every integer equals the transform kernel's."""
     fs, n = 8_184_000, 8184
     n_ms = 409
     iq, inits = _scene_and_inits(fs, n, n_ms, 4, 5150)
     eng_t = _engine_with_env(fs, n, GYP_NO_SPEC=1)
     rec_t, st_t, _, _ = _bank_run(eng_t, iq, inits, n, fs, n_ms)
     eng_t.close()
-    eng_s = _engine_with_env(fs, n, GYP_SPEC_FAIL_AT=250)
-    rec_s, st_s, _, bad = _bank_run(eng_s, iq, inits, n, fs, n_ms)
+    eng_s = _engine_with_env(fs, n, GYP_SPEC_FAIL_AT=250, GYP_SPEC_REDO=redo)
+    rec_s, st_s, bad, stats = _bank_run_stats(eng_s, iq, inits, n, fs, n_ms)
     eng_s.close()
-    assert bad.tolist() == [1, 0, 0, 0]
     fast = (rec_s["path_info"] & 3) == 1
-    assert fast[0, :200].mean() > 0.9 and not fast[0, 200:].any()      # channel 0: speculative up to its checkpoint, transform kernel after
+    if redo:
+        assert bad.tolist() == [0, 0, 0, 0]
+        assert stats["sub_blocks"] == 4 and stats["redos"] == 1 and stats["to_transform_kernel"] == 0, stats
+        assert not fast[0, 250] and fast[0].mean() > 0.9                # channel 0 stayed speculative around the one forced millisecond
+    else:
+        assert bad.tolist() == [1, 0, 0, 0]
+        assert fast[0, :200].mean() > 0.9 and not fast[0, 200:].any()  # channel 0: speculative up to its checkpoint, transform kernel after
     assert fast[1:].mean() > 0.9                                        # the others never left the speculative path
     for f in ("code_phase", "peak_offset", "pseudosymbol", "locked"):
         assert np.array_equal(rec_s[f], rec_t[f]), f
     np.testing.assert_allclose(rec_s["discriminator"], rec_t["discriminator"], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(rec_s["peak_re"], rec_t["peak_re"], rtol=0, atol=2e-5 * np.abs(rec_t["peak_re"]).max())
+    np.testing.assert_allclose(rec_s["strength"], rec_t["strength"], rtol=1e-4)
     for key in ("code_phase", "lost"):
         assert np.array_equal(st_s[key], st_t[key]), key
     np.testing.assert_allclose(st_s["doppler_hz"], st_t["doppler_hz"], rtol=0, atol=1e-5)
+
+
+def test_redo_rounds_hand_hopeless_channels_to_the_transform_kernel():
+    """The round protocol under fire: kappa = 0 trusts every interior window maximum, so noise-only channels fail verification
+    almost everywhere.  They use up their forced-transform slots and are finished by the transform kernel from their last good
+    checkpoint -- bit for bit what the transform kernel gives alone -- while a weak-but-present channel may be re-done a few
+    times; the channels with a strong signal never notice.  Several sub-blocks (609 ms = 4 x 150), so roll-backs, stale rounds
+    and the end-of-block consultation all run."""
+    fs, n = 8_184_000, 8184
+    n_ms = 609
+    scene = synth.random_scene(fs, n_ms, 4, 9911, max_code_phase=2046)
+    iq = synth.render(scene)
+    present = {s.sat_id for s in scene.sats}
+    absent = [sv for sv in range(1, 33) if sv not in present][:3]
+    inits = np.zeros(len(scene.sats) + len(absent), dtype=_lib.CHAN_INIT)
+    for i, s in enumerate(scene.sats):
+        inits[i] = (0, s.sat_id, float(round(s.doppler_hz)), s.carrier_phase, s.code_phase, 0)
+    for j, sv in enumerate(absent):
+        inits[len(scene.sats) + j] = (0, sv, 1000.0 * (j - 1), 0.5, 100 + 700 * j, 0)
+    eng_t = _engine_with_env(fs, n, GYP_NO_SPEC=1)
+    rec_t, st_t, _, _ = _bank_run(eng_t, iq, inits, n, fs, n_ms)
+    eng_t.close()
+    eng_s = _engine_with_env(fs, n, GYP_SPEC_KAPPA=0)
+    rec_s, st_s, bad, stats = _bank_run_stats(eng_s, iq, inits, n, fs, n_ms)
+    eng_s.close()
+    assert bad[len(scene.sats):].all(), (bad, stats)         # the noise-only channels ended up with the transform kernel ...
+    assert stats["redos"] >= 3 * len(absent) and stats["to_transform_kernel"] == int(bad.sum()), stats
+    for i in range(len(inits)):                              # ... and every integer of every channel is the transform kernel's
+        for f in ("code_phase", "peak_offset", "pseudosymbol", "locked", "status"):
+            assert np.array_equal(rec_s[i][f], rec_t[i][f]), (i, f, bad, stats)
+        np.testing.assert_allclose(rec_s[i]["strength"], rec_t[i]["strength"], rtol=1e-4)
+    for key in ("code_phase", "lost"):
+        assert np.array_equal(st_s[key], st_t[key]), key
+    np.testing.assert_allclose(st_s["doppler_hz"], st_t["doppler_hz"], rtol=0, atol=1e-5)
+
+
+def test_redo_rounds_give_up_after_eight_forced_milliseconds():
+    """A long block (20 sub-blocks, 28 rounds): a noise-only channel under kappa = 0 fills its eight forced-transform slots inside
+    the rounds and is declared dead there; the transform kernel finishes it from that sub-block's checkpoint.  Same integers as the
+    transform kernel alone, for it and for the channel with a signal beside it."""
+    fs, n = 8_184_000, 8184
+    n_ms = 4109
+    scene = synth.random_scene(fs, n_ms, 2, 31415, max_code_phase=2046)
+    iq = synth.render(scene)
+    present = {s.sat_id for s in scene.sats}
+    absent = [sv for sv in range(1, 33) if sv not in present][:1]
+    inits = np.zeros(len(scene.sats) + 1, dtype=_lib.CHAN_INIT)
+    for i, s in enumerate(scene.sats):
+        inits[i] = (0, s.sat_id, float(round(s.doppler_hz)), s.carrier_phase, s.code_phase, 0)
+    inits[len(scene.sats)] = (0, absent[0], 500.0, 0.5, 333, 0)
+    eng_t = _engine_with_env(fs, n, GYP_NO_SPEC=1)
+    rec_t, st_t, _, _ = _bank_run(eng_t, iq, inits, n, fs, n_ms)
+    eng_t.close()
+    eng_s = _engine_with_env(fs, n, GYP_SPEC_KAPPA=0)
+    rec_s, st_s, bad, stats = _bank_run_stats(eng_s, iq, inits, n, fs, n_ms)
+    eng_s.close()
+    assert stats["sub_blocks"] == 20 and bad[-1] == 1 and stats["redos"] >= 8, (bad, stats)
+    for i in range(len(inits)):
+        for f in ("code_phase", "peak_offset", "pseudosymbol", "locked", "status"):
+            assert np.array_equal(rec_s[i][f], rec_t[i][f]), (i, f, bad, stats)
+    for key in ("code_phase", "lost"):
+        assert np.array_equal(st_s[key], st_t[key]), key
+
+
+def test_debug_switches_are_range_checked(engine_factory):
+    """the A/B switches and test hooks are no longer read from the environment by the library; gyp_debug_set checks
+    names and ranges (a malformed value used to become 0 through atof and silently change the path)."""
+    from gypsum_amd._lib import GypsumHipError
+    eng = engine_factory(8_184_000, 8184)
+    for name, bad_value in (("symbol_tau", -1.0), ("symbol_tau", float("nan")), ("track_chunk_ms", 1), ("acq_lanes", 0), ("acq_lanes", 2.5),
+                            ("no_spec", 2), ("no_such_switch", 1)):
+        with pytest.raises(GypsumHipError):
+            eng.debug_set(name, bad_value)
+    before = eng.debug_get("track_chunk_ms")
+    eng.debug_set("track_chunk_ms", 250)
+    assert eng.debug_get("track_chunk_ms") == 250
+    eng.debug_set("track_chunk_ms", before)

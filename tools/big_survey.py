@@ -3,6 +3,8 @@ int(self.phase) comes out one sample different from the float64 oracle for a mil
     python tools/big_survey.py <n_scenes> [GYP_NO_SPEC|-] [fs] [first_seed]"""
 import os
 import sys
+
+os.environ["GYP_TEST_HOOKS"] = "1"   # GypsumEngine forwards GYP_* switches to gyp_debug_set only under this opt-in
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]

@@ -1,3 +1,4 @@
+export GYP_TEST_HOOKS=1   # GypsumEngine forwards GYP_* switches (gyp_debug_set) only under this opt-in
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for C in 0 500 250 125; do
   echo "== GYP_TRACK_CHUNK_MS=$C"

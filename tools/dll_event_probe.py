@@ -3,6 +3,8 @@ discriminator differences and the oracle's DLL accumulator (how close to an inte
     python tools/dll_event_probe.py <seed> <channel> <ms> [GYP_NO_SPEC]"""
 import os
 import sys
+
+os.environ["GYP_TEST_HOOKS"] = "1"   # GypsumEngine forwards GYP_* switches to gyp_debug_set only under this opt-in
 from pathlib import Path
 
 import numpy as np

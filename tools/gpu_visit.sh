@@ -1,8 +1,9 @@
 #!/bin/bash
 # One GPU visit (through gpurun), steps chosen by name:
 #   gpurun --timeout 1500 -- 'bash tools/gpu_visit.sh <tag> step [step ...]'
-# steps: probe64  quick  tests  bench  benchfast  kt  pmc  surveys  single  phases  acqtl
+# steps: probe64  quick  newtests  abexact  tests  bench  benchfast  kt  pmc  surveys  single  phases  acqtl
 set -u
+export GYP_TEST_HOOKS=1   # GypsumEngine forwards GYP_* switches (gyp_debug_set) only under this opt-in
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
@@ -15,6 +16,16 @@ for step in "$@"; do
     probe64)
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/valu_rate_probe64.hip -o /tmp/valu_probe64 2>/dev/null && timeout 120 /tmp/valu_probe64 > $O/valu_probe64.txt 2>&1
       cat $O/valu_probe64.txt ;;
+    newtests)
+      timeout 900 python -m pytest tests/test_gpu_dll_exact.py tests/test_gpu_acq_lanes.py tests/test_gpu_end_to_end.py -x -q -m gpu > $O/pytest_new.log 2>&1
+      echo "pytest rc=$?" >> $O/pytest_new.log; tail -25 $O/pytest_new.log ;;
+    abexact)
+      for v in 0 1 2 3; do
+        echo "== exact_prefetch $v"
+        GYP_EXACT_PREFETCH=$v timeout 300 python bench.py --no-cpu-baseline --no-extras --steps 4 --warmup 1 2>/dev/null | python -c "
+import json,sys
+l=json.loads(sys.stdin.read()); print({k:l[k] for k in ('value','ms_per_step','acquire_ms_per_step','track_ms_per_step')}, l['track_kernels_ms_per_step'])"
+      done ;;
     quick)
       timeout 900 python -m pytest tests/test_gpu_dll_exact.py tests/test_gpu_parity.py tests/test_gpu_params.py -x -q -m gpu > $O/pytest_quick.log 2>&1
       echo "pytest rc=$?" >> $O/pytest_quick.log; tail -25 $O/pytest_quick.log ;;
@@ -46,6 +57,12 @@ for step in "$@"; do
     acqtl)
       timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/acqtl -o acq -- python tools/acq_timeline.py run > $O/acqtl.log 2>&1
       python tools/acq_timeline.py show $O/acqtl > $O/acq_timeline.txt 2>&1; rm -rf $O/acqtl; tail -25 $O/acq_timeline.txt ;;
+    singleab)
+      for v in 1 0; do
+        echo "== spec_redo $v"
+        GYP_SPEC_REDO=$v timeout 300 python tools/single_stream_probe.py 2>&1 | tail -4
+      done
+      timeout 300 python tools/gpu_profile_probe.py --single 2>&1 | tail -22 ;;
     single)
       timeout 600 python tools/single_stream_probe.py > $O/single_stream.txt 2>&1; tail -5 $O/single_stream.txt ;;
     *) echo "unknown step $step" ;;
