@@ -999,6 +999,8 @@ def main() -> None:
         # uninitialised HSA runtime (ncclCommInitRank: "no ROCm-capable device is detected").  INTEGRATION.md section 6.
         import torch  # noqa: F401
     eng = GypsumEngine(local_rank)
+    # one process per GPU: this rank's host thread (launches, pinned staging buffers) belongs on its GPU's NUMA node
+    host_bound = eng.bind_host_thread_to_gpu_node() if world > 1 else False
     comm = Comm(eng, rank, world, force_dist, args.allow_host_gather)
     rng = np.random.default_rng(20260925 + 7919 * rank)
 
@@ -1095,6 +1097,7 @@ def main() -> None:
                               "kernel_ms_per_launch": round(dom["ms"], 4)},
             "collective": {**eng.comm_info(), "ranks_launched": world, **({"fallback": comm.fallback} if comm.fallback else {}),
                            "device_ordinal_of_rank0": local_rank,
+                           "rank0_gpu_locality": {**{k: v for k, v in eng.locality().items() if k != "cpus"}, "host_thread_bound_to_it": host_bound},
                            "visible_devices_env": {k: os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")
                                                    if os.environ.get(k) is not None},
                            **({"allgather": result["allgather"]} if "allgather" in result else {})},

@@ -407,60 +407,68 @@ struct OwnSamples {
     static_assert(T * CH == 1024, "every thread owns CH chips, the last one of the last thread being the padding chip");
     cf w[CH][K];
 };
+// The raw samples of a thread's c-th chip (c < CH = 1024 / T).  The padding chip (m == 1023, one thread's last chip) re-reads chip
+// 1022: stage_emit_chip wipes it with a zero carrier, so that S = P = 0 without a branch or sixteen register clears in every thread.
+template <int K, int T>
+__device__ __forceinline__ void stage_fetch_chip(const cf* __restrict__ block, int c, cf (&dst)[K], int tid) {
+    constexpr int CH = OwnSamples<K, T>::CH;
+    const int m = c + 1 < CH ? tid + c * T : min(tid + c * T, kChips - 1);
+    load_samples<K>(block + K * m, dst);
+}
 template <int K, int T>
 __device__ __forceinline__ void stage_fetch_own(const cf* __restrict__ block, OwnSamples<K, T>& s, int tid) {
     constexpr int CH = OwnSamples<K, T>::CH;
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        // the padding chip (m == 1023, one thread's last chip) re-reads chip 1022: stage_emit_own_anchored wipes it with a
-        // zero carrier, so that S = P = 0 without a branch or sixteen register clears in every thread
-        const int m = c + 1 < CH ? tid + c * T : min(tid + c * T, kChips - 1);
-        load_samples<K>(block + K * m, s.w[c]);
-    }
+    for (int c = 0; c < CH; ++c) stage_fetch_chip<K, T>(block, c, s.w[c], tid);
 }
 __device__ __forceinline__ cf next_lane(cf v) {   // lane i <- lane i+1, lane 63 <- 0
     return make_float2(__uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v.x), 0x130, 0xF, 0xF, false)),
                        __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v.y), 0x130, 0xF, 0xF, false)));
 }
+// One chip of the halo-free staging: wipe the chip's K raw samples with the carrier `anchor` (its value at the chip's first
+// sample) advancing by rot1 per sample, publish the lane-0 prefix sums, write y_r[m] = S_r(m) + P_r(m + 1) for every row.
+// `wiped(c, w)` sees the chip's K wiped samples before they are summed (the tracking kernels take boundary samples there).
+template <int K, int T, typename Wiped>
+__device__ __forceinline__ void stage_emit_chip(const cf (&raw)[K], int c, cf anchor, cf rot1, cf* (&y_rows)[K], cf* __restrict__ halo, int tid,
+                                                Wiped&& wiped) {
+    constexpr int CH = OwnSamples<K, T>::CH;
+    const int lane = tid & 63;
+    const int m = tid + c * T;   // m == kChips (padding chip) carries zeros: writes y_r[1023] = 0
+    cf w[K];   // (not in place: the raw samples' registers are free for the next prefetch as soon as they are read)
+    cf car = anchor;
+    if (c + 1 == CH) {   // see stage_fetch_chip
+        car.x = m < kChips ? car.x : 0.f;
+        car.y = m < kChips ? car.y : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        w[i] = cmul(raw[i], car);
+        car = cmul(car, rot1);
+    }
+    wiped(c, w);
+    cf pre[K];   // pre[r] = P_r, pre[0] = 0
+    pre[0] = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int r = 1; r < K; ++r) pre[r] = cadd(pre[r - 1], w[r - 1]);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < K; ++r) halo[(m >> 6) * K + r] = pre[r];   // m = 64*g for a lane-0 chip
+    }
+    cf suf = make_float2(0.f, 0.f);   // running S_r from r = K-1 down
+#pragma unroll
+    for (int r = K - 1; r >= 1; --r) {
+        suf = cadd(suf, w[r]);
+        y_rows[r][m] = cadd(suf, next_lane(pre[r]));
+    }
+    y_rows[0][m] = cadd(suf, w[0]);
+}
 // `anchor[c]`: the carrier at the first sample of the thread's c-th chip.
-// `wiped(c, w)` sees chip c's K wiped samples before they are summed (the tracking kernels take boundary samples there).
 template <int K, int T, typename Wiped>
 __device__ __forceinline__ void stage_emit_own_anchored(OwnSamples<K, T>& s, const cf (&anchor)[OwnSamples<K, T>::CH], const CarrierSteps& cs,
                                                         cf* (&y_rows)[K], cf* __restrict__ halo, int tid, Wiped&& wiped) {
     constexpr int CH = OwnSamples<K, T>::CH;
-    const cf rot1 = cs.rot1;
-    const int lane = tid & 63;
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const int m = tid + c * T;   // m == kChips (padding chip) carries zeros: writes y_r[1023] = 0
-        cf w[K];   // (not in place: the raw samples' registers are free for the next prefetch as soon as they are read)
-        cf car = anchor[c];
-        if (c + 1 == CH) {   // see stage_fetch_own
-            car.x = m < kChips ? car.x : 0.f;
-            car.y = m < kChips ? car.y : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            w[i] = cmul(s.w[c][i], car);
-            car = cmul(car, rot1);
-        }
-        wiped(c, w);
-        cf pre[K];   // pre[r] = P_r, pre[0] = 0
-        pre[0] = make_float2(0.f, 0.f);
-#pragma unroll
-        for (int r = 1; r < K; ++r) pre[r] = cadd(pre[r - 1], w[r - 1]);
-        if (lane == 0) {
-#pragma unroll
-            for (int r = 0; r < K; ++r) halo[(m >> 6) * K + r] = pre[r];   // m = 64*g for a lane-0 chip
-        }
-        cf suf = make_float2(0.f, 0.f);   // running S_r from r = K-1 down
-#pragma unroll
-        for (int r = K - 1; r >= 1; --r) {
-            suf = cadd(suf, w[r]);
-            y_rows[r][m] = cadd(suf, next_lane(pre[r]));
-        }
-        y_rows[0][m] = cadd(suf, w[0]);
-    }
+    for (int c = 0; c < CH; ++c) stage_emit_chip<K, T>(s.w[c], c, anchor[c], cs.rot1, y_rows, halo, tid, wiped);
 }
 template <int K, int T>
 __device__ __forceinline__ void stage_emit_own_anchored(OwnSamples<K, T>& s, const cf (&anchor)[OwnSamples<K, T>::CH], const CarrierSteps& cs,

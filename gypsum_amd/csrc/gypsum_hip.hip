@@ -593,6 +593,7 @@ static int launch_track_block_t(gyp_ctx* ctx, const TrackBlockParams& p, int mod
     const int grid = p.n_chan;
     if (mode == 2) {   // 512 threads whatever the rate (launch_k's block size follows its rate argument: 8 -> 512)
         if (ctx->k == 2) return launch_k(ctx, track_block_kernel<2, PROF, 2>, 8, grid, p, lds_bytes_spec<2>());
+        if (ctx->k == 16) return launch_k(ctx, track_block_kernel<16, PROF, 2>, 8, grid, p, lds_bytes_spec<16>());
         return launch_k(ctx, track_block_kernel<8, PROF, 2>, 8, grid, p, lds_bytes_spec<8>());
     }
     switch (ctx->k) {
@@ -610,7 +611,7 @@ static int launch_track_block(gyp_ctx* ctx, const TrackBlockParams& p, int mode)
 static int launch_track_verify(gyp_ctx* ctx, const TrackVerifyParams& p, hipStream_t stream) {
     const int n_units = p.n_chan * (p.trk_round ? p.sub_len : p.ms_end - p.ms_begin);
     int grid = std::max(8, std::min(n_units, ctx->n_cus * blocks_per_cu(ctx->k)) & ~7);
-    if (p.trk_round && ctx->k == 8) {
+    if (p.trk_round && ctx->k >= 8) {
         // Round protocol: this launch runs beside the NEXT round's tracking launch, whose workgroups (one per channel, 97 KB of LDS)
         // fit no CU that already holds one of these (78 KB): a verify launch that fills the chip first makes the tracking launch wait
         // for it to drain, every round (0.3 us per ms-step of a 12-channel bank).  One workgroup per CU on all but the CUs the channels
@@ -623,6 +624,10 @@ static int launch_track_verify(gyp_ctx* ctx, const TrackVerifyParams& p, hipStre
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(track_verify_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds_bytes<2>()));
         hipLaunchKernelGGL(track_verify_kernel<2>, dim3(grid), dim3(threads_for(2)), lds_bytes<2>(), stream, p);
+    } else if (ctx->k == 16) {
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(track_verify_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds_bytes<16>()));
+        hipLaunchKernelGGL(track_verify_kernel<16>, dim3(grid), dim3(threads_for(16)), lds_bytes<16>(), stream, p);
     } else {
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(track_verify_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds_bytes<8>()));
@@ -872,7 +877,7 @@ int gyp_grid_best_bins_dev(gyp_ctx* ctx, const gyp_cell* cells_dev, int32_t n_ro
 // acquisition.py:70-152 from (center, spread) down to min_spread -- or exactly one level -- for every (stream, satellite).
 static int acquire_search(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_t stream_stride_samples, int32_t n_ms,
                           const int32_t* sat_ids_host, int32_t n_sats, double center0, double spread0, bool single_level,
-                          gyp_acq_result* out_dev) {
+                          gyp_acq_result* out_dev, int stream_base = 0) {
     if (!ctx) return GYP_E_BAD_ARG;
     if (!ctx->k) return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
     if (!iq_dev || !sat_ids_host || !out_dev || n_streams <= 0 || n_sats <= 0 || n_ms <= 0)
@@ -950,14 +955,14 @@ static int acquire_search(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, 
         hipLaunchKernelGGL(acq_exact_decide_kernel, dim3((unsigned)std::min(n_states, 32)), dim3(256), 0, ctx->stream, ep);
     }
     if (single_level) {
-        hipLaunchKernelGGL(acq_finish_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, (const gyp_cell*)nullptr, out_dev);
+        hipLaunchKernelGGL(acq_finish_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, (const gyp_cell*)nullptr, out_dev, stream_base);
         HIP_TRY(ctx, hipGetLastError());
         return GYP_OK;
     }
     hipLaunchKernelGGL(acq_plan_coherent_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_cells);
     rc = gyp_correlate_cells_dev(ctx, iq_dev, stream_stride_samples, n_ms, d_cells, n_states, GYP_COHERENT, d_out, nullptr);
     if (rc) return rc;
-    hipLaunchKernelGGL(acq_finish_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_out, out_dev);
+    hipLaunchKernelGGL(acq_finish_kernel, dim3(nblk), dim3(tpb), 0, ctx->stream, d_states, n_states, d_out, out_dev, stream_base);
     HIP_TRY(ctx, hipGetLastError());
     return GYP_OK;
 }
@@ -1007,7 +1012,7 @@ int gyp_acquire_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_
         const int cnt = (n_streams - s0) / (lanes - i);           // remaining streams spread evenly over the remaining lanes
         gyp_ctx* c = lane_ctx[i];
         rc = acquire_search(c, iq_dev + (int64_t)s0 * stream_stride_samples * 2, cnt, stream_stride_samples, n_ms, sat_ids_host, n_sats,
-                            0.0, ctx->params.acq_initial_spread_hz, false, out_dev + (size_t)s0 * n_sats);
+                            0.0, ctx->params.acq_initial_spread_hz, false, out_dev + (size_t)s0 * n_sats, s0);
         if (rc) why = c == ctx ? ctx->err : std::string("part of the scan on a helper stream: ") + c->err;
         enqueued = i + 1;   // (a part that failed half way may have launches in flight too)
         s0 += cnt;
@@ -1527,7 +1532,7 @@ int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stri
         HIP_TRY(ctx, hipMemsetAsync(bank->d_prof_delta, 0, (size_t)bank->n_chan * bank->prof_depth * sizeof(int32_t), ctx->stream));
         return track_block_throughput(bank, p, nullptr, nullptr);
     }
-    const bool light = (ctx->k == 8 || ctx->k == 2) && p.n_chan <= ctx->n_cus && !ctx->no_pipe;   // one workgroup per CU anyway
+    const bool light = (ctx->k == 8 || ctx->k == 2 || ctx->k == 16) && p.n_chan <= ctx->n_cus && !ctx->no_pipe;   // one workgroup per CU anyway
     if (light && !ctx->no_spec) return track_block_speculative(bank, p);
     return track_block_throughput(bank, p, nullptr, nullptr);
 }
@@ -2130,7 +2135,14 @@ int gyp_ingest_open(gyp_ctx* ctx, const char* path, int32_t fmt, int64_t fs_hz, 
             return GYP_OK;
         }
         HIP_TRY(ctx, hipSetDevice(ctx->device));
-        for (auto& p : g->host) HIP_TRY(ctx, hipHostMalloc((void**)&p, block_bytes, hipHostMallocDefault));
+        g->locality = device_locality(ctx->device);
+        {
+            ScopedAffinity on_the_gpus_node(g->locality);   // pinned pages land on the node of the thread that allocates them
+            for (auto& p : g->host) {
+                HIP_TRY(ctx, hipHostMalloc((void**)&p, block_bytes, hipHostMallocDefault));
+                std::memset(p, 0, block_bytes);              // first touch, still on that node
+            }
+        }
         HIP_TRY(ctx, hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
         g->dev_raw.assign(depth, nullptr);
         g->dev_iq.assign(depth, nullptr);
@@ -2151,6 +2163,14 @@ int gyp_ingest_open(gyp_ctx* ctx, const char* path, int32_t fmt, int64_t fs_hz, 
     }
     ingest_start_reader(g, 0);
     *out = g;
+    return GYP_OK;
+}
+
+int gyp_device_locality(gyp_ctx* ctx, int32_t* numa_node_out, char* cpulist_out, int32_t cap) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    const HostLocality loc = device_locality(ctx->device);
+    if (numa_node_out) *numa_node_out = loc.numa_node;
+    if (cpulist_out && cap > 0) std::snprintf(cpulist_out, (size_t)cap, "%s", loc.cpulist.c_str());
     return GYP_OK;
 }
 

@@ -9,15 +9,92 @@
 #pragma once
 
 #include <fcntl.h>
+#include <pthread.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <cctype>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <mutex>
 #include <thread>
 
 enum : int32_t { kFmtF32 = 0, kFmtI8 = 1, kFmtI16 = 2, kFmtU8 = 3 };
+
+// ---------------------------------------------------------------------------------------------------------
+// Host locality (SURVEY section 8 e: one process per GPU on an 8-GPU node).  A rank's reader thread and its pinned ring belong on
+// the NUMA node its GPU hangs off: across the socket interconnect a pinned H2D stream loses bandwidth and eight ranks' rings
+// would all land on the node the launcher happened to start on.  The GPU's node comes from sysfs (PCI bus id -> numa_node), the
+// node's CPUs from /sys/devices/system/node/nodeN/cpulist; a host without that information (containers, single-node boxes
+// reporting -1) is left alone.
+// ---------------------------------------------------------------------------------------------------------
+struct HostLocality {
+    int numa_node = -1;
+    std::string cpulist;       // as sysfs prints it, e.g. "0-31,128-159"
+    cpu_set_t cpus;
+    bool have_cpus = false;
+};
+static bool parse_cpulist(const std::string& text, cpu_set_t* set) {
+    CPU_ZERO(set);
+    int count = 0;
+    const char* p = text.c_str();
+    while (*p) {
+        char* end = nullptr;
+        const long a = std::strtol(p, &end, 10);
+        if (end == p || a < 0) break;
+        long b = a;
+        p = end;
+        if (*p == '-') {
+            b = std::strtol(p + 1, &end, 10);
+            if (end == p + 1 || b < a) break;
+            p = end;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET((int)c, set); ++count; }
+        if (*p == ',') ++p;
+        else break;
+    }
+    return count > 0;
+}
+static std::string read_small_file(const std::string& path) {
+    std::string out;
+    if (FILE* f = std::fopen(path.c_str(), "r")) {
+        char buf[512];
+        const size_t n = std::fread(buf, 1, sizeof(buf) - 1, f);
+        std::fclose(f);
+        out.assign(buf, n);
+        while (!out.empty() && (out.back() == '\n' || out.back() == ' ')) out.pop_back();
+    }
+    return out;
+}
+static HostLocality device_locality(int device) {
+    HostLocality loc;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) return loc;
+    for (char* c = bus; *c; ++c) *c = (char)std::tolower((unsigned char)*c);   // sysfs spells bus ids in lower case
+    const std::string node = read_small_file(std::string("/sys/bus/pci/devices/") + bus + "/numa_node");
+    if (node.empty()) return loc;
+    loc.numa_node = std::atoi(node.c_str());
+    if (loc.numa_node < 0) return loc;
+    loc.cpulist = read_small_file("/sys/devices/system/node/node" + std::to_string(loc.numa_node) + "/cpulist");
+    loc.have_cpus = parse_cpulist(loc.cpulist, &loc.cpus);
+    return loc;
+}
+// While alive, the calling thread runs on the given CPUs (pinned pages are allocated on the node of the thread that asks for them).
+struct ScopedAffinity {
+    cpu_set_t saved;
+    bool active = false;
+    explicit ScopedAffinity(const HostLocality& loc) {
+        if (!loc.have_cpus) return;
+        if (pthread_getaffinity_np(pthread_self(), sizeof(saved), &saved) != 0) return;
+        active = pthread_setaffinity_np(pthread_self(), sizeof(loc.cpus), &loc.cpus) == 0;
+    }
+    ~ScopedAffinity() {
+        if (active) (void)pthread_setaffinity_np(pthread_self(), sizeof(saved), &saved);
+    }
+};
 
 static inline int ingest_word_bytes(int32_t fmt) {
     switch (fmt) {
@@ -58,6 +135,7 @@ struct gyp_ingest {
     size_t ms_bytes = 0;
     int64_t total_ms = 0;     // milliseconds the reference provider delivers before NoMoreSamplesError
     std::string err;
+    HostLocality locality;    // the GPU's NUMA node: the pinned ring is allocated there and the reader thread runs there
 
     // host ring, filled by the reader thread
     std::vector<uint8_t*> host;
@@ -152,6 +230,8 @@ static void ingest_start_reader(gyp_ingest* g, int64_t at_ms) {
     g->eof = false;
     g->io_errno = 0;
     g->reader = std::thread(ingest_reader_main, g);
+    if (g->locality.have_cpus)   // (best effort: a cpuset that forbids those CPUs leaves the thread where it is)
+        (void)pthread_setaffinity_np(g->reader.native_handle(), sizeof(g->locality.cpus), &g->locality.cpus);
 }
 
 // Blocks until the reader has a block; returns false at end of data (or on an I/O error, see io_errno).

@@ -398,11 +398,13 @@ __global__ void acq_plan_coherent_kernel(const AcqSearchState* states, int n_sta
     cells[i] = d;
 }
 
-__global__ void acq_finish_kernel(const AcqSearchState* states, int n_states, const gyp_cell* cells, gyp_acq_result* out) {
+// stream_base: index of this call's first stream in the caller's numbering (a scan split over helper contexts: every part searches
+// its own streams 0 .. cnt-1, the records carry the caller's indices)
+__global__ void acq_finish_kernel(const AcqSearchState* states, int n_states, const gyp_cell* cells, gyp_acq_result* out, int stream_base) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_states) return;
     gyp_acq_result r;
-    r.stream = states[i].stream; r.sat_id = states[i].sat_id;
+    r.stream = states[i].stream + stream_base; r.sat_id = states[i].sat_id;
     r.doppler_hz = states[i].best_doppler; r.code_phase = states[i].best_index;
     r.carrier_phase = cells ? atan2((double)cells[i].tap_im, (double)cells[i].tap_re) : 0.0;   // no coherent pass after a single level
     r.strength = states[i].best_strength;

@@ -459,7 +459,11 @@ __device__ __forceinline__ void rec_flush(const RedScratch* red, gyp_track_rec* 
 // 1024 chip slots two apiece whatever K is (K = 8: the workgroup the other kernels use; K = 2: four times theirs).
 constexpr int kSpecThreads = 512;
 template <int K>
-constexpr bool kSpecRate = (K == 2 || K == 8);
+constexpr bool kSpecRate = (K == 2 || K == 8 || K == 16);   // the reference's 2x, 8x and 16x recording formats (radio_input.py:101-111)
+// K = 16: all sixteen rows resident (148 KB) leave no room for a second twiddle table in LDS: tw2048 stays in global memory / L1, as
+// in the throughput kernels (only the rare in-kernel transform path reads it).
+template <int K>
+constexpr bool kSpecTw2048InLds = (K <= 8);
 // ---- the Costas half again, split three ways for the speculative tracker (see RedScratch::cc) ----------------
 // One candidate: tracker.py:246-262 with the given loop bandwidth.
 template <int K>
@@ -679,8 +683,9 @@ constexpr int kSpecWinBytes = 32 * 8;
 constexpr int kSpecChipBytes = 2048 * 4;
 template <int K>
 constexpr int lds_bytes_spec() {
-    return lds_bytes<K>() + kTablesBytes + kSpecChipBytes + kSpecEinBytes + kSpecFinBytes + kSpecWinBytes;
+    return lds_bytes<K>() + (kSpecTw2048InLds<K> ? kTablesBytes : 0) + kSpecChipBytes + kSpecEinBytes + kSpecFinBytes + kSpecWinBytes;
 }
+static_assert(lds_bytes_spec<16>() <= 160 * 1024, "the 16.368 Msps speculative tracker fits a CU's LDS");
 struct SpecLds {
     float* chipf;     // [2048] +-1.0f, this channel's code twice over
     float* ein_part;  // [512]
@@ -716,7 +721,10 @@ __device__ __forceinline__ void spec_window(const Smem& sm, const SpecLds& sl, i
     const int jf = hk < 15 ? 63 + 64 * hk : kChips - 1;
     const int hrow = (hk < 15 ? hk + 1 : 0) * K;
     const bool on = lane < 16;
-    if (qa != wc.q) {   // wave-uniform
+    // (K = 16: the cache's 27 registers are the ones that spill -- and a reload of a spilled value queues behind the next
+    // millisecond's sample requests -- so the code values are simply read again every millisecond, in the same batch as the rows)
+    constexpr bool kCacheCodes = K <= 8;
+    if (!kCacheCodes || qa != wc.q) {   // wave-uniform
         const float* ca = sl.chipf + (kChips - qa) + lane;    // chip[(j - q) mod 1023] = chipf[j - q + 1023]
 #pragma unroll
         for (int k = 0; k < 16; ++k) wc.c[k] = ca[64 * k];
@@ -755,14 +763,14 @@ __device__ __forceinline__ void spec_window(const Smem& sm, const SpecLds& sl, i
         const int ss = __builtin_amdgcn_readfirstlane(sN);
         const int se = ss == 0 ? N - 1 : ss - 1, sl_ = ss + 1 == N ? 0 : ss + 1;
         const int re = se % K, qe = se / K, rl = sl_ % K, ql = sl_ / K;
-        if (qe != wc.qe) {
+        if (!kCacheCodes || qe != wc.qe) {
             const float* cp = sl.chipf + (kChips - qe) + lane + 256 * pq;
 #pragma unroll
             for (int k = 0; k < 4; ++k) wc.e[k] = cp[64 * k];
             wc.eh = (on && pq == 0) ? sl.chipf[jf - qe + kChips] : 0.f;
             wc.qe = qe;
         }
-        if (ql != wc.ql) {
+        if (!kCacheCodes || ql != wc.ql) {
             const float* cp = sl.chipf + (kChips - ql) + lane + 256 * pq;
 #pragma unroll
             for (int k = 0; k < 4; ++k) wc.l[k] = cp[64 * k];
@@ -798,22 +806,45 @@ template <int K>
 __device__ __attribute__((noinline)) EplResult spec_transform_path(const Smem& sm, const cf* __restrict__ rep, int sN) {
     const int tid = launder(threadIdx.x);
     const int wave = tid >> 6, lane = tid & 63, l = lane & 31, h = lane >> 5;
-    if (wave < K) {   // (uniform) one polyphase row per wavefront; at K = 2 six of the eight wavefronts only join the barrier
-        cf x[32];
-        const cf* yw = sm.xch + wave * kXchWave;
+    const LdsTables t{sm.tw1024, sm.tw2048};
+    if constexpr (K > 8) {   // sixteen rows, eight wavefronts: two rounds out of the rows already staged, per-lane running statistics
+        constexpr int W = Geom<K>::W;
+        static_assert(W == 8 && Geom<K>::R * W == K, "rows = rounds x wavefronts");
+        LaneStats ls = lane_stats_init();
+#pragma unroll 1
+        for (int rho = 0; rho < Geom<K>::R; ++rho) {
+            const int row = rho * W + wave;
+            cf x[32];
+            const cf* yw = sm.xch + row * kXchWave;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) x[j] = yw[32 * j + l];
-        halo_fixup<K>(x, sm.halo, wave, l);
-        wave_lds_fence();
-        float* tile_half = reinterpret_cast<float*>(sm.xch + wave * kXchWave) + h * kXchTile;
-        const LdsTables t{sm.tw1024, sm.tw2048};
-        cf c[16];
-        wave_fft_fwd(x, tile_half, t, l, h);
-        spectrum_mul_from(x, rep, lane);
-        wave_fft_inv(x, c, tile_half, t, l, h);
-        epl_round_wave<K>(c, sN, sN, sm.red, nullptr, tid);
+            for (int j = 0; j < 32; ++j) x[j] = yw[32 * j + l];
+            halo_fixup<K>(x, sm.halo, row, l);
+            wave_lds_fence();
+            float* tile_half = reinterpret_cast<float*>(sm.xch + row * kXchWave) + h * kXchTile;
+            cf c[16];
+            wave_fft_fwd(x, tile_half, t, l, h);
+            spectrum_mul_from(x, rep, lane);
+            wave_fft_inv(x, c, tile_half, t, l, h);
+            epl_round<K>(c, rho, sN, sN, ls, sm.red, nullptr, tid);
+        }
+        return epl_finish<K>(ls, sm.red, tid);
+    } else {
+        if (wave < K) {   // (uniform) one polyphase row per wavefront; at K = 2 six of the eight wavefronts only join the barrier
+            cf x[32];
+            const cf* yw = sm.xch + wave * kXchWave;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) x[j] = yw[32 * j + l];
+            halo_fixup<K>(x, sm.halo, wave, l);
+            wave_lds_fence();
+            float* tile_half = reinterpret_cast<float*>(sm.xch + wave * kXchWave) + h * kXchTile;
+            cf c[16];
+            wave_fft_fwd(x, tile_half, t, l, h);
+            spectrum_mul_from(x, rep, lane);
+            wave_fft_inv(x, c, tile_half, t, l, h);
+            epl_round_wave<K>(c, sN, sN, sm.red, nullptr, tid);
+        }
+        return epl_finish_wave<K>(sm.red);
     }
-    return epl_finish_wave<K>(sm.red);
 }
 
 // MODE 0: throughput form (several workgroups per CU).  MODE 2: the latency form for at most one workgroup per CU (the
@@ -827,20 +858,20 @@ template <int K, bool PROF, int MODE = 0>
 __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPerSimd) void track_block_kernel(TrackBlockParams p) {
     static_assert(MODE == 0 || MODE == 2, "r01's non-speculative latency variant (MODE 1) is gone: superseded by MODE 2");
     constexpr bool LAT = MODE == 2, SPEC = MODE == 2;
-    static_assert(!LAT || kSpecRate<K>, "the speculative form exists for K = 2 and K = 8");
+    static_assert(!LAT || kSpecRate<K>, "the speculative form exists for K = 2, 8 and 16");
     constexpr int kThreadsHere = SPEC ? kSpecThreads : Geom<K>::kThreads;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int N = K * kChips;
     Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
     SpecLds sl{};
-    if (LAT) {
+    if (LAT && kSpecTw2048InLds<K>) {
         cf* tw2048 = reinterpret_cast<cf*>(smem_raw + lds_bytes<K>());
         for (int i = threadIdx.x; i < 1024; i += kThreadsHere) tw2048[i] = p.tw_tables[1024 + i];
         sm.tw2048 = tw2048;
         sm.ones = nullptr;
     }
     if (SPEC) {
-        char* b = smem_raw + lds_bytes<K>() + kTablesBytes;
+        char* b = smem_raw + lds_bytes<K>() + (kSpecTw2048InLds<K> ? kTablesBytes : 0);
         sl.chipf = reinterpret_cast<float*>(b); b += kSpecChipBytes;
         sl.ein_part = reinterpret_cast<float*>(b); b += kSpecEinBytes;
         sl.fin = reinterpret_cast<double*>(b); b += kSpecFinBytes;
@@ -948,8 +979,17 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
     if constexpr (PRE) {
         if (ms_first < ms_last && !sm.red->istate[1]) stage_fetch_own<K>(stream + (int64_t)ms_first * N, pre, launder(threadIdx.x));
     }
+    // K = 16: a thread's two chips are 32 samples = 64 registers.  Held from one millisecond's staging to the next they push the
+    // kernel past its 256 registers, and a spill is worse than slow here: its reload queues BEHIND the sample requests (vector
+    // memory returns in order).  So only the first chip's samples are requested a phase early; the second chip's are requested
+    // at the top of the staging and arrive under the first chip's wipe-off (not quite: ~1500 cycles of their latency show at the
+    // staging barrier.  Requesting them at the end of the loop update instead was measured: 20 spills, 7.97 us per ms-step against 7.08).
+    constexpr bool SPLIT = LAT && K > 8;
     if constexpr (LAT) {
-        if (ms_first < ms_last) stage_fetch_own<K>(stream + (int64_t)ms_first * N, smp, launder(threadIdx.x));
+        if (ms_first < ms_last) {
+            if constexpr (SPLIT) stage_fetch_chip<K, kSpecThreads>(stream + (int64_t)ms_first * N, 0, smp.w[0], launder(threadIdx.x));
+            else stage_fetch_own<K>(stream + (int64_t)ms_first * N, smp, launder(threadIdx.x));
+        }
     }
     WinCache wcache;
     wcache.q = -1; wcache.qe = -1; wcache.ql = -1;
@@ -1012,19 +1052,29 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
                 GYP_STAMP(1);
                 // (the last thread's second chip is the padding chip: its registers hold a copy of chip 1022, see stage_fetch_own)
                 const bool chip1 = tid + kSpecThreads < kChips;
+                if constexpr (SPLIT) stage_fetch_chip<K, kSpecThreads>(block, 1, smp.w[1], tid);   // (see SPLIT above)
                 constexpr int kEs = K >= 2 ? K / 2 : 1;   // two samples per chip are summed: every (K / 2)-th
-                const float e_in = (smp.w[0][0].x * smp.w[0][0].x + smp.w[0][0].y * smp.w[0][0].y) +
-                                   (smp.w[0][kEs].x * smp.w[0][kEs].x + smp.w[0][kEs].y * smp.w[0][kEs].y) +
-                                   (chip1 ? smp.w[1][0].x * smp.w[1][0].x + smp.w[1][0].y * smp.w[1][0].y : 0.f) +
-                                   (chip1 ? smp.w[1][kEs].x * smp.w[1][kEs].x + smp.w[1][kEs].y * smp.w[1][kEs].y : 0.f);
                 cf* y_rows[K];
 #pragma unroll
                 for (int r = 0; r < K; ++r) y_rows[r] = sm.xch + r * kXchWave;
-                {
-                    static_assert(OwnSamples<K, kSpecThreads>::CH == 2, "second chip = first + K * 512 samples");
-                    cf anchor[2];
-                    anchor[0] = carrier_from_cycles_fast(u0 + du * (double)(K * tid));
-                    anchor[1] = cmul(anchor[0], half_step);
+                static_assert(OwnSamples<K, kSpecThreads>::CH == 2, "second chip = first + K * 512 samples");
+                cf anchor[2];
+                anchor[0] = carrier_from_cycles_fast(u0 + du * (double)(K * tid));
+                anchor[1] = cmul(anchor[0], half_step);
+                float e_in;
+                if constexpr (SPLIT) {
+                    const float e0 = (smp.w[0][0].x * smp.w[0][0].x + smp.w[0][0].y * smp.w[0][0].y) +
+                                     (smp.w[0][kEs].x * smp.w[0][kEs].x + smp.w[0][kEs].y * smp.w[0][kEs].y);
+                    auto none = [](int, const cf (&)[K]) {};
+                    stage_emit_chip<K, kSpecThreads>(smp.w[0], 0, anchor[0], cs.rot1, y_rows, sm.halo, tid, none);
+                    e_in = e0 + (chip1 ? smp.w[1][0].x * smp.w[1][0].x + smp.w[1][0].y * smp.w[1][0].y : 0.f) +
+                           (chip1 ? smp.w[1][kEs].x * smp.w[1][kEs].x + smp.w[1][kEs].y * smp.w[1][kEs].y : 0.f);
+                    stage_emit_chip<K, kSpecThreads>(smp.w[1], 1, anchor[1], cs.rot1, y_rows, sm.halo, tid, none);
+                } else {
+                    e_in = (smp.w[0][0].x * smp.w[0][0].x + smp.w[0][0].y * smp.w[0][0].y) +
+                           (smp.w[0][kEs].x * smp.w[0][kEs].x + smp.w[0][kEs].y * smp.w[0][kEs].y) +
+                           (chip1 ? smp.w[1][0].x * smp.w[1][0].x + smp.w[1][0].y * smp.w[1][0].y : 0.f) +
+                           (chip1 ? smp.w[1][kEs].x * smp.w[1][kEs].x + smp.w[1][kEs].y * smp.w[1][kEs].y : 0.f);
                     stage_emit_own_anchored<K>(smp, anchor, cs, y_rows, sm.halo, tid);
                 }
                 GYP_STAMP(2);
@@ -1042,7 +1092,10 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
                     if (have_prev) rec_flush_spec(sm.red, rec ? rec - 1 : nullptr, lane);
                 }
                 // the raw samples are consumed: request the next millisecond now, the loads fly under the window sums
-                if (ms + 1 < ms_last) stage_fetch_own<K>(stream + (int64_t)(ms + 1) * N, smp, launder(threadIdx.x));
+                if (ms + 1 < ms_last) {
+                    if constexpr (SPLIT) stage_fetch_chip<K, kSpecThreads>(stream + (int64_t)(ms + 1) * N, 0, smp.w[0], launder(threadIdx.x));
+                    else stage_fetch_own<K>(stream + (int64_t)(ms + 1) * N, smp, launder(threadIdx.x));
+                }
                 if (prof) t_b = (long long)__builtin_readcyclecounter();
                 const int centre = sm.red->istate[2];
                 spec_window<K>(sm, sl, centre, sN, tid, wcache);   // (incl. this wavefront's share of the float64 boundary sums)
@@ -1141,6 +1194,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
             if (wave == 1) dll_update(launder_lds(sm.red), m.disc, lane, kc->lp);
             if (wave == 2) costas_candidate<K>(kc->inv_fs, launder_lds(sm.red), m.peak, f, phi, kc->lp.alpha_locked, kc->lp.beta_locked, 0, lane);
             if (wave == 3) costas_candidate<K>(kc->inv_fs, launder_lds(sm.red), m.peak, f, phi, kc->lp.alpha_unlocked, kc->lp.beta_unlocked, 1, lane);
+
         } else {
             // Three wavefronts side by side: the Costas loop with the lock verdict (the serial chain the next wipe-off waits for),
             // the code loop, the record's measurement fields.  The record leaves for global memory at the top of the next

@@ -118,6 +118,29 @@ class GypsumEngine:
         self._check(self.lib.gyp_device_name(self.ctx, buf, 256))
         return buf.value.decode()
 
+    def locality(self) -> Dict[str, object]:
+        """NUMA node of this engine's GPU and that node's CPUs (gyp_device_locality); node -1 / empty list where the host does not say."""
+        node = C.c_int32(-1)
+        buf = C.create_string_buffer(512)
+        self._check(self.lib.gyp_device_locality(self.ctx, C.byref(node), buf, 512))
+        text = buf.value.decode()
+        cpus = []
+        for part in filter(None, text.split(",")):
+            a, _, b = part.partition("-")
+            cpus.extend(range(int(a), int(b or a) + 1))
+        return {"numa_node": int(node.value), "cpulist": text, "cpus": cpus}
+
+    def bind_host_thread_to_gpu_node(self) -> bool:
+        """Run the calling thread (and what it allocates from now on) on the CPUs of the GPU's NUMA node; False where unknown."""
+        cpus = self.locality()["cpus"]
+        if not cpus:
+            return False
+        try:
+            os.sched_setaffinity(0, set(cpus) & os.sched_getaffinity(0) or set(cpus))
+            return True
+        except OSError:
+            return False
+
     def set_stream(self, hip_stream: Optional[int]) -> None:
         self._check(self.lib.gyp_set_stream(self.ctx, C.c_void_p(hip_stream)))
 

@@ -479,6 +479,10 @@ int gyp_ingest_seek(gyp_ingest* ing, int64_t ms);
 /* Next block as raw file words on the host (n_ms x 2N words); valid until the next call on this handle.
  * *n_ms_out == 0 means end of data. */
 int gyp_ingest_next_host(gyp_ingest* ing, const void** raw_out, int64_t* first_ms_out, int32_t* n_ms_out);
+/* Host locality of the context's GPU: its NUMA node (-1: the host does not say) and that node's CPU list as sysfs prints it
+ * ("0-31,128-159"; empty if unknown).  gyp_ingest_open allocates its pinned ring on that node and runs its reader thread there;
+ * a multi-rank launcher (bench.py --gpus N) binds each rank's host thread the same way. */
+int gyp_device_locality(gyp_ctx* ctx, int32_t* numa_node_out, char* cpulist_out, int32_t cap);
 /* Next block as complex64 (interleaved float32 I,Q) in HBM, n_ms x N samples.  The context's stream is made to wait
  * for the upload, so kernels enqueued on it afterwards see the data; nothing blocks the host except waiting for the
  * reader thread.  The block stays valid while the next depth-2 calls are made.  *n_ms_out == 0: end of data. */

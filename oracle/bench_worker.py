@@ -7,6 +7,11 @@ single-threaded; sharding by satellite over processes is h
 """
 from __future__ import annotations
 
+import os
+
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")   # one core per worker, as the single-threaded reference would use it
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+
 import sys
 import time
 from pathlib import Path

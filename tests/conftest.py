@@ -13,6 +13,8 @@ os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
 # tests flip the library's A/B switches and test hooks through GYP_* variables: GypsumEngine forwards them (gyp_debug_set) only
 # under this opt-in -- the library itself reads no environment
 os.environ.setdefault("GYP_TEST_HOOKS", "1")
+# oracle worker processes inherit this: one BLAS thread each (tests/survey_worker.py says why)
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
 
 
 def pytest_configure(config):

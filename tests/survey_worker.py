@@ -7,6 +7,14 @@ return value.
 from __future__ import annotations
 
 import os
+
+# One BLAS thread per worker.  np.correlate of two 16368-sample vectors crosses OpenBLAS's threading threshold: with the default
+# thread pool a single-lag dot product takes 35 ms instead of 0.02 ms (and sixty workers times N threads oversubscribe the host) --
+# the reason the 16.368 Msps survey never finished in r03.  Must be set before numpy loads its BLAS.
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+os.environ.setdefault("MKL_NUM_THREADS", "1")
+
 import sys
 import tempfile
 from pathlib import Path

@@ -120,7 +120,7 @@ def _oracle_rows(iq, inits, fs, n, n_ms):
 def test_forced_repairs_leave_records_and_state_exact(fs):
     """A bias of 20 on the PROVISIONAL discriminator (~0.04 samples per ms on the tracking kernels' accumulator) makes their
     int(self.phase) disagree with the exact one every few milliseconds: the scan must repair each of them.  Both tracking
-    kernels (the speculative one exists at 8.184 and 2.046 Msps), with and without the bias: every integer equals the oracle's."""
+    kernels (the speculative one exists at 2.046, 8.184 and 16.368 Msps), with and without the bias: every integer equals the oracle's."""
     n = fs // 1000
     n_ms, n_sats = (409, 4) if n <= 8184 else (209, 3)
     iq, inits = _scene_and_inits(fs, n, n_ms, n_sats, 880 + n)
@@ -132,7 +132,7 @@ def test_forced_repairs_leave_records_and_state_exact(fs):
             # GYP_SYMBOL_TAU = 10: EVERY millisecond's pseudosymbol is rewritten from the float64 prompt value at the arg-max lag
             # (by default only those whose float32 peak has |Re| < 1e-4 |peak|): a wrong lag or carrier there would show everywhere
             ("throughput, float64 pseudosymbols", {"GYP_NO_SPEC": 1, "GYP_SYMBOL_TAU": 10.0, "GYP_DLL_PROV_BIAS": 20.0})]
-    if n in (2046, 8184):
+    if n in (2046, 8184, 16368):
         runs += [("speculative", {}), ("speculative, biased", {"GYP_DLL_PROV_BIAS": 20.0}),
                  ("speculative, float64 pseudosymbols", {"GYP_SYMBOL_TAU": 10.0})]
     states = []

@@ -190,17 +190,38 @@ def test_tracking_survey_2046(engine_factory):
 def test_tracking_survey_other_recording_rates(engine_factory, fs, n_scenes, seed0):
     """the residual of r03's off-line surveys lives at 4.092 Msps (one pseudosymbol in 3.6 M channel-ms, in a channel
     that never locked), and 16.368 Msps -- the reference's 16x recording format -- never finished a large survey.  >= 300 k channel-ms
-    each, driver-run (throughput kernel: no speculative form at these rates; K = 16 runs two rounds of transforms per millisecond).
+    each, driver-run (4.092 Msps: throughput kernel, there is no speculative form at K = 4; 16.368 Msps: the speculative tracker, new in r04).
     Code phase, peak offset and lock flags bit-exact everywhere; pseudosymbols bit-exact in every channel that locked at any point;
     in channels that never lock the Costas chain runs on float32 peaks whose rounding an unlocked loop amplifies: counted
     and bounded, not hidden."""
     n = fs // 1000
     eng = engine_factory(fs, n)
-    t = _survey(eng, list(range(seed0, seed0 + n_scenes)), 1009, 12, f"throughput kernel {fs / 1e6:.3f} Msps", fs, n)
+    t = _survey(eng, list(range(seed0, seed0 + n_scenes)), 1009, 12, f"{'speculative' if n == 16368 else 'throughput kernel'} {fs / 1e6:.3f} Msps", fs, n)
     assert t["n"] >= 300_000
     assert t["cp"] == 0 and t["off"] == 0 and t["lock"] == 0, t["first"]
     assert t["sym_locked"] == 0, t["first"]
     assert t["sym_never_locked"] <= 2, t["first"]
+    if n == 16368:
+        assert t["fast"] > 0.9 * t["n"]        # lightly loaded 16.368 Msps banks take the speculative tracker since r04
+    else:
+        assert t["fast"] == 0                  # no speculative form at 4.092 Msps
+
+
+def test_tracking_survey_16368_throughput_kernel():
+    """The 16x recording rate through the transform-only kernel as well (what a fully loaded bank runs): 8 scenes x 12 x 1000 ms."""
+    from gypsum_amd.engine import GypsumEngine
+    fs, n = 16_368_000, 16368
+    os.environ["GYP_NO_SPEC"] = "1"
+    try:
+        eng = GypsumEngine(0)
+    finally:
+        del os.environ["GYP_NO_SPEC"]
+    eng.set_stream_format(fs, n)
+    try:
+        t = _survey(eng, list(range(380000, 380008)), 1009, 12, "GYP_NO_SPEC 16.368 Msps", fs, n)
+    finally:
+        eng.close()
+    assert t["cp"] == 0 and t["off"] == 0 and t["lock"] == 0 and t["sym_locked"] == 0 and t["sym_never_locked"] <= 1, t["first"]
     assert t["fast"] == 0
 
 

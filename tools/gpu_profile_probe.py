@@ -12,6 +12,8 @@ from gypsum_amd.engine import GypsumEngine  # noqa: E402
 
 def main():
     fs, n = (8_184_000, 8184) if "--2046" not in sys.argv else (2_046_000, 2046)
+    if "--16368" in sys.argv:
+        fs, n = 16_368_000, 16368
     eng = GypsumEngine(0)
     eng.set_stream_format(fs, n)
     B, T, C_ = (1 if "--single" in sys.argv else (42 if "--full" in sys.argv else 21)), 200, 12

@@ -57,6 +57,16 @@ l=json.loads(sys.stdin.read()); print({k:l[k] for k in ('value','ms_per_step','a
     acqtl)
       timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/acqtl -o acq -- python tools/acq_timeline.py run > $O/acqtl.log 2>&1
       python tools/acq_timeline.py show $O/acqtl > $O/acq_timeline.txt 2>&1; rm -rf $O/acqtl; tail -25 $O/acq_timeline.txt ;;
+    survey16)
+      timeout 420 python -m pytest tests/test_gpu_track_survey.py -x -q -m gpu -s -k "other_recording_rates or 16368_throughput" 2>&1 | grep -v "^$" | tail -12 ;;
+    prof16)
+      timeout 300 python tools/gpu_profile_probe.py --single --16368 2>&1 | tail -22 ;;
+    lanes)
+      timeout 600 python -m pytest tests/test_gpu_acq_lanes.py -x -q -m gpu 2>&1 | tail -5 ;;
+    rate16)
+      timeout 300 python tools/rate_probe.py 16 1 4000 2>&1 | tail -2
+      GYP_NO_SPEC=1 timeout 300 python tools/rate_probe.py 16 1 1000 2>&1 | tail -1
+      timeout 300 python tools/rate_probe.py 2 1 5000 2>&1 | tail -1 ;;
     singleab)
       for v in 1 0; do
         echo "== spec_redo $v"
