@@ -43,6 +43,12 @@ template <int K>
 constexpr int lds_bytes() { return kTablesBytes + lds_rows<K>() * kXchWaveBytes + kRedBytes + halo_bytes<K>(); }
 static_assert(lds_bytes<16>() <= 160 * 1024, "K = 16 rows resident");
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory queue (s_waitcnt
+// vmcnt(0)), which in a latency-bound loop means waiting for prefetches and record stores nobody reads here.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 struct WaveCand {   // one wavefront's candidate for the profile maximum
     float v;
     int key;

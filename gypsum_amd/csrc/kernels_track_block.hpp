@@ -281,11 +281,6 @@ __device__ __forceinline__ void spec_ctl_begin(const TrackBlockParams& p, int ch
     for (int i = 0; i < kMaxForce; ++i) red->force_ms[i] = c.force_ms[i];
 }
 
-// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory queue (s_waitcnt
-// vmcnt(0)), which in the latency-bound tracking loop means waiting for prefetches and record stores nobody reads here.
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 __device__ __forceinline__ void workgroup_mem_fence_wave() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -983,7 +978,8 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
     // kernel past its 256 registers, and a spill is worse than slow here: its reload queues BEHIND the sample requests (vector
     // memory returns in order).  So only the first chip's samples are requested a phase early; the second chip's are requested
     // at the top of the staging and arrive under the first chip's wipe-off (not quite: ~1500 cycles of their latency show at the
-    // staging barrier.  Requesting them at the end of the loop update instead was measured: 20 spills, 7.97 us per ms-step against 7.08).
+    // staging barrier.  Measured and not kept: requesting them at the end of the loop update instead (20 spills, 7.97 us per ms-step
+    // against 7.08); touching one dword per line of them a phase early so that they wait in L2 (7.16-7.48).
     constexpr bool SPLIT = LAT && K > 8;
     if constexpr (LAT) {
         if (ms_first < ms_last) {

@@ -207,6 +207,29 @@ def test_tracking_survey_other_recording_rates(engine_factory, fs, n_scenes, see
         assert t["fast"] == 0                  # no speculative form at 4.092 Msps
 
 
+def test_known_4092_scene_whose_peak_has_a_zero_real_part(engine_factory):
+    """The one pseudosymbol that has ever differed from the oracle (profiles/r03_surveys.txt; located in r04: 4.092 Msps, scene seed
+    1700093, channel 8, ms 190).  The prompt peak there is (8.6e-07, -16.96): its real part -- whose SIGN is the pseudosymbol,
+    tracker.py:316 -- is 5e-8 of its modulus, below float32 resolution, in a channel that never locks (so its Costas loop, running
+    on float32 peaks, sits ~1e-7 rad from the float64 oracle's by then: the float64 re-evaluation at that millisecond -- which
+    dll_scan_kernel does for every |Re| < 1e-4 |peak| -- decides the sign of THAT state's value, not of the oracle's).  Documented
+    expectation: every integer of the scene equal, except possibly this one pseudosymbol; if it differs, it is that channel and
+    that millisecond and the peak is real-part-zero to 1e-6."""
+    global SEED_OFFSET
+    fs, n = 4_092_000, 4092
+    keep, SEED_OFFSET = SEED_OFFSET, 0
+    try:
+        t = _survey(engine_factory(fs, n), [1700093], 1009, 12, "known scene 4.092 Msps", fs, n)
+    finally:
+        SEED_OFFSET = keep
+    assert t["cp"] == 0 and t["off"] == 0 and t["lock"] == 0, t["first"]
+    assert t["sym"] <= 1 and t["sym_locked"] == 0, t["first"]
+    if t["sym"]:
+        assert "seed 1700093 ch 8 ms 190" in t["first"][0], t["first"]
+        re_, im_ = (float(v) for v in t["first"][0].split("peak (")[1].split(")")[0].split(","))
+        assert abs(re_) < 1e-6 * abs(complex(re_, im_)), t["first"]
+
+
 def test_tracking_survey_16368_throughput_kernel():
     """The 16x recording rate through the transform-only kernel as well (what a fully loaded bank runs): 8 scenes x 12 x 1000 ms."""
     from gypsum_amd.engine import GypsumEngine

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU visit (through gpurun), steps chosen by name:
 #   gpurun --timeout 1500 -- 'bash tools/gpu_visit.sh <tag> step [step ...]'
-# steps: probe64  quick  newtests  abexact  tests  bench  benchfast  kt  pmc  surveys  single  phases  acqtl
+# steps: probe64  quick  newtests  abexact  tests  bench  benchfast  kt  pmc  pmcgrid  surveys  single  singleab  rate16  prof16  survey16  find4092  lanes  phases  acqtl
 set -u
 export GYP_TEST_HOOKS=1   # GypsumEngine forwards GYP_* switches (gyp_debug_set) only under this opt-in
 TAG=$1; shift
@@ -30,7 +30,7 @@ l=json.loads(sys.stdin.read()); print({k:l[k] for k in ('value','ms_per_step','a
       timeout 900 python -m pytest tests/test_gpu_dll_exact.py tests/test_gpu_parity.py tests/test_gpu_params.py -x -q -m gpu > $O/pytest_quick.log 2>&1
       echo "pytest rc=$?" >> $O/pytest_quick.log; tail -25 $O/pytest_quick.log ;;
     tests)
-      timeout 1500 python -m pytest tests -m gpu -x -q -s > $O/pytest_gpu.log 2>&1
+      timeout ${TESTS_TIMEOUT:-720} python -m pytest tests -m gpu -x -q -s > $O/pytest_gpu.log 2>&1
       echo "pytest rc=$?" >> $O/pytest_gpu.log; grep -v "^$" $O/pytest_gpu.log | tail -40 ;;
     bench)
       timeout 900 python bench.py > $O/bench_cfg3.json 2> $O/bench_cfg3.err; echo "bench rc=$?"; head -c 7000 $O/bench_cfg3.json; echo ;;
@@ -49,6 +49,18 @@ l=json.loads(sys.stdin.read()); print({k:l[k] for k in ('value','ms_per_step','a
       timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES --output-format csv -d $O/pmc_sq2 -o bench -- $B > $O/pmc_sq2.log 2>&1
       rm -f $O/pmc_*/*/bench_agent_info.csv
       ls $O ;;
+    pmcgrid)
+      # other_configs' kernels: per-kernel times and HBM counters of the flat-grid workloads (each counter in a pass of its own)
+      for W in cfg2 cfg5; do
+        B="python bench.py --workload $W --no-cpu-baseline --steps 2 --warmup 1"
+        timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$W -o bench -- $B > $O/kt_$W.log 2>&1
+        rm -f $O/kt_$W/bench_kernel_trace.csv $O/kt_$W/*/bench_kernel_trace.csv $O/kt_$W/bench_agent_info.csv $O/kt_$W/*/bench_agent_info.csv
+        for c in FETCH_SIZE WRITE_SIZE; do
+          timeout 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${W}_${c} -o bench -- $B > $O/pmc_${W}_${c}.log 2>&1
+          rm -f $O/pmc_${W}_${c}/*/bench_agent_info.csv
+        done
+      done
+      ls $O ;;
     surveys)
       timeout 1500 python tools/big_survey.py ${SURVEY_SCENES:-500} - 8184000 ${SURVEY_SEED_A:-800000} > $O/survey_spec.txt 2>&1; tail -4 $O/survey_spec.txt
       timeout 1500 python tools/big_survey.py ${SURVEY_SCENES:-500} GYP_NO_SPEC 8184000 ${SURVEY_SEED_B:-900000} > $O/survey_nospec.txt 2>&1; tail -4 $O/survey_nospec.txt ;;
@@ -57,6 +69,9 @@ l=json.loads(sys.stdin.read()); print({k:l[k] for k in ('value','ms_per_step','a
     acqtl)
       timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/acqtl -o acq -- python tools/acq_timeline.py run > $O/acqtl.log 2>&1
       python tools/acq_timeline.py show $O/acqtl > $O/acq_timeline.txt 2>&1; rm -rf $O/acqtl; tail -25 $O/acq_timeline.txt ;;
+    find4092)
+      # the one pseudosymbol of r03's 3.6 M channel-ms at 4.092 Msps (profiles/r03_surveys.txt): which scene?
+      timeout 400 python tools/big_survey.py 300 - 4092000 1700000 > $O/survey_4092.txt 2>&1; tail -6 $O/survey_4092.txt ;;
     survey16)
       timeout 420 python -m pytest tests/test_gpu_track_survey.py -x -q -m gpu -s -k "other_recording_rates or 16368_throughput" 2>&1 | grep -v "^$" | tail -12 ;;
     prof16)

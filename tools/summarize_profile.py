@@ -85,10 +85,31 @@ for k, v in entry.items():
                           "correction": "FETCH_SIZE / WRITE_SIZE are in KB; factors = bytes moved per counted byte measured by "
                                         "tools/fetch_calib.hip for this kernel's patterns (16 B per lane at a 64-byte lane stride: "
                                         "read_staging; 56-byte records written dword by dword: write_records)"}
-    if "dll_exact_wave_kernel<8>" in k and "FETCH_SIZE" in v:
+    if "dll_exact_wave_kernel<8" in k and "FETCH_SIZE" in v:
         latest["cfg3_dll_exact"] = {"kernel": k, "fetch_kb_raw": v["FETCH_SIZE"]["mean_per_launch"], "fetch_factor": factor["read_windows"],
                                     "hbm_bytes_per_launch": factor["read_windows"] * v["FETCH_SIZE"]["mean_per_launch"] * 1024.0,
                                     "kernel_ms_during_counter_pass": durs.get(k)}
+# the flat-grid workloads (tools/gpu_visit.sh pmcgrid): every gyp kernel of one `bench.py --workload cfgN` step summed -- fold / wipe /
+# boxcar + cells -- with the guide's gfx950 correction for wide coalesced reads (x2 on FETCH_SIZE; writes as counted)
+for w in ("cfg2", "cfg5"):
+    fv, fd = pmc(f"pmc_{w}_FETCH_SIZE")
+    wv, _ = pmc(f"pmc_{w}_WRITE_SIZE")
+    kernels = {k: v for k, v in fv.items() if "gyp::grid_" in k}
+    if not kernels:
+        continue
+    per_launch = {}
+    for k, v in kernels.items():
+        f_kb = v["FETCH_SIZE"]["mean_per_launch"]
+        w_kb = wv.get(k, {}).get("WRITE_SIZE", {}).get("mean_per_launch", 0.0)
+        per_launch[k] = {"fetch_kb_raw": f_kb, "write_kb_raw": w_kb, "kernel_ms_during_counter_pass": fd.get(k), "launches": v["FETCH_SIZE"]["launches"]}
+    total = sum((2.0 * x["fetch_kb_raw"] + x["write_kb_raw"]) * 1024.0 for x in per_launch.values())
+    latest[w] = {"kernels": per_launch, "fetch_factor": 2.0, "write_factor": 1.0, "hbm_bytes_per_launch": total, "commit": commit, "tag": tag,
+                 "correction": "sum over the workload's grid_* kernels of one step; FETCH_SIZE x 2 (gfx950 under-reports wide coalesced reads, "
+                               "MI355X_MICROARCH.md / tools/fetch_calib.hip read_contiguous), WRITE_SIZE as counted; KB -> bytes"}
+    summary[w] = per_launch
+    for f in (src / f"kt_{w}").rglob("*kernel_stats.csv"):
+        shutil.copy(f, dst / f"{tag}_bench_{w}_kernel_stats.csv")
+json.dump(summary, open(dst / f"{tag}_pmc_summary.json", "w"), indent=1)
 json.dump(latest, open(dst / "pmc_latest.json", "w"), indent=1)
 print(json.dumps(latest, indent=1))
 sq = summary.get("sq_cfg3", {})
