@@ -403,8 +403,11 @@ constexpr int largest_divisor_up_to_8(int k) {
 template <int K, int T_ = 64 * largest_divisor_up_to_8(K)>
 struct OwnSamples {
     static constexpr int T = T_;
-    static constexpr int CH = (kChips + T - 1) / T;
-    static_assert(T * CH == 1024, "every thread owns CH chips, the last one of the last thread being the padding chip");
+    static constexpr int CH = (kChips + 1 + T - 1) / T;
+    // T * CH == 1024: every thread owns CH chips, the last one of the last thread being the padding chip (m == 1023).  Workgroups
+    // of 320 / 384 threads (K = 10, 12) do not divide 1024: their last chip index runs past 1023 for most threads, which then
+    // wipe a clamped copy of chip 1022 with a zero carrier and write nothing.
+    static constexpr bool kExact = T * CH == 1024;
     cf w[CH][K];
 };
 // The raw samples of a thread's c-th chip (c < CH = 1024 / T).  The padding chip (m == 1023, one thread's last chip) re-reads chip
@@ -412,7 +415,7 @@ struct OwnSamples {
 template <int K, int T>
 __device__ __forceinline__ void stage_fetch_chip(const cf* __restrict__ block, int c, cf (&dst)[K], int tid) {
     constexpr int CH = OwnSamples<K, T>::CH;
-    const int m = c + 1 < CH ? tid + c * T : min(tid + c * T, kChips - 1);
+    const int m = (c + 1 < CH && OwnSamples<K, T>::kExact) ? tid + c * T : min(tid + c * T, kChips - 1);
     load_samples<K>(block + K * m, dst);
 }
 template <int K, int T>
@@ -436,10 +439,11 @@ __device__ __forceinline__ void stage_emit_chip(const cf (&raw)[K], int c, cf an
     const int m = tid + c * T;   // m == kChips (padding chip) carries zeros: writes y_r[1023] = 0
     cf w[K];   // (not in place: the raw samples' registers are free for the next prefetch as soon as they are read)
     cf car = anchor;
-    if (c + 1 == CH) {   // see stage_fetch_chip
+    if ((c + 1) * T > kChips) {   // (known at compile time after unrolling) see stage_fetch_chip
         car.x = m < kChips ? car.x : 0.f;
         car.y = m < kChips ? car.y : 0.f;
     }
+    const bool in_row = OwnSamples<K, T>::kExact || m <= kChips;   // slots 0 .. 1023 of a row exist (1023: the zero padding)
 #pragma unroll
     for (int i = 0; i < K; ++i) {
         w[i] = cmul(raw[i], car);
@@ -450,7 +454,7 @@ __device__ __forceinline__ void stage_emit_chip(const cf (&raw)[K], int c, cf an
     pre[0] = make_float2(0.f, 0.f);
 #pragma unroll
     for (int r = 1; r < K; ++r) pre[r] = cadd(pre[r - 1], w[r - 1]);
-    if (lane == 0) {
+    if (lane == 0 && in_row) {
 #pragma unroll
         for (int r = 0; r < K; ++r) halo[(m >> 6) * K + r] = pre[r];   // m = 64*g for a lane-0 chip
     }
@@ -458,9 +462,10 @@ __device__ __forceinline__ void stage_emit_chip(const cf (&raw)[K], int c, cf an
 #pragma unroll
     for (int r = K - 1; r >= 1; --r) {
         suf = cadd(suf, w[r]);
-        y_rows[r][m] = cadd(suf, next_lane(pre[r]));
+        const cf y = cadd(suf, next_lane(pre[r]));   // (the DPP move runs on every lane: outside the store's guard)
+        if (in_row) y_rows[r][m] = y;
     }
-    y_rows[0][m] = cadd(suf, w[0]);
+    if (in_row) y_rows[0][m] = cadd(suf, w[0]);
 }
 // `anchor[c]`: the carrier at the first sample of the thread's c-th chip.
 template <int K, int T, typename Wiped>

@@ -26,21 +26,31 @@ struct Geom {
     static_assert(K % W == 0, "W divides K");
     static constexpr int kThreads = 64 * W;
     // 16 wavefronts per CU (4 per SIMD, 128 VGPRs) for K == 8, 12 (168 VGPRs) below, 8 (256 VGPRs) for branch rounds
-    static constexpr int kMinWavesPerSimd = K > 8 ? 2 : (K == 8 ? 4 : 3);
+    static constexpr int kMinWavesPerSimd = K > 8 ? 2 : ((K == 8 || K == 2) ? 4 : 3);
 };
 // Halo-free staging (stage_fetch_own / stage_emit_own / halo_fixup): every sample is wiped once and ALL K polyphase rows
-// of the millisecond are resident in LDS -- K == 2, 4, 8 (one round; 2x and 8x are the reference's recording formats)
-// and K == 16 (its 16x recordings: two rounds of transforms out of one staging pass, 148 KB, one workgroup per CU): the
-// workgroup's 64 W threads own the 1024 chip slots evenly.  The other K <= 8 stage with a halo (stage_ms: every thread
-// also loads and wipes the next chip's first K - 1 samples), the other K > 8 stage W rows per round (stage_general).
+// of the millisecond are resident in LDS -- K == 2, 4, 8 (one round; 2x and 8x are the reference's recording formats),
+// K == 16 (its 16x recordings: two rounds of transforms out of one staging pass, 148 KB, one workgroup per CU) and, since r04,
+// K == 10 and 12 (two rounds, 96 / 114 KB; their 320 / 384 threads do not divide the 1024 chip slots: OwnSamples::kExact).
+// The other K <= 8 stage with a halo (stage_ms: every thread also loads and wipes the next chip's first K - 1 samples), the other
+// K > 8 (20, 48: their rows do not fit a CU's LDS) stage W rows per round (stage_general).
 template <int K>
-constexpr bool kOwnStaging = (K == 2 || K == 4 || K == 8 || K == 16);
+constexpr bool kOwnStaging = (K == 2 || K == 4 || K == 8 || K == 10 || K == 12 || K == 16);
 template <int K>
 constexpr int lds_rows() { return kOwnStaging<K> ? K : Geom<K>::W; }
+// The two-wavefront workgroups of K = 2 (the reference's 2x recording rate) carry the 8 KB tw1024 table per workgroup: 30 % of a
+// workgroup's LDS, which holds the CU at 5 workgroups = 10 wavefronts.  There the table stays in global memory / L1 like tw2048
+// does everywhere: 19.5 KB per workgroup, 8 per CU, 16 wavefronts (128 VGPRs).  Measured (profiles/r04_rate_probe.txt): 1536
+// channels x 1000 ms at 2.046 Msps 28.7 -> 25.1 ms; a 384-channel bank, which does not fill the chip either way, 2.66 -> 2.76 ms.
+// Tried for K = 1, 3, 4 as well and not kept: their small banks lose 8-13 % to the slower table reads.
+template <int K>
+constexpr bool kTw1024InLds = K != 2;
+template <int K>
+constexpr int tables_bytes() { return kTw1024InLds<K> ? kTablesBytes : 0; }
 template <int K>
 constexpr int halo_bytes() { return kOwnStaging<K> ? 16 * K * 8 : 0; }   // [16][K] prefix sums of the lane-0 chips
 template <int K>
-constexpr int lds_bytes() { return kTablesBytes + lds_rows<K>() * kXchWaveBytes + kRedBytes + halo_bytes<K>(); }
+constexpr int lds_bytes() { return tables_bytes<K>() + lds_rows<K>() * kXchWaveBytes + kRedBytes + halo_bytes<K>(); }
 static_assert(lds_bytes<16>() <= 160 * 1024, "K = 16 rows resident");
 
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory queue (s_waitcnt
@@ -135,13 +145,19 @@ constexpr int kHaloBytes = 16 * 8 * 8;   // K == 8 (the pipelined kernels keep t
 template <int K>
 __device__ __forceinline__ Smem carve_smem(char* base, const cf* __restrict__ tw_global) {
     Smem s;
-    s.tw1024 = reinterpret_cast<cf*>(base);
     s.tw2048 = tw_global + 1024;
     s.ones = tw_global + 2048;
-    s.xch = s.tw1024 + 1024;
-    s.red = reinterpret_cast<RedScratch*>(base + kTablesBytes + lds_rows<K>() * kXchWaveBytes);
-    s.halo = reinterpret_cast<cf*>(base + kTablesBytes + lds_rows<K>() * kXchWaveBytes + kRedBytes);
-    for (int i = threadIdx.x; i < 1024; i += Geom<K>::kThreads) s.tw1024[i] = tw_global[i];
+    if constexpr (kTw1024InLds<K>) {
+        s.tw1024 = reinterpret_cast<cf*>(base);
+        s.xch = s.tw1024 + 1024;
+    } else {
+        s.tw1024 = const_cast<cf*>(tw_global);   // (read only)
+        s.xch = reinterpret_cast<cf*>(base);
+    }
+    s.red = reinterpret_cast<RedScratch*>(base + tables_bytes<K>() + lds_rows<K>() * kXchWaveBytes);
+    s.halo = reinterpret_cast<cf*>(base + tables_bytes<K>() + lds_rows<K>() * kXchWaveBytes + kRedBytes);
+    if constexpr (kTw1024InLds<K>)
+        for (int i = threadIdx.x; i < 1024; i += Geom<K>::kThreads) s.tw1024[i] = tw_global[i];
     return s;
 }
 

@@ -678,7 +678,8 @@ constexpr int kSpecWinBytes = 32 * 8;
 constexpr int kSpecChipBytes = 2048 * 4;
 template <int K>
 constexpr int lds_bytes_spec() {
-    return lds_bytes<K>() + (kSpecTw2048InLds<K> ? kTablesBytes : 0) + kSpecChipBytes + kSpecEinBytes + kSpecFinBytes + kSpecWinBytes;
+    return lds_bytes<K>() + (kSpecTw2048InLds<K> ? kTablesBytes : 0) + kSpecChipBytes + kSpecEinBytes + kSpecFinBytes + kSpecWinBytes +
+           (kTw1024InLds<K> ? 0 : kTablesBytes);   // (the latency form keeps tw1024 in LDS at every rate: its own copy where carve_smem has none)
 }
 static_assert(lds_bytes_spec<16>() <= 160 * 1024, "the 16.368 Msps speculative tracker fits a CU's LDS");
 struct SpecLds {
@@ -870,7 +871,12 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
         sl.chipf = reinterpret_cast<float*>(b); b += kSpecChipBytes;
         sl.ein_part = reinterpret_cast<float*>(b); b += kSpecEinBytes;
         sl.fin = reinterpret_cast<double*>(b); b += kSpecFinBytes;
-        sl.win = reinterpret_cast<cf*>(b);
+        sl.win = reinterpret_cast<cf*>(b); b += kSpecWinBytes;
+        if constexpr (!kTw1024InLds<K>) {
+            cf* tw1024 = reinterpret_cast<cf*>(b);
+            for (int i = threadIdx.x; i < 1024; i += kThreadsHere) tw1024[i] = p.tw_tables[i];
+            sm.tw1024 = tw1024;
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();

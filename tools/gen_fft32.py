@@ -76,6 +76,60 @@ def gen(sign: int, in_slot, out_slot):
     return e, {out_slot[k]: v[k] for k in range(32)}
 
 
+def gen_split_radix(sign: int):
+    """The same transform as a split-radix (2/4) network with every multiplication folded into an FMA, for the count only (VERDICT
+    r03 item 1d asked whether split-radix codelets would be shorter): X[k], X[k+N/2] = U[k] +- (w^k Z[k] + w^3k Z'[k]),
+    X[k+N/4], X[k+3N/4] = U[k+N/4] -+ sign*i (w^k Z[k] - w^3k Z'[k]), each output pair as one FMA chain + one `2a - out`.
+    A general-position L-butterfly (4 outputs, two radix-2 stages' worth) costs 20 instructions against 24 for four folded radix-2
+    butterflies, but the radix-2 network has more multiplier-free butterflies (w = 1, -+i): 424 against 388 for N = 32 as generated
+    here (404 if the k = N/8 butterflies were special-cased at 16 instructions each).  On a
+    machine where a multiply-add costs what an add costs, radix 2 with `a - w b = 2a - (a + w b)` is already the short form."""
+    e = Emitter()
+
+    def rec(idx):
+        n = len(idx)
+        if n == 1:
+            return [(f"x[{idx[0]}].x", f"x[{idx[0]}].y")]
+        if n == 2:
+            (ar, ai), (br, bi) = (f"x[{idx[0]}].x", f"x[{idx[0]}].y"), (f"x[{idx[1]}].x", f"x[{idx[1]}].y")
+            return [(e.op("add", ar, br), e.op("add", ai, bi)), (e.op("sub", ar, br), e.op("sub", ai, bi))]
+        u, z, zp = rec(idx[0::2]), rec(idx[1::4]), rec(idx[3::4])
+        out = [None] * n
+        q = n // 4
+        for k in range(q):
+            (ur, ui), (vr, vi) = u[k], u[k + q]
+            (zr, zi), (yr, yi) = z[k], zp[k]
+            a1, a3 = sign * 2.0 * math.pi * k / n, sign * 2.0 * math.pi * 3 * k / n
+            c1, s1, c3, s3 = math.cos(a1), math.sin(a1), math.cos(a3), math.sin(a3)
+            if k == 0:
+                sr, si, dr, di = e.op("add", zr, yr), e.op("add", zi, yi), e.op("sub", zr, yr), e.op("sub", zi, yi)
+                out[k] = (e.op("add", ur, sr), e.op("add", ui, si))
+                out[k + 2 * q] = (e.op("sub", ur, sr), e.op("sub", ui, si))
+                # sign*i*D = sign * (-di, dr)
+                if sign < 0:
+                    out[k + q] = (e.op("add", vr, di), e.op("sub", vi, dr))
+                    out[k + 3 * q] = (e.op("sub", vr, di), e.op("add", vi, dr))
+                else:
+                    out[k + q] = (e.op("sub", vr, di), e.op("add", vi, dr))
+                    out[k + 3 * q] = (e.op("add", vr, di), e.op("sub", vi, dr))
+                continue
+            # X[k] = U + w1 Z + w3 Z'
+            r0 = e.op("fma", zi, -s1, ur); r0 = e.op("fma", zr, c1, r0); r0 = e.op("fma", yi, -s3, r0); r0 = e.op("fma", yr, c3, r0)
+            i0 = e.op("fma", zr, s1, ui); i0 = e.op("fma", zi, c1, i0); i0 = e.op("fma", yr, s3, i0); i0 = e.op("fma", yi, c3, i0)
+            out[k] = (r0, i0)
+            out[k + 2 * q] = (e.op("fnma2", ur, r0), e.op("fnma2", ui, i0))
+            # X[k+q] = V + sign*i*(w1 Z - w3 Z'):  A = w1 Z = (zr c1 - zi s1, zi c1 + zr s1),  B = w3 Z' likewise;  i*(A-B) = (-(Ai-Bi), Ar-Br)
+            g = float(sign)
+            r1 = e.op("fma", zi, -g * c1, vr); r1 = e.op("fma", zr, -g * s1, r1); r1 = e.op("fma", yi, g * c3, r1); r1 = e.op("fma", yr, g * s3, r1)
+            i1 = e.op("fma", zr, g * c1, vi); i1 = e.op("fma", zi, -g * s1, i1); i1 = e.op("fma", yr, -g * c3, i1); i1 = e.op("fma", yi, g * s3, i1)
+            out[k + q] = (r1, i1)
+            out[k + 3 * q] = (e.op("fnma2", vr, r1), e.op("fnma2", vi, i1))
+        return out
+
+    v = rec(list(range(32)))
+    return e, {k: v[k] for k in range(32)}
+
+
 def cpp(name: str, comment: str, e: Emitter, outs) -> str:
     rows = [f"// {comment}", f"__device__ __forceinline__ void {name}(cf (&x)[32]) {{"]
     for t, kind, a in e.lines:
@@ -148,6 +202,15 @@ def check():
         err = np.abs(got - want).max()
         assert err < 1e-12, (name, err)
         print(f"{name}: {len(e.lines)} float instructions, max |error| {err:.1e} (float64 evaluation vs numpy.fft)")
+    for sign in (-1, +1):   # the split-radix alternative: correct, and longer
+        e, outs = gen_split_radix(sign)
+        t = rng.standard_normal(32) + 1j * rng.standard_normal(32)
+        got = evaluate(e, outs, t)
+        ref = np.fft.fft(t) if sign < 0 else np.fft.ifft(t) * 32
+        err = np.abs(got - ref).max()
+        assert err < 1e-12, ("split radix", sign, err)
+        print(f"split-radix FMA network, sign {sign:+d}: {len(e.lines)} float instructions (not emitted: the radix-2 codelets above are shorter), "
+              f"max |error| {err:.1e}")
 
 
 def main():

@@ -74,6 +74,8 @@ l=json.loads(sys.stdin.read()); print({k:l[k] for k in ('value','ms_per_step','a
       timeout 400 python tools/big_survey.py 300 - 4092000 1700000 > $O/survey_4092.txt 2>&1; tail -6 $O/survey_4092.txt ;;
     survey16)
       timeout 420 python -m pytest tests/test_gpu_track_survey.py -x -q -m gpu -s -k "other_recording_rates or 16368_throughput" 2>&1 | grep -v "^$" | tail -12 ;;
+    rates)
+      for k in ${RATES:-1 2 3 4 5 6 8 10 12 16 20 48}; do timeout 200 python tools/rate_probe.py $k 32 200 2>&1 | tail -1; done ;;
     prof16)
       timeout 300 python tools/gpu_profile_probe.py --single --16368 2>&1 | tail -22 ;;
     lanes)
