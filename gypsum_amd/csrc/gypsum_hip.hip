@@ -611,11 +611,12 @@ static int launch_track_block(gyp_ctx* ctx, const TrackBlockParams& p, int mode)
 static int launch_track_verify(gyp_ctx* ctx, const TrackVerifyParams& p, hipStream_t stream) {
     const int n_units = p.n_chan * (p.trk_round ? p.sub_len : p.ms_end - p.ms_begin);
     int grid = std::max(8, std::min(n_units, ctx->n_cus * blocks_per_cu(ctx->k)) & ~7);
-    if (p.trk_round && ctx->k >= 8) {
+    if (p.trk_round) {
         // Round protocol: this launch runs beside the NEXT round's tracking launch, whose workgroups (one per channel, 97 KB of LDS)
         // fit no CU that already holds one of these (78 KB): a verify launch that fills the chip first makes the tracking launch wait
         // for it to drain, every round (0.3 us per ms-step of a 12-channel bank).  One workgroup per CU on all but the CUs the channels
         // need (workgroup b goes to XCD b % 8; inside an XCD the dispatcher fills the emptiest CU first) leaves those CUs empty.
+        // (K = 2: the same with 46 KB / 8 x 212 registers against up to eight 2-wavefront verify workgroups per CU.)
         const int per_xcd = ctx->n_cus / 8, need = (p.n_chan + 7) / 8 + 1;
         grid = 8 * std::max(4, per_xcd - need);
         grid = std::max(8, std::min(grid, n_units & ~7));
@@ -1311,7 +1312,7 @@ static int track_block_throughput(gyp_bank* bank, TrackBlockParams p, const int3
 // Sub-blocks of a speculative block: the last sub-block's verification trails the tracking, and a failed verification costs a
 // sub-block (more, shorter ones for long blocks); each round re-reads the channel state and the tables (~20 us).
 static constexpr int kMaxSub = 20;
-static int spec_sub_blocks(int n_ms) { return n_ms >= 4096 ? kMaxSub : (n_ms >= 256 ? 4 : 1); }
+static int spec_sub_blocks(int n_ms) { return n_ms >= 2048 ? std::min(kMaxSub, std::max(4, n_ms / 500)) : (n_ms >= 256 ? 4 : 1); }
 static int ensure_spec_buffers(gyp_bank* bank, int n_sub, int rounds) {
     gyp_ctx* ctx = bank->ctx;
     if (!bank->verify_stream) {
@@ -1432,7 +1433,7 @@ static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
     const int sub = (p.n_ms + n_sub - 1) / n_sub;
     const int n_sub_used = (p.n_ms + sub - 1) / sub;
     // a re-do costs its channel two rounds: room for three of them behind the last sub-block, then the transform kernel takes over
-    const int rounds = n_sub_used + 2 + (n_sub_used >= kMaxSub ? 6 : 2);
+    const int rounds = n_sub_used + 2 + (n_sub_used >= 8 ? 6 : 2);
     int rc;
     if ((rc = ensure_spec_buffers(bank, n_sub_used, rounds))) return rc;
     if ((rc = ensure_dll_buffers(bank, n_rec))) return rc;

@@ -300,11 +300,12 @@ def test_redo_rounds_hand_hopeless_channels_to_the_transform_kernel():
 
 
 def test_redo_rounds_give_up_after_eight_forced_milliseconds():
-    """A long block (20 sub-blocks, 28 rounds): a noise-only channel under kappa = 0 fills its eight forced-transform slots inside
-    the rounds and is declared dead there; the transform kernel finishes it from that sub-block's checkpoint.  Same integers as the
-    transform kernel alone, for it and for the channel with a signal beside it."""
+    """A long block (6100 ms = 12 sub-blocks, 20 rounds): a noise-only channel under kappa = 0 fails its verification in every pass;
+    it fills its eight forced-transform slots inside the rounds, is declared dead at the ninth failure, and the transform kernel
+    finishes it from that sub-block's checkpoint.  Same integers as the transform kernel alone, for it and for the channels with a
+    signal beside it."""
     fs, n = 8_184_000, 8184
-    n_ms = 4109
+    n_ms = 6109
     scene = synth.random_scene(fs, n_ms, 2, 31415, max_code_phase=2046)
     iq = synth.render(scene)
     present = {s.sat_id for s in scene.sats}
@@ -319,7 +320,7 @@ def test_redo_rounds_give_up_after_eight_forced_milliseconds():
     eng_s = _engine_with_env(fs, n, GYP_SPEC_KAPPA=0)
     rec_s, st_s, bad, stats = _bank_run_stats(eng_s, iq, inits, n, fs, n_ms)
     eng_s.close()
-    assert stats["sub_blocks"] == 20 and bad[-1] == 1 and stats["redos"] >= 8, (bad, stats)
+    assert stats["sub_blocks"] == 12 and bad[-1] == 1 and stats["redos"] >= 8, (bad, stats)
     for i in range(len(inits)):
         for f in ("code_phase", "peak_offset", "pseudosymbol", "locked", "status"):
             assert np.array_equal(rec_s[i][f], rec_t[i][f]), (i, f, bad, stats)
