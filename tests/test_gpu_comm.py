@@ -125,3 +125,22 @@ def test_wait_for_orders_two_contexts():
     b.wait_for(b)                                            # a context waiting for itself is a no-op
     a.close()
     b.close()
+
+
+def test_device_locality_and_host_binding(engine_factory):
+    """gyp_device_locality: the GPU's NUMA node and its CPUs as sysfs gives them (node -1 / empty list where the host does not say);
+    binding the calling thread there must either work or decline -- never raise -- and leaves the process able to run."""
+    import os
+    eng = engine_factory(2_046_000, 2046)
+    loc = eng.locality()
+    assert set(loc) == {"numa_node", "cpulist", "cpus"} and loc["numa_node"] >= -1
+    if loc["numa_node"] >= 0 and loc["cpulist"]:
+        assert loc["cpus"] == sorted(set(loc["cpus"])) and all(0 <= c < 8192 for c in loc["cpus"])
+    before = os.sched_getaffinity(0)
+    try:
+        bound = eng.bind_host_thread_to_gpu_node()
+        assert isinstance(bound, bool)
+        if bound:
+            assert os.sched_getaffinity(0) <= set(loc["cpus"]) | before
+    finally:
+        os.sched_setaffinity(0, before)
