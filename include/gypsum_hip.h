@@ -98,7 +98,9 @@ typedef struct gyp_params {
      * bit-identical across kappa: a fast-path millisecond feeds the loop filters the window's direct sum at the peak lag,
      * a transform-path millisecond (and the throughput kernel) the FFT's value -- the two agree to float32 rounding
      * (~1e-7 relative), and so do peak_re/peak_im/error/doppler_hz/carrier_phase downstream.  Two lags whose |c|^2 the
-     * float32 transform cannot order (within 4e-6 relative) count as agreement with the window's choice. */
+     * float32 transform cannot order (within 4e-6 relative) count as agreement with the window's choice.
+     * The value is quoted for 8184 lags (8.184 Msps): the chance that a noise lag beats a peak of kappa x energy is (lags) x exp(-kappa),
+     * so the library applies kappa + ln(N / 8184) at N samples per millisecond (18.6 at 2.046 Msps, 20.7 at 16.368); 0 stays 0. */
     double spec_confidence_kappa;      /* 20 */
     /* acquisition.py:200-219: the reference keeps a cache of integrated profiles keyed by (data, Doppler, PRN) but has its
      * lookup switched off (`if False and key in ...`, "to rule it out as a confounding factor"), so it correlates a bin
