@@ -139,6 +139,7 @@ struct gyp_ctx {
     int comm_rank = 0, comm_world = 1;
     gyp_params params;
     bool spec_redo = true;       // gyp_debug_set("spec_redo"): 0 = A/B switch back to re-running a failed speculation on the throughput kernel
+    int prof_wave = 0;           // gyp_debug_set("prof_wave"): which wavefront of workgroup 0 stamps gyp_debug_track_profile's counters
     int exact_prefetch = 0;      // gyp_debug_set("exact_prefetch"): A/B switch of dll_exact_wave_kernel's software prefetch depth
     bool no_spec = false;        // gyp_debug_set("no_spec"): A/B switch: lightly loaded banks use the throughput kernel too
     int spec_fail_at = -1;       // gyp_debug_set("spec_fail_at", ms) (test hook): channel 0's verification is made to fail at that millisecond of a block
@@ -1509,6 +1510,7 @@ int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stri
     p.inv_fs = 1.0 / (double)ctx->fs;
     p.fs = (double)ctx->fs;
     p.prof = ctx->d_prof;
+    p.prof_wave = ctx->prof_wave;
     p.codes = CodeTables{ctx->d_trans, ctx->d_ntrans, ctx->d_chipf};
     {
         const gyp_params& g = ctx->params;
@@ -1786,7 +1788,7 @@ const DebugKnob kDebugKnobs[] = {
     {"no_pipe", 0, 1, true}, {"no_shared_fwd", 0, 1, true}, {"no_acq_split", 0, 1, true}, {"no_spec", 0, 1, true},
     {"spec_debug", 0, 1, true}, {"acq_lanes", 1, gyp_ctx::kMaxAcqLanes, true}, {"track_chunk_ms", 0, 1e6, true},
     {"symbol_tau", 0, 100, false}, {"dll_prov_bias", -1e6, 1e6, false}, {"spec_fail_at", -1, 2147483647.0, true},
-    {"spec_redo", 0, 1, true}, {"exact_prefetch", 0, 1, true},
+    {"spec_redo", 0, 1, true}, {"exact_prefetch", 0, 1, true}, {"prof_wave", 0, 7, true},
 };
 }  // namespace
 static int debug_apply(gyp_ctx* ctx, const char* name, double v, bool set, double* out) {
@@ -1805,6 +1807,7 @@ static int debug_apply(gyp_ctx* ctx, const char* name, double v, bool set, doubl
     GYP_KNOB_NUM("dll_prov_bias", dll_prov_bias, double)
     GYP_KNOB_NUM("spec_fail_at", spec_fail_at, int)
     GYP_KNOB_NUM("exact_prefetch", exact_prefetch, int)
+    GYP_KNOB_NUM("prof_wave", prof_wave, int)
 #undef GYP_KNOB_BOOL
 #undef GYP_KNOB_NUM
     return GYP_E_BAD_ARG;

@@ -229,6 +229,7 @@ struct TrackBlockParams {
     double inv_fs;
     double fs;
     long long* prof;           // optional: per-phase cycle counters of workgroup 0 (debug)
+    int32_t prof_wave;         // ... as seen by this wavefront's lane 0 (gyp_debug_set "prof_wave")
     CodeTables codes;
     LoopParams lp;
     // speculative mode (MODE 2)
@@ -959,7 +960,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
         DllExact x; x.dll = st->dll_phase; x.code_phase = st->code_phase; x.repairs = 0;
         p.exact0[ch] = x;
     }
-    const bool prof = PROF && p.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+    const bool prof = PROF && p.prof != nullptr && blockIdx.x == 0 && (int)threadIdx.x == 64 * p.prof_wave;   // (lane 0 of the chosen wavefront)
     long long tp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long t_last = 0;
     // speculative mode: tp[6 + i] accumulates the cycles between stamp i-1 and stamp i of workgroup 0's thread 0
@@ -1249,8 +1250,8 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
         const LoopState ls = sm.red->loop;
         st->dll_phase = ls.dll_phase; st->n_steps = ls.n_steps; st->last_watchdog_time = ls.last_watchdog;
         st->sums = ls.sums;
-        if (prof) for (int i = 0; i < 16; ++i) p.prof[i] = tp[i];
     }
+    if (prof) for (int i = 0; i < 16; ++i) p.prof[i] = tp[i];
 }
 
 // The full-profile half of the speculative path: for every (channel, millisecond) the tracking kernel advanced on its

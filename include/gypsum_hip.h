@@ -505,6 +505,7 @@ int gyp_ingest_times(const gyp_ingest* ing, int64_t first_ms, int32_t n_ms, doub
  *   "spec_debug" 0/1 (0)        per-ms window dump for gyp_debug_spec_read
  *   "track_chunk_ms" 0 | >= 20 (500)   launch length of the throughput tracking kernel (0: whole blocks)
  *   "exact_prefetch" 0/1 (0)    dll_exact_wave_kernel with its next window software-prefetched (A/B: measured slower, profiles/r04_exact_ab.txt)
+ *   "prof_wave" 0..7 (0)        which wavefront of workgroup 0 stamps the counters of gyp_debug_track_profile
  *   "symbol_tau" 0..100 (1e-4)  |Re peak| / |peak| below which dll_scan_kernel decides the pseudosymbol in float64 (test: 10 = always)
  *   "dll_prov_bias" (0)         test hook: added to the PROVISIONAL discriminator so that the repair path runs; results must not change
  *   "spec_fail_at" >= -1 (-1)   test hook: channel 0's verification is made to fail at that millisecond of a block
