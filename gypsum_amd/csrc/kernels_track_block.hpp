@@ -3,6 +3,9 @@
 #pragma once
 #include "kernels_track_step.hpp"
 
+#ifndef GYP_EXPERIMENT_SKIP_UPDATE
+#define GYP_EXPERIMENT_SKIP_UPDATE 0   // 1 (development builds only): the throughput kernel without its Costas / lock-detector update -- how much of the kernel's time the serial update costs
+#endif
 namespace gyp {
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1204,7 +1207,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
             // millisecond (rec_flush by wavefront 1), off this path too.
             RedScratch* red = launder_lds(sm.red);
             constexpr int kW = Geom<K>::W;          // (rates whose workgroup has fewer than three wavefronts double up)
-            if (wave == 0) {
+            if (wave == 0 && !GYP_EXPERIMENT_SKIP_UPDATE) {
                 const long long u0_ = prof ? (long long)__builtin_readcyclecounter() : 0;
                 fetch_leaving(st, red, leave);
                 if (prof) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
