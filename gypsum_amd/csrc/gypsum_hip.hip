@@ -1390,8 +1390,7 @@ static int track_block_speculative_rerun(gyp_bank* bank, TrackBlockParams p) {
     if ((rc = ensure_dll_buffers(bank, n_rec))) return rc;
     HIP_TRY(ctx, hipMemsetAsync(bank->d_bad, 0, (size_t)bank->n_chan * sizeof(int32_t), ctx->stream));
     HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)bank->d_bad_from, 0x7fffffff, (size_t)bank->n_chan, ctx->stream));
-    const int32_t st0[4] = {n_sub, n_sub, 0, 0};
-    HIP_TRY(ctx, hipMemcpyAsync(bank->d_redo_stats, st0, sizeof(st0), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(set4_kernel, dim3(1), dim3(1), 0, ctx->stream, bank->d_redo_stats, n_sub, n_sub, 0, 0);
     if ((rc = spec_prepare(bank, p, n_rec))) return rc;
     TrackVerifyParams v = verify_params(bank, p);
     DllExactParams x = dll_exact_params(bank, p);
@@ -1444,8 +1443,7 @@ static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
     HIP_TRY(ctx, hipMemsetAsync(bank->d_ctl, 0, (size_t)bank->n_chan * sizeof(SpecCtl), ctx->stream));   // cursor 0, nothing forced (rb_round 0 only ever matters for R = 1, which consults nothing)
     HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)bank->d_fail, 0x7fffffff, (size_t)rounds * bank->n_chan, ctx->stream));
     HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)bank->d_trk, 0xffffffff, (size_t)rounds * bank->n_chan, ctx->stream));
-    const int32_t st0[4] = {n_sub_used, rounds, 0, 0};
-    HIP_TRY(ctx, hipMemcpyAsync(bank->d_redo_stats, st0, sizeof(st0), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(set4_kernel, dim3(1), dim3(1), 0, ctx->stream, bank->d_redo_stats, n_sub_used, rounds, 0, 0);
     if ((rc = spec_prepare(bank, p, n_rec))) return rc;
     p.ctl = bank->d_ctl; p.trk = bank->d_trk; p.fail = bank->d_fail; p.ckpt = bank->d_ckpt;
     p.n_sub = n_sub_used; p.sub_len = sub; p.exact_hist = bank->d_hist;

@@ -549,6 +549,11 @@ __global__ __launch_bounds__(256) void spec_finalize_kernel(SpecFinalizeParams p
     }
 }
 
+// {a, b, c, d} -> p[0..3] on the stream (telemetry headers: no host buffer has to outlive the call)
+__global__ void set4_kernel(int32_t* p, int32_t a, int32_t b, int32_t c, int32_t d) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
+}
+
 __global__ void bank_reset_kernel(ChanState* states, const gyp_chan_init* inits, int n_chan) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_chan) return;

@@ -69,6 +69,13 @@ l=json.loads(sys.stdin.read()); print({k:l[k] for k in ('value','ms_per_step','a
     acqtl)
       timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/acqtl -o acq -- python tools/acq_timeline.py run > $O/acqtl.log 2>&1
       python tools/acq_timeline.py show $O/acqtl > $O/acq_timeline.txt 2>&1; rm -rf $O/acqtl; tail -25 $O/acq_timeline.txt ;;
+    bigsurveys)
+      # fresh seeds through the paths r04 changed: round protocol (8.184 / 2.046 Msps), K = 16 speculative tracker, K = 10 / 12 staging
+      for spec in "500 - 8184000 2000000" "500 - 2046000 2100000" "200 - 16368000 2200000" "100 GYP_NO_SPEC 16368000 2300000" "100 - 10230000 2400000" "100 - 12276000 2500000" "200 GYP_NO_SPEC 8184000 2600000"; do
+        set -- $spec
+        timeout 420 python tools/big_survey.py $1 $2 $3 $4 2>&1 | grep -v "^$" | tail -4 >> $O/surveys.txt
+        tail -3 $O/surveys.txt | cut -c1-420
+      done ;;
     find4092)
       # the one pseudosymbol of r03's 3.6 M channel-ms at 4.092 Msps (profiles/r03_surveys.txt): which scene?
       timeout 400 python tools/big_survey.py 300 - 4092000 1700000 > $O/survey_4092.txt 2>&1; tail -6 $O/survey_4092.txt ;;
