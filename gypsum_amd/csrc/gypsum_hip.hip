@@ -1431,7 +1431,13 @@ static int track_block_speculative_rerun(gyp_bank* bank, TrackBlockParams p) {
 static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
     gyp_ctx* ctx = bank->ctx;
     const int n_sub = spec_sub_blocks(p.n_ms);
-    if (n_sub == 1 || !ctx->spec_redo) return track_block_speculative_rerun(bank, p);
+    // The rounds couple the tracking launches to the verify launches two rounds back, so the verify kernels must keep up beside the
+    // tracking -- on the CUs the channels leave free, one workgroup per CU (launch_track_verify).  That holds for a receiver's bank
+    // (12 channels: verify 0.4 ms per 500-ms round against 2 ms of tracking) and up to about two streams; beyond, the verify launches
+    // become the bottleneck (tools/mid_bank_probe.sh: 48 channels 5.5 against 4.7 ms per 1000 ms, 252 channels 109 against 16), and
+    // those banks keep r03's flow, in which nothing waits for the verification until the end of the block.
+    constexpr int kMaxRoundProtocolChannels = 24;
+    if (n_sub == 1 || !ctx->spec_redo || bank->n_chan > kMaxRoundProtocolChannels) return track_block_speculative_rerun(bank, p);
     const size_t n_rec = (size_t)bank->n_chan * p.n_ms;
     const int sub = (p.n_ms + n_sub - 1) / n_sub;
     const int n_sub_used = (p.n_ms + sub - 1) / sub;
