@@ -169,9 +169,9 @@ class GpuTelemetry:
     sample per second; the driver's fresh box has measured ~6 % under the builder's lease at the same code -- this says whether
     the clock explains it).  Reporting only: any failure ends up in the record as an error string."""
 
-    def __init__(self, device: int) -> None:
+    def __init__(self, device: int, enabled: bool = True) -> None:
         import shutil
-        self.device, self.samples, self.err, self._stop, self._thr = device, [], None, False, None
+        self.device, self.samples, self.err, self._stop, self._thr, self.enabled = device, [], None, False, None, enabled
         self.exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
 
     def _poll(self) -> None:
@@ -202,8 +202,9 @@ class GpuTelemetry:
 
     def __enter__(self):
         import threading
-        self._thr = threading.Thread(target=self._poll, daemon=True)
-        self._thr.start()
+        if self.enabled:
+            self._thr = threading.Thread(target=self._poll, daemon=True)
+            self._thr.start()
         return self
 
     def __exit__(self, *a) -> None:
@@ -456,7 +457,7 @@ def run_cfg3(eng, comm, args, rng, eng_scan=None) -> dict:
         eng.wait_for(eng_scan)
         comm.allgather(acq_send, acq_recv, acq_bytes)           # behind both, on the engine's stream, no host sync
 
-    with GpuTelemetry(eng.device) as tele:
+    with GpuTelemetry(eng.device, enabled=comm.rank == 0) as tele:      # (rank 0 only: eight ranks need not poll rocm-smi eight times)
         elapsed = timed_steps(eng, comm, step, args.warmup, args.steps, extra_sync=(eng_scan,) if eng_scan is not None else ())
     # the all-gather alone (HIP events on the library's stream around gyp_allgather_dev), outside the timed region
     ag_ms = []
