@@ -265,6 +265,43 @@ def test_a_failed_verification_costs_its_sub_block_only(redo):
     np.testing.assert_allclose(st_s["doppler_hz"], st_t["doppler_hz"], rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("fs", [2_046_000, 16_368_000])
+def test_planted_failure_at_the_other_speculative_rates_and_across_calls(fs):
+    """The round protocol at the 2x and 16x recording rates, and its hand-over from call to call: block A (400 ms, a verification
+    failure planted at ms 250 -> sub-block 2 re-done) followed by block B (300 ms) on the same bank.  Every integer of both blocks and
+    the final state equal the transform kernel's over the same two calls."""
+    n = fs // 1000
+    n_ms = 709
+    iq, inits = _scene_and_inits(fs, n, n_ms, 3, 6100 + n)
+    t0 = [orc.chunk_times(ms * n, n, fs)[0] for ms in range(9, n_ms)]
+
+    def two_calls(eng):
+        bank = eng.create_bank(inits)
+        a = bank.track_block(iq[9 * n:409 * n], 1, 400, t0[:400])
+        stats = _redo_stats(eng, bank.handle)
+        b = bank.track_block(iq[409 * n:709 * n], 1, 300, t0[400:])
+        st = bank.state()
+        bank.close()
+        return np.concatenate([a, b], axis=1), st, stats
+
+    eng_t = _engine_with_env(fs, n, GYP_NO_SPEC=1)
+    rec_t, st_t, _ = two_calls(eng_t)
+    eng_t.close()
+    eng_s = _engine_with_env(fs, n, GYP_SPEC_FAIL_AT=250)
+    rec_s, st_s, stats = two_calls(eng_s)
+    eng_s.close()
+    assert stats["redos"] == 1 and stats["to_transform_kernel"] == 0, stats
+    fast = (rec_s["path_info"] & 3) == 1
+    assert not fast[0, 250] and fast.mean() > 0.6
+    for f in ("code_phase", "peak_offset", "pseudosymbol", "locked", "status"):
+        assert np.array_equal(rec_s[f], rec_t[f]), f
+    np.testing.assert_allclose(rec_s["discriminator"], rec_t["discriminator"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(rec_s["strength"], rec_t["strength"], rtol=1e-4)
+    for key in ("code_phase", "lost"):
+        assert np.array_equal(st_s[key], st_t[key]), key
+    np.testing.assert_allclose(st_s["doppler_hz"], st_t["doppler_hz"], rtol=0, atol=1e-5)
+
+
 def test_redo_rounds_hand_hopeless_channels_to_the_transform_kernel():
     """The round protocol under fire: kappa = 0 trusts every interior window maximum, so noise-only channels fail verification
     almost everywhere.  They use up their forced-transform slots and are finished by the transform kernel from their last good
