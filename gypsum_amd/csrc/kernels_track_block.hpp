@@ -862,6 +862,23 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
     constexpr int kThreadsHere = SPEC ? kSpecThreads : Geom<K>::kThreads;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int N = K * kChips;
+    if constexpr (SPEC) {
+        // A round in which this channel has nothing to track and nothing to take back (the idle rounds behind the last
+        // sub-block) ends here, before the 24 KB of tables are copied into LDS: same decision as spec_ctl_begin's.
+        if (p.ctl && (int)blockIdx.x < p.n_chan) {
+            const int c0 = xcd_contiguous(blockIdx.x, p.n_chan), R = p.round;
+            const SpecCtl* c = p.ctl + c0;
+            bool idle = c->dead || c->cursor >= p.n_sub;
+            if (idle && !c->dead && R >= 2 && c->rb_round != R - 1) {
+                const int s = p.trk[(size_t)(R - 2) * p.n_chan + c0];
+                idle = s < 0 || p.fail[(size_t)(R - 2) * p.n_chan + c0] == kNoFail;
+            }
+            if (idle) {
+                if (threadIdx.x == 0) p.trk[(size_t)R * p.n_chan + c0] = -1;
+                return;
+            }
+        }
+    }
     Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
     SpecLds sl{};
     if (LAT && kSpecTw2048InLds<K>) {
@@ -1292,6 +1309,11 @@ template <int K>
 __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void track_verify_kernel(TrackVerifyParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int N = K * kChips;
+    if (p.trk_round) {   // a round in which no channel tracked anything: nothing to verify (uniform over the grid)
+        bool any = false;
+        for (int c = 0; c < p.n_chan; ++c) any |= p.trk_round[c] >= 0;
+        if (!any) return;
+    }
     const Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
     __syncthreads();
     const int n_units = p.n_chan * (p.trk_round ? p.sub_len : p.ms_end - p.ms_begin);
