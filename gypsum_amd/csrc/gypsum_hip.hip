@@ -1379,6 +1379,18 @@ static int spec_prepare(gyp_bank* bank, TrackBlockParams& p, size_t n_rec) {
     return GYP_OK;
 }
 
+// An error between the first launch on the verify stream and the join leaves work enqueued there that reads the caller's IQ and writes
+// the bank's buffers: it is waited out before the error reaches the caller (who may free either).
+struct VerifyStreamGuard {
+    gyp_bank* bank;
+    bool armed = true;
+    ~VerifyStreamGuard() {
+        if (!armed) return;
+        (void)hipStreamSynchronize(bank->verify_stream);
+        (void)hipStreamSynchronize(bank->ctx->stream);
+    }
+};
+
 // r03 form (blocks of one sub-block, or gyp_debug_set "spec_redo" 0): every sub-block's verification trails its tracking on the
 // verify stream; channels that failed one are re-run from that sub-block's checkpoint by the TRANSFORM kernel afterwards.
 static int track_block_speculative_rerun(gyp_bank* bank, TrackBlockParams p) {
@@ -1392,6 +1404,7 @@ static int track_block_speculative_rerun(gyp_bank* bank, TrackBlockParams p) {
     HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)bank->d_bad_from, 0x7fffffff, (size_t)bank->n_chan, ctx->stream));
     hipLaunchKernelGGL(set4_kernel, dim3(1), dim3(1), 0, ctx->stream, bank->d_redo_stats, n_sub, n_sub, 0, 0);
     if ((rc = spec_prepare(bank, p, n_rec))) return rc;
+    VerifyStreamGuard join_on_error{bank};
     TrackVerifyParams v = verify_params(bank, p);
     DllExactParams x = dll_exact_params(bank, p);
     DllScanParams d = dll_scan_params(bank, p);
@@ -1418,6 +1431,7 @@ static int track_block_speculative_rerun(gyp_bank* bank, TrackBlockParams p) {
     }
     HIP_TRY(ctx, hipEventRecord(bank->ev_verify, bank->verify_stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, bank->ev_verify, 0));
+    join_on_error.armed = false;
     // channels whose window maximum was not the global one somewhere (any count is handled): again from the checkpoint of the
     // sub-block in which that happened, through the transform kernel, their code loop re-integrated behind it
     p.dbg = nullptr;
@@ -1451,6 +1465,7 @@ static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
     HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)bank->d_trk, 0xffffffff, (size_t)rounds * bank->n_chan, ctx->stream));
     hipLaunchKernelGGL(set4_kernel, dim3(1), dim3(1), 0, ctx->stream, bank->d_redo_stats, n_sub_used, rounds, 0, 0);
     if ((rc = spec_prepare(bank, p, n_rec))) return rc;
+    VerifyStreamGuard join_on_error{bank};
     p.ctl = bank->d_ctl; p.trk = bank->d_trk; p.fail = bank->d_fail; p.ckpt = bank->d_ckpt;
     p.n_sub = n_sub_used; p.sub_len = sub; p.exact_hist = bank->d_hist;
     p.ms_begin = 0; p.ms_end = p.n_ms;
@@ -1478,6 +1493,7 @@ static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
     }
     HIP_TRY(ctx, hipEventRecord(bank->ev_verify, bank->verify_stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, bank->ev_verify, 0));
+    join_on_error.armed = false;
     SpecFinalizeParams f;
     f.ctl = bank->d_ctl; f.trk = bank->d_trk; f.fail = bank->d_fail; f.states = bank->d_states; f.ckpt = bank->d_ckpt; f.hist = bank->d_hist;
     f.exact = bank->d_dllx; f.bad = bank->d_bad; f.bad_from = bank->d_bad_from; f.stats = bank->d_redo_stats;
