@@ -610,7 +610,7 @@ static int launch_track_block(gyp_ctx* ctx, const TrackBlockParams& p, int mode)
     return (p.prof || p.prof_tail) ? launch_track_block_t<true>(ctx, p, mode) : launch_track_block_t<false>(ctx, p, mode);
 }
 static int launch_track_verify(gyp_ctx* ctx, const TrackVerifyParams& p, hipStream_t stream) {
-    const int n_units = p.n_chan * (p.trk_round ? p.sub_len : p.ms_end - p.ms_begin);
+    const int n_units = p.n_chan * (p.trk_round ? p.sub.longest : p.ms_end - p.ms_begin);
     int grid = std::max(8, std::min(n_units, ctx->n_cus * blocks_per_cu(ctx->k)) & ~7);
     if (p.trk_round) {
         // Round protocol: this launch runs beside the NEXT round's tracking launch, whose workgroups (one per channel, 97 KB of LDS)
@@ -1249,7 +1249,7 @@ static DllExactParams dll_exact_params(gyp_bank* bank, const TrackBlockParams& p
     DllExactParams x;
     x.iq = p.iq; x.stream_stride = p.stream_stride; x.n_ms = p.n_ms; x.ms_begin = 0; x.ms_end = p.n_ms; x.start_time = p.start_time;
     x.states = bank->d_states; x.n_chan = bank->n_chan; x.spec = bank->d_spec; x.disc_out = bank->d_disc; x.chipf = ctx->d_chipf;
-    x.inv_fs = p.inv_fs; x.only_if = nullptr; x.from_sub = nullptr; x.sub_len = 0; x.trk_round = nullptr;
+    x.inv_fs = p.inv_fs; x.only_if = nullptr; x.from_sub = nullptr; x.sub = SubLayout::none(); x.trk_round = nullptr;
     return x;
 }
 static DllScanParams dll_scan_params(gyp_bank* bank, const TrackBlockParams& p) {
@@ -1259,7 +1259,7 @@ static DllScanParams dll_scan_params(gyp_bank* bank, const TrackBlockParams& p) 
     d.states = bank->d_states; d.ckpt = nullptr; d.n_chan = bank->n_chan; d.spec = bank->d_spec; d.disc = bank->d_disc;
     d.rec_out = p.rec_out; d.exact = bank->d_dllx; d.bad = nullptr; d.only_bad = 0; d.chipf = ctx->d_chipf;
     d.inv_fs = p.inv_fs; d.dll_gain = p.lp.dll_gain; d.dll_modulus = p.lp.dll_modulus; d.n_samples = p.lp.n_samples;
-    d.first = 1; d.final = 1; d.from_sub = nullptr; d.sub_len = 0; d.hist_out = nullptr;
+    d.first = 1; d.final = 1; d.from_sub = nullptr; d.sub = SubLayout::none(); d.hist_out = nullptr;
     d.prof_delta = p.prof_tail ? bank->d_prof_delta : nullptr; d.prof_from = p.prof_from; d.prof_depth = p.prof_depth;
     d.symbol_tau = ctx->symbol_tau;
     d.trk_round = nullptr; d.hist = nullptr;
@@ -1269,14 +1269,14 @@ static DllScanParams dll_scan_params(gyp_bank* bank, const TrackBlockParams& p) 
 // The throughput tracking kernel with its code loop re-integrated exactly behind it (same stream).  only_if / restore_from: the
 // re-run of channels whose speculation failed verification.
 static int track_block_throughput(gyp_bank* bank, TrackBlockParams p, const int32_t* only_if, const ChanState* restore_from,
-                                  const int32_t* from_sub = nullptr, const DllExact* exact_hist = nullptr, int sub_len = 0) {
+                                  const int32_t* from_sub = nullptr, const DllExact* exact_hist = nullptr, SubLayout sub = SubLayout::none()) {
     gyp_ctx* ctx = bank->ctx;
     int rc;
     if ((rc = ensure_dll_buffers(bank, (size_t)bank->n_chan * p.n_ms))) return rc;
     p.ms_begin = 0; p.ms_end = p.n_ms;
     p.spec_out = bank->d_spec; p.exact0 = bank->d_dllx; p.dbg = nullptr;
     p.only_if = only_if; p.restore_from = restore_from;
-    p.from_sub = from_sub; p.exact_hist = exact_hist; p.sub_len = sub_len;
+    p.from_sub = from_sub; p.exact_hist = exact_hist; p.sub = sub;
     const bool timed = ctx->time_track && !only_if;
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_track[0], ctx->stream));
     // The channels of a stream are independent workgroups that read the same samples; nothing keeps them within an L2's worth
@@ -1295,11 +1295,11 @@ static int track_block_throughput(gyp_bank* bank, TrackBlockParams p, const int3
     }
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_track[1], ctx->stream));
     DllExactParams x = dll_exact_params(bank, p);
-    x.only_if = only_if; x.from_sub = from_sub; x.sub_len = sub_len;
+    x.only_if = only_if; x.from_sub = from_sub; x.sub = sub;
     if ((rc = launch_dll_exact(ctx, x, ctx->stream))) return rc;
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_track[2], ctx->stream));
     DllScanParams d = dll_scan_params(bank, p);
-    d.bad = only_if; d.only_bad = only_if ? 1 : 0; d.from_sub = from_sub; d.sub_len = sub_len;
+    d.bad = only_if; d.only_bad = only_if ? 1 : 0; d.from_sub = from_sub; d.sub = sub;
     if ((rc = launch_dll_scan(ctx, d, ctx->stream))) return rc;
     if (timed) { HIP_TRY(ctx, hipEventRecord(ctx->ev_track[3], ctx->stream)); ctx->track_timed = true; }
     return GYP_OK;
@@ -1314,6 +1314,33 @@ static int track_block_throughput(gyp_bank* bank, TrackBlockParams p, const int3
 // sub-block (more, shorter ones for long blocks); each round re-reads the channel state and the tables (~20 us).
 static constexpr int kMaxSub = 20;
 static int spec_sub_blocks(int n_ms) { return n_ms >= 2048 ? std::min(kMaxSub, std::max(4, n_ms / 500)) : (n_ms >= 256 ? 4 : 1); }
+// ... and their lengths: equal ones, except that a block of sub-blocks of >= 160 ms ends with three shrinking ones (0.56, 0.34 and
+// 0.20 of the usual length) in place of its last one (SubLayout: only the last sub-block's verification is not hidden behind tracking;
+// each piece is ~0.6 of the one before because round R waits for the verification of round R - 2, which takes about half as long
+// as the tracking of the same milliseconds at 16.368 Msps and a third at 8.184).
+static SubLayout spec_layout(int n_ms, int n_sub) {
+    SubLayout l = SubLayout::none();
+    const int len = (n_ms + n_sub - 1) / n_sub;
+    int at = 0;
+    auto push = [&](int piece) {
+        if (piece <= 0 || at >= n_ms || l.n >= kMaxSubBlocks) return;
+        piece = std::min(piece, n_ms - at);
+        l.start[l.n++] = at;
+        l.longest = std::max(l.longest, piece);
+        at += piece;
+    };
+    if (n_sub > 1 && len >= 160) {
+        const int t1 = (56 * len + 99) / 100, t2 = (34 * len + 99) / 100, t3 = std::max(32, len / 5);
+        const int body = n_ms - (t1 + t2 + t3), piece = (body + n_sub - 2) / (n_sub - 1);
+        for (int j = 0; j < n_sub - 1; ++j) push(piece);
+        push(t1); push(t2);
+        push(n_ms - at);
+    } else {
+        for (int j = 0; j < n_sub; ++j) push(len);
+    }
+    for (int i = l.n; i <= kMaxSubBlocks; ++i) l.start[i] = n_ms;
+    return l;
+}
 static int ensure_spec_buffers(gyp_bank* bank, int n_sub, int rounds) {
     gyp_ctx* ctx = bank->ctx;
     if (!bank->verify_stream) {
@@ -1356,14 +1383,14 @@ static TrackVerifyParams verify_params(gyp_bank* bank, const TrackBlockParams& p
     v.states = bank->d_states; v.n_chan = bank->n_chan; v.spec = bank->d_spec; v.rec_out = p.rec_out; v.bad = bank->d_bad;
     v.bad_from = bank->d_bad_from; v.sub_index = 0; v.force_fail_ms = ctx->spec_fail_at;
     v.replica_table = ctx->d_replicas; v.tw_tables = ctx->d_tw; v.inv_fs = p.inv_fs; v.tie_tol = 4e-6f;
-    v.trk_round = nullptr; v.fail_round = nullptr; v.sub_len = 0;
+    v.trk_round = nullptr; v.fail_round = nullptr; v.sub = SubLayout::none();
     return v;
 }
 static int spec_prepare(gyp_bank* bank, TrackBlockParams& p, size_t n_rec) {
     gyp_ctx* ctx = bank->ctx;
     p.spec_out = bank->d_spec;
     p.exact0 = nullptr;
-    p.from_sub = nullptr; p.exact_hist = nullptr; p.sub_len = 0;
+    p.from_sub = nullptr; p.exact_hist = nullptr; p.sub = SubLayout::none();
     // gyp_params::spec_confidence_kappa is quoted for 8184 lags: the chance that some noise lag beats a peak of kappa x the sample
     // energy is (number of lags) x exp(-kappa), so a rate with fewer lags reaches the same risk at a lower threshold (2.046 Msps:
     // 20 -> 18.6, which moves ~5 % of its milliseconds from the in-kernel transform path to the fast path; 16.368 Msps: 20.7)
@@ -1397,7 +1424,8 @@ static int track_block_speculative_rerun(gyp_bank* bank, TrackBlockParams p) {
     gyp_ctx* ctx = bank->ctx;
     const size_t n_rec = (size_t)bank->n_chan * p.n_ms;
     int rc;
-    const int n_sub = spec_sub_blocks(p.n_ms);
+    const SubLayout lay = spec_layout(p.n_ms, spec_sub_blocks(p.n_ms));
+    const int n_sub = lay.n;
     if ((rc = ensure_spec_buffers(bank, n_sub, 1))) return rc;
     if ((rc = ensure_dll_buffers(bank, n_rec))) return rc;
     HIP_TRY(ctx, hipMemsetAsync(bank->d_bad, 0, (size_t)bank->n_chan * sizeof(int32_t), ctx->stream));
@@ -1409,13 +1437,12 @@ static int track_block_speculative_rerun(gyp_bank* bank, TrackBlockParams p) {
     DllExactParams x = dll_exact_params(bank, p);
     DllScanParams d = dll_scan_params(bank, p);
     d.ckpt = bank->d_ckpt; d.bad = bank->d_bad; d.only_bad = 0;
-    const int sub = (p.n_ms + n_sub - 1) / n_sub;
-    int j = 0;
-    for (int b0 = 0; b0 < p.n_ms; b0 += sub, ++j) {
+    for (int j = 0; j < n_sub; ++j) {
+        const int b0 = lay.begin(j);
         HIP_TRY(ctx, hipMemcpyAsync(bank->d_ckpt + (size_t)j * bank->n_chan, bank->d_states, (size_t)bank->n_chan * sizeof(ChanState),
                                     hipMemcpyDeviceToDevice, ctx->stream));
         p.ms_begin = b0;
-        p.ms_end = std::min(p.n_ms, b0 + sub);
+        p.ms_end = lay.end(j, p.n_ms);
         if ((rc = launch_track_block(ctx, p, 2))) return rc;
         HIP_TRY(ctx, hipEventRecord(bank->ev_spec, ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(bank->verify_stream, bank->ev_spec, 0));
@@ -1435,7 +1462,7 @@ static int track_block_speculative_rerun(gyp_bank* bank, TrackBlockParams p) {
     // channels whose window maximum was not the global one somewhere (any count is handled): again from the checkpoint of the
     // sub-block in which that happened, through the transform kernel, their code loop re-integrated behind it
     p.dbg = nullptr;
-    return track_block_throughput(bank, p, bank->d_bad, bank->d_ckpt, bank->d_bad_from, bank->d_hist, sub);
+    return track_block_throughput(bank, p, bank->d_bad, bank->d_ckpt, bank->d_bad_from, bank->d_hist, lay);
 }
 
 // Speculative block tracking (8.184 / 2.046 Msps, at most one channel per CU) under the round protocol (SpecCtl,
@@ -1444,17 +1471,16 @@ static int track_block_speculative_rerun(gyp_bank* bank, TrackBlockParams p) {
 // synchronises with the host.
 static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
     gyp_ctx* ctx = bank->ctx;
-    const int n_sub = spec_sub_blocks(p.n_ms);
+    const SubLayout lay = spec_layout(p.n_ms, spec_sub_blocks(p.n_ms));
+    const int n_sub_used = lay.n;
     // The rounds couple the tracking launches to the verify launches two rounds back, so the verify kernels must keep up beside the
     // tracking -- on the CUs the channels leave free, one workgroup per CU (launch_track_verify).  That holds for a receiver's bank
     // (12 channels: verify 0.4 ms per 500-ms round against 2 ms of tracking) and up to about two streams; beyond, the verify launches
     // become the bottleneck (tools/mid_bank_probe.sh: 48 channels 5.5 against 4.7 ms per 1000 ms, 252 channels 109 against 16), and
     // those banks keep r03's flow, in which nothing waits for the verification until the end of the block.
     constexpr int kMaxRoundProtocolChannels = 24;
-    if (n_sub == 1 || !ctx->spec_redo || bank->n_chan > kMaxRoundProtocolChannels) return track_block_speculative_rerun(bank, p);
+    if (n_sub_used == 1 || !ctx->spec_redo || bank->n_chan > kMaxRoundProtocolChannels) return track_block_speculative_rerun(bank, p);
     const size_t n_rec = (size_t)bank->n_chan * p.n_ms;
-    const int sub = (p.n_ms + n_sub - 1) / n_sub;
-    const int n_sub_used = (p.n_ms + sub - 1) / sub;
     // a re-do costs its channel two rounds: room for three of them behind the last sub-block, then the transform kernel takes over
     const int rounds = n_sub_used + 2 + (n_sub_used >= 8 ? 6 : 2);
     int rc;
@@ -1467,15 +1493,15 @@ static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
     if ((rc = spec_prepare(bank, p, n_rec))) return rc;
     VerifyStreamGuard join_on_error{bank};
     p.ctl = bank->d_ctl; p.trk = bank->d_trk; p.fail = bank->d_fail; p.ckpt = bank->d_ckpt;
-    p.n_sub = n_sub_used; p.sub_len = sub; p.exact_hist = bank->d_hist;
+    p.n_sub = n_sub_used; p.sub = lay; p.exact_hist = bank->d_hist;
     p.ms_begin = 0; p.ms_end = p.n_ms;
     TrackVerifyParams v = verify_params(bank, p);
-    v.bad = nullptr; v.bad_from = nullptr; v.sub_len = sub;
+    v.bad = nullptr; v.bad_from = nullptr; v.sub = lay;
     DllExactParams x = dll_exact_params(bank, p);
-    x.sub_len = sub;
+    x.sub = lay;
     DllScanParams d = dll_scan_params(bank, p);
     d.ckpt = bank->d_ckpt; d.bad = nullptr; d.only_bad = 0; d.first = 0; d.final = 0; d.hist_out = nullptr;
-    d.sub_len = sub; d.hist = bank->d_hist;
+    d.sub = lay; d.hist = bank->d_hist;
     for (int R = 0; R < rounds; ++R) {
         if (R >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, bank->ev_vring[(R - 2) % 3], 0));   // round R - 2's reports are in
         p.round = R;
@@ -1503,7 +1529,7 @@ static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
     // channels the rounds did not finish (out of forced-transform slots or of rounds): the transform kernel, from their last good checkpoint
     p.dbg = nullptr;
     p.ctl = nullptr; p.trk = nullptr; p.fail = nullptr; p.ckpt = nullptr; p.n_sub = 0; p.round = 0;
-    return track_block_throughput(bank, p, bank->d_bad, bank->d_ckpt, bank->d_bad_from, bank->d_hist, sub);
+    return track_block_throughput(bank, p, bank->d_bad, bank->d_ckpt, bank->d_bad_from, bank->d_hist, lay);
 }
 
 int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stride_samples, int32_t n_ms,
@@ -1548,7 +1574,7 @@ int gyp_track_block_dev(gyp_bank* bank, const float* iq_dev, int64_t stream_stri
     p.prov_bias = ctx->dll_prov_bias;
     p.only_if = nullptr;
     p.restore_from = nullptr;
-    p.from_sub = nullptr; p.exact_hist = nullptr; p.sub_len = 0;
+    p.from_sub = nullptr; p.exact_hist = nullptr; p.sub = SubLayout::none();
     p.dbg = nullptr;
     p.prof_tail = nullptr; p.prof_from = 0; p.prof_depth = 0;
     p.ctl = nullptr; p.trk = nullptr; p.fail = nullptr; p.ckpt = nullptr; p.round = 0; p.n_sub = 0;

@@ -53,6 +53,38 @@ template <int K>
 constexpr int lds_bytes() { return tables_bytes<K>() + lds_rows<K>() * kXchWaveBytes + kRedBytes + halo_bytes<K>(); }
 static_assert(lds_bytes<16>() <= 160 * 1024, "K = 16 rows resident");
 
+// Sub-blocks of a speculative block (SpecCtl, kernels_track_block.hpp): sub-block s is [start[s], start[s + 1]).  The verification
+// of a sub-block runs beside the tracking of the next one, so only the LAST one's trails the block with nothing to hide it -- 1.8 ms
+// of a 10-s block at 16.368 Msps when that sub-block is 500 ms long (tools/spec_timeline.sh), 3 % of the block.  The host therefore
+// ends a block with a few shrinking sub-blocks (spec_layout in gypsum_hip.hip; each at least ~0.6 of the one before, so that round
+// R - 2's verification is still done when round R is launched).
+constexpr int kMaxSubBlocks = 32;
+struct SubLayout {
+    int32_t n;                          // sub-blocks in use (0: no layout)
+    int32_t longest;                    // the longest of them
+    int32_t start[kMaxSubBlocks + 1];   // start[n] = the block's length
+    __host__ __device__ int begin(int s) const { return start[s < n ? s : n]; }
+    __host__ __device__ int end(int s, int n_ms) const { const int e = start[s + 1 < n ? s + 1 : n]; return e < n_ms ? e : n_ms; }
+    __host__ __device__ int sub_of(int ms) const {   // the sub-block millisecond ms belongs to (the last one beyond the block)
+        int s = 0;
+        while (s + 1 < n && ms >= start[s + 1]) ++s;
+        return s;
+    }
+    static SubLayout none() { SubLayout l; l.n = 0; l.longest = 0; for (int i = 0; i <= kMaxSubBlocks; ++i) l.start[i] = 0; return l; }
+};
+
+// The longest sub-block any channel tracked in this round (0: none did): the verify / exact-sums kernels spread
+// n_chan x round_length units over their grid -- by the layout's longest sub-block, the units of a short one would all land in the
+// first XCDs' slices (xcd_contiguous).  At most 24 channels run the round protocol: every thread reads the same few words.
+__device__ __forceinline__ int round_length(const int32_t* __restrict__ trk_round, int n_chan, const SubLayout& sub, int n_ms) {
+    int len = 0;
+    for (int c = 0; c < n_chan; ++c) {
+        const int s = trk_round[c];
+        if (s >= 0) len = max(len, sub.end(s, n_ms) - sub.begin(s));
+    }
+    return len;
+}
+
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory queue (s_waitcnt
 // vmcnt(0)), which in a latency-bound loop means waiting for prefetches and record stores nobody reads here.
 __device__ __forceinline__ void lds_barrier() {

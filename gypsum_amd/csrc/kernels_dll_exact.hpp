@@ -30,8 +30,8 @@ struct DllExactParams {
     const float* chipf;        // CodeTables::chipf
     double inv_fs;
     const int32_t* only_if;    // optional: only channels with only_if[ch] != 0 (the re-run of failed speculations) ...
-    const int32_t* from_sub;   // ... and of those only the milliseconds from sub-block from_sub[ch] on (sub_len milliseconds each)
-    int32_t sub_len;
+    const int32_t* from_sub;   // ... and of those only the milliseconds from sub-block from_sub[ch] on (SubLayout)
+    SubLayout sub;
     const int32_t* trk_round;  // round protocol (SpecCtl): channel ch's milliseconds are sub-block trk_round[ch] (-1: none); null: [ms_begin, ms_end)
 };
 
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, MINW) void dll_exact_wave_kernel(DllExactParam
     constexpr int N = K * kChips;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int n_units = p.n_chan * (p.trk_round ? p.sub_len : p.ms_end - p.ms_begin);
+    const int n_units = p.n_chan * (p.trk_round ? round_length(p.trk_round, p.n_chan, p.sub, p.n_ms) : p.ms_end - p.ms_begin);
     const int n_groups = (n_units + 3) >> 2;
     for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
         // four consecutive units per workgroup, consecutive groups inside an XCD's slice: the channels of a stream-ms (shared IQ) meet in one L2
@@ -169,11 +169,12 @@ __global__ __launch_bounds__(256, MINW) void dll_exact_wave_kernel(DllExactParam
         const int ch = u % p.n_chan;
         if (p.trk_round) {                                        // wave-uniform
             const int sub = p.trk_round[ch];
-            ms = sub * p.sub_len + u / p.n_chan;
-            if (sub < 0 || ms >= p.n_ms) continue;
+            if (sub < 0) continue;
+            ms = p.sub.begin(sub) + u / p.n_chan;
+            if (ms >= p.sub.end(sub, p.n_ms)) continue;
         }
         if (p.only_if && !p.only_if[ch]) continue;                // wave-uniform
-        if (p.from_sub && ms < p.from_sub[ch] * p.sub_len) continue;
+        if (p.from_sub && ms < p.sub.begin(p.from_sub[ch])) continue;
         const int64_t at = (int64_t)ch * p.n_ms + ms;
         const SpecIn in = p.spec[at];
         if (in.key == kSpecKeyLost) continue;                     // wave-uniform
@@ -225,18 +226,19 @@ __global__ __launch_bounds__(256) void dll_exact_block_kernel(DllExactParams p) 
     constexpr int N = K * kChips;
     __shared__ double part[4][6];
     const int tid = threadIdx.x;
-    const int n_units = p.n_chan * (p.trk_round ? p.sub_len : p.ms_end - p.ms_begin);
+    const int n_units = p.n_chan * (p.trk_round ? round_length(p.trk_round, p.n_chan, p.sub, p.n_ms) : p.ms_end - p.ms_begin);
     for (int v = blockIdx.x; v < n_units; v += gridDim.x) {
         const int u = (n_units & 7) ? v : xcd_contiguous(v, n_units);
         int ms = p.ms_begin + u / p.n_chan;
         const int ch = u % p.n_chan;
         if (p.trk_round) {                                        // uniform
             const int sub = p.trk_round[ch];
-            ms = sub * p.sub_len + u / p.n_chan;
-            if (sub < 0 || ms >= p.n_ms) continue;
+            if (sub < 0) continue;
+            ms = p.sub.begin(sub) + u / p.n_chan;
+            if (ms >= p.sub.end(sub, p.n_ms)) continue;
         }
         if (p.only_if && !p.only_if[ch]) continue;                // uniform
-        if (p.from_sub && ms < p.from_sub[ch] * p.sub_len) continue;
+        if (p.from_sub && ms < p.sub.begin(p.from_sub[ch])) continue;
         const int64_t at = (int64_t)ch * p.n_ms + ms;
         const SpecIn in = p.spec[at];
         if (in.key == kSpecKeyLost) continue;                     // uniform
@@ -277,8 +279,8 @@ struct DllScanParams {
     DllExact* exact;
     const int32_t* bad;        // optional per-channel flags of failed speculations ...
     int32_t only_bad;          // ... 0: flagged channels are left alone (the re-run gives them everything); 1: ONLY flagged ones (after it)
-    const int32_t* from_sub;   // only_bad: the re-run started at sub-block from_sub[ch] (sub_len milliseconds each)
-    int32_t sub_len;
+    const int32_t* from_sub;   // only_bad: the re-run started at sub-block from_sub[ch] (SubLayout)
+    SubLayout sub;
     DllExact* hist_out;        // optional: the loop's state at the end of this launch's range is also left here (the next sub-block's checkpoint)
     const float* chipf;
     double inv_fs, dll_gain, dll_modulus, n_samples;
@@ -324,8 +326,8 @@ __global__ __launch_bounds__(kScanThreads) void dll_scan_kernel(DllScanParams p)
     if (p.trk_round) {   // uniform
         sub_here = p.trk_round[ch];
         if (sub_here < 0) return;
-        range_lo = sub_here * p.sub_len;
-        range_hi = min(p.n_ms, range_lo + p.sub_len);
+        range_lo = p.sub.begin(sub_here);
+        range_hi = p.sub.end(sub_here, p.n_ms);
     }
     if (tid == 0) {
         if (p.trk_round) {
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(kScanThreads) void dll_scan_kernel(DllScanParams p)
     const float* chipf = p.chipf + (st->sat_id - 1) * 2048;
     const cf* stream = p.iq + (int64_t)st->stream * p.stream_stride;
     const int64_t row = (int64_t)ch * p.n_ms;
-    const int ms_first = (p.only_bad && p.from_sub) ? max(p.ms_begin, min(p.from_sub[ch], (p.n_ms - 1) / max(p.sub_len, 1)) * p.sub_len) : range_lo;
+    const int ms_first = (p.only_bad && p.from_sub) ? max(p.ms_begin, p.sub.begin(min(p.from_sub[ch], p.sub.sub_of(p.n_ms - 1)))) : range_lo;
     for (int c0 = ms_first; c0 < range_hi; c0 += kScanChunk) {
         const int len = min(kScanChunk, range_hi - c0);
         for (int i = tid; i < len; i += kScanThreads) {

@@ -196,7 +196,7 @@ struct DllExact {
 };
 
 // The speculative tracker's round protocol (gyp_track_block_dev on lightly loaded banks, blocks of more than one sub-block).
-// A block is cut into n_sub sub-blocks of sub_len milliseconds.  The host enqueues T = n_sub + a few rounds; in round R the
+// A block is cut into n_sub sub-blocks (SubLayout: full ones, then short ones at the end of the block).  The host enqueues T = n_sub + a few rounds; in round R the
 // tracking kernel (main stream) advances every channel through ITS next sub-block, and the verify / exact-sums / scan kernels
 // (verify stream) check that sub-block while round R + 1 is being tracked.  Launch R of the tracking kernel waits for the verify
 // kernels of round R - 2, so a channel learns in round R whether the sub-block it tracked in round R - 2 held: if not, it goes
@@ -243,12 +243,12 @@ struct TrackBlockParams {
     // re-run mode: only channels with only_if[ch] != 0 run, after restoring their state from a checkpoint.  A block of the
     // speculative tracker is checkpointed at the start of every verify sub-block: channel ch restarts at sub-block
     // j = from_sub[ch] (the first one in which its verification failed) from restore_from[j * n_chan + ch], with the EXACT code
-    // loop of that point (exact_hist[j * n_chan + ch]; j == 0: the checkpoint's own), at millisecond j * sub_len.
+    // loop of that point (exact_hist[j * n_chan + ch]; j == 0: the checkpoint's own), at millisecond sub.begin(j).
     const int32_t* only_if;
     const ChanState* restore_from;
     const int32_t* from_sub;
     const DllExact* exact_hist;
-    int32_t sub_len;
+    SubLayout sub;
     float* dbg;                // optional [n_chan][n_ms][20]: |window|^2 x 16, sample energy, code phase mod N, 0, 0 (debug)
     // tracker.py:308-309 (non_coherent_correlation_profiles), throughput path only: the prompt profile of every millisecond
     // from prof_from on goes to prof_tail[ch][ms - prof_from][N], rolled by the code phase the millisecond RAN with (the
@@ -914,8 +914,8 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
             const int sub = sm.red->ctl_sub, restore = sm.red->ctl_restore;
             if (sub < 0) return;
             n_force = __builtin_amdgcn_readfirstlane(sm.red->ctl_nforce);
-            ms_first = sub * p.sub_len;
-            ms_last = min(p.n_ms, ms_first + p.sub_len);
+            ms_first = p.sub.begin(sub);
+            ms_last = p.sub.end(sub, p.n_ms);
             // the sub-block's checkpoint: taken now, or -- a verification failed in here two rounds ago -- gone back to
             ChanState* ck = p.ckpt + (size_t)sub * p.n_chan + ch;
             const uint32_t* src = reinterpret_cast<const uint32_t*>(restore ? ck : st);
@@ -932,8 +932,8 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
         }
     }
     if (p.restore_from) {   // re-run of a channel whose speculation failed verification: back to the checkpoint before the failure
-        const int j = p.from_sub ? min(p.from_sub[ch], (p.n_ms - 1) / max(p.sub_len, 1)) : 0;
-        ms_first = p.from_sub ? j * p.sub_len : p.ms_begin;
+        const int j = p.from_sub ? min(p.from_sub[ch], p.sub.sub_of(p.n_ms - 1)) : 0;
+        ms_first = p.from_sub ? p.sub.begin(j) : p.ms_begin;
         const uint32_t* src = reinterpret_cast<const uint32_t*>(p.restore_from + (size_t)j * p.n_chan + ch);
         uint32_t* dst = reinterpret_cast<uint32_t*>(st);
         for (int i = threadIdx.x; i < (int)(sizeof(ChanState) / 4); i += kThreadsHere) dst[i] = src[i];
@@ -1298,33 +1298,31 @@ struct TrackVerifyParams {
     double inv_fs;
     float tie_tol;
     int32_t force_fail_ms;     // test hook (gyp_debug_set "spec_fail_at"): channel 0's verification "fails" at this millisecond; < 0: off
-    // round protocol (SpecCtl): channel ch's range is sub-block trk_round[ch] (sub_len milliseconds; -1: nothing to verify) and a
+    // round protocol (SpecCtl): channel ch's range is sub-block trk_round[ch] (SubLayout; -1: nothing to verify) and a
     // failure is reported as the first failing millisecond in fail_round[ch]; null: [ms_begin, ms_end) of every channel, bad / bad_from
     const int32_t* trk_round;
     int32_t* fail_round;
-    int32_t sub_len;
+    SubLayout sub;
 };
 
 template <int K>
 __global__ __launch_bounds__(Geom<K>::kThreads, Geom<K>::kMinWavesPerSimd) void track_verify_kernel(TrackVerifyParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int N = K * kChips;
-    if (p.trk_round) {   // a round in which no channel tracked anything: nothing to verify (uniform over the grid)
-        bool any = false;
-        for (int c = 0; c < p.n_chan; ++c) any |= p.trk_round[c] >= 0;
-        if (!any) return;
-    }
+    const int round_len = p.trk_round ? round_length(p.trk_round, p.n_chan, p.sub, p.n_ms) : p.ms_end - p.ms_begin;
+    if (round_len == 0) return;   // a round in which no channel tracked anything: nothing to verify (uniform over the grid)
     const Smem sm = carve_smem<K>(smem_raw, p.tw_tables);
     __syncthreads();
-    const int n_units = p.n_chan * (p.trk_round ? p.sub_len : p.ms_end - p.ms_begin);
+    const int n_units = p.n_chan * round_len;
     for (int v = blockIdx.x; v < n_units; v += gridDim.x) {
         const int u = xcd_contiguous(v, n_units);
         int ms = p.ms_begin + u / p.n_chan;
         const int ch = u % p.n_chan;   // the channels of a millisecond are neighbours: shared IQ
         if (p.trk_round) {             // (uniform per unit)
             const int sub = p.trk_round[ch];
-            ms = sub * p.sub_len + u / p.n_chan;
-            if (sub < 0 || ms >= p.n_ms) continue;
+            if (sub < 0) continue;
+            ms = p.sub.begin(sub) + u / p.n_chan;
+            if (ms >= p.sub.end(sub, p.n_ms)) continue;
         }
         const SpecIn in = p.spec[(int64_t)ch * p.n_ms + ms];
         if (in.key < 0) continue;                                 // uniform: transform path in the tracking kernel, or not processed

@@ -337,7 +337,7 @@ def test_redo_rounds_hand_hopeless_channels_to_the_transform_kernel():
 
 
 def test_redo_rounds_give_up_after_eight_forced_milliseconds():
-    """A long block (6100 ms = 12 sub-blocks, 20 rounds): a noise-only channel under kappa = 0 fails its verification in every pass;
+    """A long block (6100 ms = 11 sub-blocks of 505 ms and three shrinking ones = 14, 22 rounds): a noise-only channel under kappa = 0 fails its verification in every pass;
     it fills its eight forced-transform slots inside the rounds, is declared dead at the ninth failure, and the transform kernel
     finishes it from that sub-block's checkpoint.  Same integers as the transform kernel alone, for it and for the channels with a
     signal beside it."""
@@ -357,7 +357,7 @@ def test_redo_rounds_give_up_after_eight_forced_milliseconds():
     eng_s = _engine_with_env(fs, n, GYP_SPEC_KAPPA=0)
     rec_s, st_s, bad, stats = _bank_run_stats(eng_s, iq, inits, n, fs, n_ms)
     eng_s.close()
-    assert stats["sub_blocks"] == 12 and bad[-1] == 1 and stats["redos"] >= 8, (bad, stats)
+    assert stats["sub_blocks"] == 14 and bad[-1] == 1 and stats["redos"] >= 8, (bad, stats)
     for i in range(len(inits)):
         for f in ("code_phase", "peak_offset", "pseudosymbol", "locked", "status"):
             assert np.array_equal(rec_s[i][f], rec_t[i][f]), (i, f, bad, stats)
