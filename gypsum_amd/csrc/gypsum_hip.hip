@@ -1748,6 +1748,13 @@ int gyp_debug_spec_read(gyp_bank* bank, float* out, int32_t n_floats, int32_t* b
     return GYP_OK;
 }
 
+int gyp_debug_spec_layout(int32_t n_ms, int32_t* starts_out) {
+    if (n_ms <= 0 || !starts_out) return GYP_E_BAD_ARG;
+    const SubLayout l = spec_layout(n_ms, spec_sub_blocks(n_ms));
+    for (int i = 0; i <= l.n; ++i) starts_out[i] = l.start[i];
+    return l.n;
+}
+
 int gyp_debug_spec_redo_read(gyp_bank* bank, int32_t* out4) {
     if (!bank || !out4) return GYP_E_BAD_ARG;
     gyp_ctx* ctx = bank->ctx;

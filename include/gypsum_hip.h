@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-/* 201: gyp_debug_set / gyp_debug_get / gyp_debug_spec_redo_read added (the library no longer reads GYP_* environment switches).
+/* 201: gyp_debug_set / gyp_debug_get / gyp_debug_spec_redo_read / gyp_debug_spec_layout added (the library no longer reads GYP_* environment switches).
  * 200: gyp_chan_out carries the float64 early/late pair (80 bytes), gyp_track_rec::path_info, gyp_debug_track_profile writes
  * 16 values, gyp_params grew; a binding written against another value must not load the library (gypsum_amd/_lib.py checks). */
 #define GYP_VERSION 201 /* 0.2.1 */
@@ -540,6 +540,11 @@ int gyp_debug_dll_read(gyp_bank* bank, int32_t* repairs_out);
  * millisecond then takes the transform path), channels finished by the transform kernel instead (out of forced-transform slots or
  * of rounds; every failure went this way up to ABI 200)}.  Zeros if the bank never took the speculative path.  Synchronises the stream. */
 int gyp_debug_spec_redo_read(gyp_bank* bank, int32_t* out4);
+/* Debug (host arithmetic only, no device needed): the sub-blocks the speculative tracker cuts a block of n_ms milliseconds into --
+ * starts_out[0 .. n] with starts_out[n] = n_ms, n <= 32 returned (sub-block s is [starts_out[s], starts_out[s + 1])); long blocks end
+ * with shrinking sub-blocks because only the LAST sub-block's verification is not hidden behind tracking.
+ * starts_out must hold 33 values.  Returns n, or GYP_E_BAD_ARG (negative). */
+int gyp_debug_spec_layout(int32_t n_ms, int32_t* starts_out);
 /* Debug: time `iters` forward+inverse wavefront transform pairs per wavefront, `wgs` workgroups of `waves_per_wg`
  * wavefronts (LDS-resident data, no global traffic): the floor the correlator kernels are measured against. */
 int gyp_debug_fft_bench(gyp_ctx* ctx, int waves_per_wg, int wgs, int iters, float* ms_out);

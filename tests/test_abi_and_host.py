@@ -223,3 +223,29 @@ def test_the_library_reads_no_switch_from_the_environment(lib):
     assert names == {"GYP_RCCL_LIB"}, names
     # and without a context the entry point refuses instead of crashing
     assert lib.gyp_debug_set(None, b"no_spec", 1.0) == _lib.GYP_E_BAD_ARG
+
+
+def test_speculative_blocks_are_cut_into_sub_blocks_that_cover_them_and_shrink_at_the_end(lib):
+    """gyp_debug_spec_layout (host arithmetic): the sub-blocks partition [0, n_ms); there are at most 32; a long block ends with
+    shrinking pieces, each no shorter than about half its predecessor (round R waits for the verification of round R - 2, which takes
+    about half the tracking time of the same milliseconds: a steeper step would stall the rounds), the last one short (it is the one
+    whose verification nothing hides) -- and short blocks keep their equal pieces."""
+    out = np.zeros(33, dtype=np.int32)
+    assert lib.gyp_debug_spec_layout(0, _lib.ptr(out)) == _lib.GYP_E_BAD_ARG
+    for n_ms in list(range(1, 1300)) + [2000, 2047, 2048, 2049, 3999, 4000, 6109, 9999, 10000, 10001, 20000, 60000, 600000]:
+        n = lib.gyp_debug_spec_layout(n_ms, _lib.ptr(out))
+        assert 1 <= n <= 32, (n_ms, n)
+        starts = out[: n + 1].astype(int)
+        assert starts[0] == 0 and starts[n] == n_ms, (n_ms, starts)
+        lens = np.diff(starts)
+        assert (lens > 0).all(), (n_ms, lens)
+        if n_ms < 256:
+            assert n == 1
+        elif n_ms < 637:                                 # (4 x 160 - 3) equal pieces, the last one takes the remainder
+            assert n == 4 and (lens[:-1] == lens[0]).all() and lens[-1] <= lens[0], (n_ms, lens)
+        else:
+            body, tail = lens[:-3], lens[-3:]
+            assert (body[:-1] == body[0]).all() and body[-1] <= body[0], (n_ms, lens)
+            assert tail[0] <= 0.6 * body[0] + 1 and tail[1] <= 0.65 * tail[0] + 1, (n_ms, lens)
+            assert tail[0] >= 0.5 * body[0] and tail[1] >= 0.5 * tail[0], (n_ms, lens)   # no step steeper than a half
+            assert lens[-1] <= 0.3 * body[0] + 32, (n_ms, lens)
