@@ -1032,6 +1032,9 @@ def main() -> None:
                 ("h2d_inclusive", lambda: run_h2d(eng, eng2, result["_su"])),
                 ("single_stream_2046", lambda: run_single_stream(eng, eng2, fs=2_046_000)),
                 ("batched_2046", lambda: run_batched_rate(eng, comm, 2_046_000)),
+                # the reference's third recording format (radio_input.py:111, 16x): same scene rule as tools/rate_probe.py (a N = 41, sigma = 6 a)
+                ("single_stream_16368", lambda: run_single_stream(eng, eng2, steps=3, warmup=1, fs=16_368_000, amplitude=41.0 / 16368,
+                                                                  sigma=6 * 41.0 / 16368)),
                 ("single_stream_snr", snr_points))
         for name, fn in legs:
             try:
