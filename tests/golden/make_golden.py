@@ -218,7 +218,7 @@ def make_bits() -> None:
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["prn", "grid", "acq", "track", "track16368", "lock", "long", "long8184", "bits"]
+    what = sys.argv[1:] or ["prn", "grid", "acq", "track", "track16368", "track4092", "lock", "long", "long8184", "bits"]
     if "prn" in what:
         make_prn()
     if "grid" in what:
@@ -235,6 +235,10 @@ if __name__ == "__main__":
     if "track16368" in what:
         # the reference's 16x recording format (radio_input.py: 16.368 Msps): acquisition seeds + closed loop
         make_tracking("16368", 16_368_000, 20260933, 300, 2)
+    if "track4092" in what:
+        # 4x: the rate at which the one pseudosymbol of 3.6 M channel-ms differed from the oracle in r03 (a channel that never locks;
+        # tests/test_gpu_track_survey.py plants that scene): pins the oracle -- and the device -- against the reference itself there too
+        make_tracking("4092", 4_092_000, 20260934, 400, 3)
     if "lock" in what:
         make_tracking("2046_lock", 2_046_000, 20260931, 1500, 2, n_sats=4, noise_sigma=0.02)
     if "long" in what:

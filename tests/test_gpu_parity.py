@@ -78,7 +78,7 @@ def test_acquisition_matches_reference(engine_factory, tag):
     assert np.array_equal(detected, z["detected"])
 
 
-@pytest.mark.parametrize("tag", ["2046", "8184", "16368"])
+@pytest.mark.parametrize("tag", ["2046", "8184", "16368", "4092"])
 def test_track_step_teacher_forced(engine_factory, tag):
     """Feed the reference's own per-ms (doppler, phase, code phase) and compare every correlator output."""
     z = gu.load(f"track_{tag}.npz")
@@ -111,7 +111,7 @@ def test_track_step_teacher_forced(engine_factory, tag):
         assert worst_mag < RTOL_MAG and worst_str < RTOL_MAG and worst_disc < RTOL_MAG, (worst_mag, worst_str, worst_disc)
 
 
-@pytest.mark.parametrize("tag", ["2046", "8184", "2046_lock", "16368"])
+@pytest.mark.parametrize("tag", ["2046", "8184", "2046_lock", "16368", "4092"])
 def test_track_block_closed_loop(engine_factory, tag):
     """Device-resident loops started from the reference's acquisition result, compared per ms with the
     reference's closed-loop trajectory."""

@@ -66,7 +66,7 @@ def _run_oracle_tracker(z, sv, n_steps):
     return recs
 
 
-@pytest.mark.parametrize("tag,steps", [("2046", 120), ("8184", 40), ("2046_lock", 800), ("16368", 30)])
+@pytest.mark.parametrize("tag,steps", [("2046", 120), ("8184", 40), ("2046_lock", 800), ("16368", 30), ("4092", 391)])
 def test_tracker_trajectory(tag, steps):
     z = gu.load(f"track_{tag}.npz")
     sv = int(z["tracked"][-1])
