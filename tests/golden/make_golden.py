@@ -218,7 +218,7 @@ def make_bits() -> None:
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["prn", "grid", "acq", "track", "track16368", "track4092", "lock", "long", "long8184", "bits"]
+    what = sys.argv[1:] or ["prn", "grid", "acq", "acq16368", "track", "track16368", "track4092", "lock", "long", "long8184", "bits"]
     if "prn" in what:
         make_prn()
     if "grid" in what:
@@ -229,6 +229,9 @@ if __name__ == "__main__":
         # r03: all 32 satellites at the headline rate too (24 of them noise-only: the cells where top-two gaps are ~1e-2 and
         # the cross-level near-ties of acquisition.py:92-101 live); r01/r02 held the rows of satellites 1, 2, 3 + three visible
         make_acquisition("8184", 8_184_000, 20260927, None)
+    if "acq16368" in what:
+        # the 16x recording format: five satellites that are not in the scene + three that are
+        make_acquisition("16368", 16_368_000, 20260935, [1, 2, 3, 4, 5])
     if "track" in what:
         make_tracking("2046", 2_046_000, 20260928, 700, 3)
         make_tracking("8184", 8_184_000, 20260929, 300, 2)

@@ -61,7 +61,7 @@ def test_cells_profile_matches_oracle_coherent_and_noncoherent(engine_factory):
                 assert abs(tap - ref[cells["tap_index"][i]]) <= 2e-5 * scale
 
 
-@pytest.mark.parametrize("tag", ["2046", "8184"])
+@pytest.mark.parametrize("tag", ["2046", "8184", "16368"])
 def test_acquisition_matches_reference(engine_factory, tag):
     z = gu.load(f"acq_{tag}.npz")
     fs, n = int(z["fs"]), int(z["n"])

@@ -39,7 +39,7 @@ def test_grid_kat_cells():
     assert tuple(z["best"][29, :2]) == (0, 0) and z["best"][29, 2] == pytest.approx(11.7221, abs=1e-4)
 
 
-@pytest.mark.parametrize("tag,rows", [("2046", (2, 18, 0, 9)), ("8184", (1,))])
+@pytest.mark.parametrize("tag,rows", [("2046", (2, 18, 0, 9)), ("8184", (1,)), ("16368", (1, 3))])
 def test_full_acquisition(tag, rows):
     z = gu.load(f"acq_{tag}.npz")
     fs, n = int(z["fs"]), int(z["n"])
