@@ -218,7 +218,7 @@ def make_bits() -> None:
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["prn", "grid", "acq", "acq16368", "track", "track16368", "track4092", "lock", "long", "long8184", "bits"]
+    what = sys.argv[1:] or ["prn", "grid", "acq", "acq16368", "track", "track16368", "track4092", "lock16368", "lock", "long", "long8184", "bits"]
     if "prn" in what:
         make_prn()
     if "grid" in what:
@@ -242,6 +242,9 @@ if __name__ == "__main__":
         # 4x: the rate at which the one pseudosymbol of 3.6 M channel-ms differed from the oracle in r03 (a channel that never locks;
         # tests/test_gpu_track_survey.py plants that scene): pins the oracle -- and the device -- against the reference itself there too
         make_tracking("4092", 4_092_000, 20260934, 400, 3)
+    if "lock16368" in what:
+        # the 16x rate through lock acquisition (is_locked() compares absolute variances: a*N = 20, three satellites, low noise -- as in 8184_long)
+        make_tracking("16368_lock", 16_368_000, 20260936, 1600, 2, n_sats=3, noise_sigma=0.004, amplitude=20.0 / 16368)
     if "lock" in what:
         make_tracking("2046_lock", 2_046_000, 20260931, 1500, 2, n_sats=4, noise_sigma=0.02)
     if "long" in what:

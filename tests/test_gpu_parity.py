@@ -111,7 +111,7 @@ def test_track_step_teacher_forced(engine_factory, tag):
         assert worst_mag < RTOL_MAG and worst_str < RTOL_MAG and worst_disc < RTOL_MAG, (worst_mag, worst_str, worst_disc)
 
 
-@pytest.mark.parametrize("tag", ["2046", "8184", "2046_lock", "16368", "4092"])
+@pytest.mark.parametrize("tag", ["2046", "8184", "2046_lock", "16368", "4092", "16368_lock"])
 def test_track_block_closed_loop(engine_factory, tag):
     """Device-resident loops started from the reference's acquisition result, compared per ms with the
     reference's closed-loop trajectory."""
