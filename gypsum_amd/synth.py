@@ -82,6 +82,24 @@ def random_scene(fs: int, n_ms: int, n_sats: int, seed: int, max_doppler: float 
     return SyntheticScene(fs=fs, n_ms=n_ms, sats=sats, noise_sigma=sg, seed=seed + 1)
 
 
+def lock_regime_scene(fs: int, n_ms: int, seed: int) -> SyntheticScene:
+    """A scene in which `is_locked()` (tracker.py:157-203) is REACHABLE.
+
+    The lock test compares absolute variances of the un-normalised prompt peaks: var(last 250 I*Q) < 900 and the mean of the two
+    poles' var(I) < 2 (config.py:25-27, tracker.py:170-186).  With peak ~ a*N and per-component noise variance v = sigma^2 * N
+    (plus ~(a*N)^2 / 2046 per interfering satellite), that is v < 2 and (a*N)^2 * v < 900: SURVEY section 8 d2's sigma = 6a puts
+    v at 5.1 (2.046 Msps) / 7.4 (8.184 Msps), where no channel can ever lock.  Here a*N ~ U(14, 27), v ~ U(0.05, 1.7) and
+    2-4 satellites: most channels lock once the 250-ms window has filled (the regime a receiver that reaches a position fix
+    lives in), those near (a*N)^2 * v ~ 900 flap between the 3-Hz and 6-Hz loops, some never lock."""
+    rng = np.random.default_rng([seed, 0x10C4ED])
+    n = fs // 1000
+    n_sats = int(rng.integers(2, 5))
+    a_n = float(rng.uniform(14.0, 27.0))
+    v = float(rng.uniform(0.05, 1.7))
+    return random_scene(fs, n_ms, n_sats, seed, max_code_phase=(2046 if n > 2046 else None),
+                        amplitude=a_n / n, noise_sigma=float(np.sqrt(v / n)))
+
+
 def render(scene: SyntheticScene, block_ms: int = 50) -> np.ndarray:
     """complex64[n_ms * N].  float64 synthesis, complex64 storage; deterministic in `scene.seed`."""
     n = scene.samples_per_ms

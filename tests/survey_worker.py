@@ -37,23 +37,33 @@ def scene_inits(scene, rng):
 
 
 def run_scene(args):
-    """args = (fs, n_ms, n_sats, seed, keep_iq_dir).  Returns (seed, iq_path, inits, traj) with traj[ch] an int64/float64
-    array of per-ms rows (pseudosymbol, code_phase_after, peak_offset, locked, doppler_after, lost_flag)."""
-    fs, n_ms, n_sats, seed, iq_dir = args
+    """args = (fs, n_ms, n_sats, seed, keep_iq_dir[, regime]).  Returns (seed, iq_path, inits, traj) with traj[ch] an int64/float64
+    array of per-ms rows (pseudosymbol, code_phase_after, peak_offset, locked, doppler_after, lost_flag, nudged)."""
+    fs, n_ms, n_sats, seed, iq_dir = args[:5]
+    regime = args[5] if len(args) > 5 else "pull-in"
     from gypsum_amd import synth
     from oracle import gypsum_oracle as orc
 
     n = fs // 1000
-    scene = synth.random_scene(fs, n_ms, n_sats, seed, max_code_phase=(2046 if n > 2046 else None))
+    if regime == "lock":
+        # scenes in which is_locked() is reachable (synth.lock_regime_scene); n_sats is drawn by the scene (2..4)
+        scene = synth.lock_regime_scene(fs, n_ms, seed)
+    else:
+        scene = synth.random_scene(fs, n_ms, n_sats, seed, max_code_phase=(2046 if n > 2046 else None))
     iq = synth.render(scene)
     rng = np.random.default_rng(seed ^ 0x5EED)
     inits = scene_inits(scene, rng)
+    if regime == "lock" and n_ms > 6100:
+        # long scenes reach the 6-second watchdog (tracker.py:370-387): some channels start off in Doppler, so that it finds a
+        # constellation to nudge (circularity < 0.93) or to drop (< 0.2) beside the ones that have been locked for seconds
+        off = rng.choice([0.0, 0.0, 25.0, -40.0, 120.0, -250.0], size=len(inits))
+        inits = [(sv, dop + float(o), phi, cp) for (sv, dop, phi, cp), o in zip(inits, off)]
     chips = orc.generate_ca_codes()
     times = [orc.chunk_times(ms * n, n, fs) for ms in range(9, n_ms)]
     traj = []
     for sv, dop, phi, cp in inits:
         trk = orc.Tracker(orc.TrackingState(dop, phi, cp), orc.prn_as_complex(chips[sv - 1], n), fs, n)
-        rows = np.zeros((len(times), 6), dtype=np.float64)
+        rows = np.zeros((len(times), 7), dtype=np.float64)
         for j, (st, en) in enumerate(times):
             ms = 9 + j
             try:
@@ -61,7 +71,7 @@ def run_scene(args):
             except orc.LostSatelliteLock:
                 rows[j:, 5] = 1.0
                 break
-            rows[j] = (r.pseudosymbol, r.code_phase_after, r.peak_offset, float(r.locked), r.doppler_after, 0.0)
+            rows[j] = (r.pseudosymbol, r.code_phase_after, r.peak_offset, float(r.locked), r.doppler_after, 0.0, float(r.nudged))
         traj.append(rows)
     base = iq_dir or ("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir())
     path = os.path.join(base, f"gyp_survey_{os.getpid()}_{seed}.npy")

@@ -1,6 +1,8 @@
 """Not a test: the closed-loop survey of tests/test_gpu_track_survey.py at a larger scale, to put a number on how often
 int(self.phase) comes out one sample different from the float64 oracle for a millisecond.
-    python tools/big_survey.py <n_scenes> [GYP_NO_SPEC|-] [fs] [first_seed]"""
+    python tools/big_survey.py <n_scenes> [GYP_NO_SPEC|-] [fs] [first_seed] [pull-in|lock] [long_scenes]
+("lock": synth.lock_regime_scene, 2-4 channels x 2500 ms per scene, the last `long_scenes` of them 6300 ms; GYP_SURVEY_SEED=0 makes
+first_seed absolute)"""
 import os
 import sys
 
@@ -23,5 +25,11 @@ if __name__ == "__main__":
         os.environ[env] = "1"
     eng = GypsumEngine(0)
     eng.set_stream_format(fs, fs // 1000)
-    t = ts._survey(eng, list(range(seed0, seed0 + n)), 1009, 12, (env or "speculative") + f" {fs / 1e6:.3f} Msps", fs, fs // 1000)
+    regime = sys.argv[5] if len(sys.argv) > 5 else "pull-in"
+    long_scenes = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    if regime == "lock":
+        t = ts._survey(eng, list(range(seed0, seed0 + n)), 2509, 0, "lock regime, " + (env or "speculative") + f" {fs / 1e6:.3f} Msps",
+                       fs, fs // 1000, regime="lock", long_scenes=long_scenes)
+    else:
+        t = ts._survey(eng, list(range(seed0, seed0 + n)), 1009, 12, (env or "speculative") + f" {fs / 1e6:.3f} Msps", fs, fs // 1000)
     print({k: v for k, v in t.items() if k != "first"})

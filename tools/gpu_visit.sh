@@ -76,6 +76,18 @@ l=json.loads(sys.stdin.read()); print({k:l[k] for k in ('value','ms_per_step','a
         timeout 420 python tools/big_survey.py $1 $2 $3 $4 2>&1 | grep -v "^$" | tail -4 >> $O/surveys.txt
         tail -3 $O/surveys.txt | cut -c1-420
       done ;;
+    locktests)
+      timeout 900 python -m pytest tests/test_gpu_track_survey.py -x -q -m gpu -s -k "locked_regime" > $O/pytest_lock.log 2>&1
+      echo "pytest rc=$?" >> $O/pytest_lock.log; grep -v "^$" $O/pytest_lock.log | cut -c1-600 | tail -40 ;;
+    locksurveys)
+      # fresh seeds in the LOCK regime (synth.lock_regime_scene) through both tracking kernels at the reference's three recording rates
+      export GYP_SURVEY_SEED=${LOCK_SEED_BASE:-0}
+      for spec in "${LS_A:-600} - 8184000 5000000 lock 6" "${LS_B:-300} GYP_NO_SPEC 8184000 5100000 lock 3" "${LS_C:-600} - 2046000 5200000 lock 6" "${LS_D:-300} GYP_NO_SPEC 2046000 5300000 lock 3" "${LS_E:-200} - 16368000 5400000 lock 2" "${LS_F:-100} GYP_NO_SPEC 16368000 5500000 lock 1"; do
+        set -- $spec
+        timeout 600 python tools/big_survey.py $1 $2 $3 $4 $5 $6 2>&1 | grep -v "^$" | tail -8 >> $O/lock_surveys.txt
+        tail -8 $O/lock_surveys.txt | cut -c1-600
+      done
+      unset GYP_SURVEY_SEED ;;
     find4092)
       # the one pseudosymbol of r03's 3.6 M channel-ms at 4.092 Msps (profiles/r03_surveys.txt): which scene?
       timeout 400 python tools/big_survey.py 300 - 4092000 1700000 > $O/survey_4092.txt 2>&1; tail -6 $O/survey_4092.txt ;;
