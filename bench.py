@@ -394,15 +394,35 @@ class Cfg3Setup:
         self.bank = eng.create_bank(inits.reshape(-1))
         t_host = np.array([round(ms * n / fs, 6) for ms in range(T)], dtype=np.float64)
         self.t_dev = eng.alloc(t_host.nbytes).upload(t_host)
-        self.rec_dev = eng.alloc(B * C_ * T * TRACK_REC.itemsize) if records else None
+        self.rec_bytes = B * C_ * T * TRACK_REC.itemsize
+        # two record buffers: step i writes slot i % 2 while slot (i - 1) % 2 is on its way to the host (records_to_host)
+        self.rec_devs = [eng.alloc(self.rec_bytes), eng.alloc(self.rec_bytes)] if records else []
+        self.rec_dev = self.rec_devs[0] if records else None
+        self.rec_host = None
 
-    def track(self, iq_ptr=None) -> None:
+    def track(self, iq_ptr=None, slot: int = 0) -> None:
         self.bank.reset_dev(self.inits_dev.ptr.value)
         self.bank.track_block_dev(iq_ptr or self.iq.ptr.value, self.stride, self.T, self.t_dev.ptr.value,
-                                  self.rec_dev.ptr.value if self.rec_dev else 0)
+                                  self.rec_devs[slot % 2].ptr.value if self.rec_devs else 0)
 
-    def records(self) -> np.ndarray:
-        return self.rec_dev.download(TRACK_REC, self.B * self.C * self.T).reshape(self.B, self.C, self.T)
+    def records_to_host(self, eng_copy, slot: int = 0) -> None:
+        """The block's per-ms records (the EmittedPseudosymbol stream of tracker.py:389 and the code phases receiver.py:110-115 reads
+        every millisecond) leave the device: an asynchronous copy into page-locked host memory on the copy context's stream, ordered
+        behind the tracking that wrote them (gyp_wait_for) and overlapped with whatever the engine's stream does next."""
+        if not self.rec_devs:
+            return
+        if self.rec_host is None:
+            self.rec_host = self.eng.host_alloc(self.rec_bytes, np.uint8)
+        eng_copy.wait_for(self.eng)
+        eng_copy.memcpy_d2h_async(self.rec_host, self.rec_devs[slot % 2].ptr.value)
+
+    def records(self, slot: int = 0) -> np.ndarray:
+        return self.rec_devs[slot % 2].download(TRACK_REC, self.B * self.C * self.T).reshape(self.B, self.C, self.T)
+
+    def free_host(self) -> None:
+        if self.rec_host is not None:
+            self.eng.host_free(self.rec_host)
+            self.rec_host = None
 
     def symbol_agreement(self, rec: np.ndarray, max_streams: int = 8) -> float:
         T = self.T
@@ -444,21 +464,57 @@ def run_cfg3(eng, comm, args, rng, eng_scan=None) -> dict:
     if eng_scan is not None:
         eng_scan.set_stream_format(fs, n)
 
-    def step(i: int) -> None:
-        s0 = (i * A) % max(1, B - A + 1)
-        if eng_scan is None:
-            eng.acquire_dev(su.iq.ptr.value + s0 * su.stride * 8, A, su.stride, 10, ALL_IDS, acq_send.ptr.value)
-            comm.allgather(acq_send, acq_recv, acq_bytes)      # on the engine's stream, no host sync
-            su.track()
-            return
-        eng_scan.wait_for(eng)                                  # the previous step's all-gather has read acq_send
-        eng_scan.acquire_dev(su.iq.ptr.value + s0 * su.stride * 8, A, su.stride, 10, ALL_IDS, acq_send.ptr.value)
-        su.track()                                              # beside the scans, on the engine's own stream
-        eng.wait_for(eng_scan)
-        comm.allgather(acq_send, acq_recv, acq_bytes)           # behind both, on the engine's stream, no host sync
+    # the records of every step cross to page-locked host memory INSIDE the timed region, on a copy context's
+    # stream beside the next step's acquisition; --no-records-d2h leaves them in HBM as r01-r04 did
+    d2h = su.rec_devs and not args.no_records_d2h
+    eng_copy = GypsumEngine(eng.device) if d2h else None
 
-    with GpuTelemetry(eng.device, enabled=comm.rank == 0) as tele:      # (rank 0 only: eight ranks need not poll rocm-smi eight times)
-        elapsed = timed_steps(eng, comm, step, args.warmup, args.steps, extra_sync=(eng_scan,) if eng_scan is not None else ())
+    def make_step(with_d2h: bool):
+        def step(i: int) -> None:
+            s0 = (i * A) % max(1, B - A + 1)
+            if eng_scan is None:
+                eng.acquire_dev(su.iq.ptr.value + s0 * su.stride * 8, A, su.stride, 10, ALL_IDS, acq_send.ptr.value)
+                comm.allgather(acq_send, acq_recv, acq_bytes)      # on the engine's stream, no host sync
+                if with_d2h:
+                    eng.wait_for(eng_copy)                          # (slot i % 2 was copied out two steps ago: never waits in practice)
+                su.track(slot=i)
+                if with_d2h:
+                    su.records_to_host(eng_copy, slot=i)
+                return
+            eng_scan.wait_for(eng)                                  # the previous step's all-gather has read acq_send
+            eng_scan.acquire_dev(su.iq.ptr.value + s0 * su.stride * 8, A, su.stride, 10, ALL_IDS, acq_send.ptr.value)
+            if with_d2h:
+                eng.wait_for(eng_copy)
+            su.track(slot=i)                                        # beside the scans, on the engine's own stream
+            if with_d2h:
+                su.records_to_host(eng_copy, slot=i)
+            eng.wait_for(eng_scan)
+            comm.allgather(acq_send, acq_recv, acq_bytes)           # behind both, on the engine's stream, no host sync
+        return step
+
+    step = make_step(bool(d2h))
+    others = tuple(e for e in (eng_scan, eng_copy) if e is not None)
+    elapsed = timed_steps(eng, comm, step, args.warmup, args.steps, extra_sync=others)
+    # the same steps again, untimed, with rocm-smi polled beside them: shader clock and power UNDER this load without a fork / exec
+    # every half second inside the metric; and a short pair with / without the D2H of the records
+    with GpuTelemetry(eng.device, enabled=comm.rank == 0 and not args.no_telemetry) as tele:      # (rank 0 only)
+        if comm.rank == 0 and not args.no_telemetry:
+            t_end = time.perf_counter() + 2.5
+            k = 0
+            while time.perf_counter() < t_end:
+                step(k); k += 1
+                if k % 4 == 0:
+                    eng.sync()
+            eng.sync()
+            for e in others:
+                e.sync()
+    d2h_pair = None
+    if d2h:
+        reps_pair = max(2, min(args.steps, 4))
+        t_with = timed_steps(eng, comm, step, 1, reps_pair, extra_sync=others) / reps_pair
+        t_without = timed_steps(eng, comm, make_step(False), 1, reps_pair, extra_sync=others) / reps_pair
+        d2h_pair = {"with_ms": round(t_with * 1e3, 3), "without_ms": round(t_without * 1e3, 3), "bytes_per_step": su.rec_bytes,
+                    "ratio": round(t_with / t_without, 4)}
     # the all-gather alone (HIP events on the library's stream around gyp_allgather_dev), outside the timed region
     ag_ms = []
     for _ in range(5):
@@ -505,8 +561,15 @@ def run_cfg3(eng, comm, args, rng, eng_scan=None) -> dict:
     sym_ok = None
     state = su.bank.state()
     repairs = su.bank.dll_repairs()     # of the last tracking call (HIP-event loop above): the exact code loop's repair steps
+    locked_fraction = None
     if su.rec_dev is not None:
-        sym_ok = su.symbol_agreement(su.records())
+        rec_all = su.records()
+        sym_ok = su.symbol_agreement(rec_all)
+        locked_fraction = float(np.mean(rec_all["locked"] != 0))
+        del rec_all
+    if eng_copy is not None:
+        su.free_host()
+        eng_copy.close()
     f_trk = C_ * (2 * fft_flops(n) + 18 * n)                          # SURVEY 8(d5), per stream-ms
     return {
         "_su": su,
@@ -541,7 +604,8 @@ def run_cfg3(eng, comm, args, rng, eng_scan=None) -> dict:
                   "acquisition_seed_hits": f"{su.acq_ok}/{B * C_}", "channels_lost": int(state["lost"].sum()),
                   "dll_repair_steps": {"total": int(repairs.sum()), "channels_with_any": int((repairs > 0).sum()),
                                        "max_in_one_channel": int(repairs.max()), "channel_ms": B * C_ * T},
-                  "symbol_agreement_ok_fraction": sym_ok,
+                  "symbol_agreement_ok_fraction": sym_ok, "locked_fraction": locked_fraction,
+                  "records_d2h_in_timed_region": bool(d2h), "records_d2h": d2h_pair,
                   "symbol_agreement_note": "fraction of sampled channels whose last 200 pseudosymbols match the generated "
                                            "navigation bits > 95 %; the float64 oracle's own fraction on equivalent scenes is "
                                            "cpu_baseline_all_cores.symbol_agreement_ok_fraction_float64_oracle (the reference's "
@@ -553,23 +617,34 @@ def run_cfg3(eng, comm, args, rng, eng_scan=None) -> dict:
     }
 
 
+def lock_regime_amplitudes(n: int) -> tuple:
+    """(a, sigma) of a scene in which a 12-satellite stream LOCKS: is_locked() compares absolute variances of the
+    un-normalised prompt peaks (var(I*Q) < 900, pole variance of I < 2, tracker.py:170-186); with eleven interfering satellites that
+    needs a*N ~ 16 and sigma^2 N ~ 0.3 (the oracle's channels lock 0.3-0.5 s into such a scene: tools/lock_scene_probe.py)."""
+    return 16.0 / n, math.sqrt(0.3 / n)
+
+
 def run_single_stream(eng, eng2, steps: int = 10, warmup: int = 2, fs: int = 8_184_000, amplitude: float = None, sigma: float = None,
                       T: int = 10_000, seed: int = 4321) -> dict:
     """STRICT configs[2] (and the same at the reference's 2x recording rate): one stream.  A step is 10 s of signal = one
-    32-satellite scan (on the second context's stream) beside 10 000 ms of 12-channel tracking with per-ms records."""
+    32-satellite scan (on the second context's stream) beside 10 000 ms of 12-channel tracking with per-ms records, which are
+    copied to page-locked host memory on a third stream inside the step."""
     rng = np.random.default_rng(777)
     su = Cfg3Setup(eng, rng, 1, T, seed, amplitude=amplitude, sigma=sigma, fs=fs)
     eng2.set_stream_format(su.fs, su.n)
     scan = eng2.alloc(32 * ACQ_RESULT.itemsize)
+    eng_copy = GypsumEngine(eng.device)
 
     def step(i: int) -> None:
         eng2.acquire_dev(su.iq.ptr.value, 1, su.stride, 10, ALL_IDS, scan.ptr.value)
-        su.track()
+        eng.wait_for(eng_copy)
+        su.track(slot=i)
+        su.records_to_host(eng_copy, slot=i)
 
     class _NoComm:
         def barrier(self):
             pass
-    elapsed = timed_steps(eng, _NoComm(), step, warmup, steps, extra_sync=(eng2,))
+    elapsed = timed_steps(eng, _NoComm(), step, warmup, steps, extra_sync=(eng2, eng_copy))
     eng.timer_start(); su.track(); trk_ms = eng.timer_stop()
     eng2.timer_start(); eng2.acquire_dev(su.iq.ptr.value, 1, su.stride, 10, ALL_IDS, scan.ptr.value); acq_ms = eng2.timer_stop()
     rec = su.records()
@@ -588,8 +663,13 @@ def run_single_stream(eng, eng2, steps: int = 10, warmup: int = 2, fs: int = 8_1
         "speculation_redo": su.redo_stats(),
         "acquisition_seed_hits": f"{su.acq_ok}/12",
         "symbol_agreement_ok_fraction": su.symbol_agreement(rec),
+        "locked_fraction": round(float(np.mean(rec["locked"] != 0)), 4),
+        "lock_transitions": int(np.sum(rec["locked"][:, :, 1:] != rec["locked"][:, :, :-1])),
+        "records_d2h_in_timed_region": True,
         "channels_lost": int(su.bank.state()["lost"].sum()),
     }
+    su.free_host()
+    eng_copy.close()
     su.bank.close()
     return out
 
@@ -601,11 +681,12 @@ SINGLE_STREAM_METHOD = ("speculative tracker: window correlations around the las
                         "millisecond on the transform path -- all inside the timed region")
 
 
-def run_batched_rate(eng, comm, fs: int, B: int = 128, T: int = 1000, steps: int = 3, warmup: int = 1) -> dict:
+def run_batched_rate(eng, comm, fs: int, B: int = 128, T: int = 1000, steps: int = 3, warmup: int = 1, amplitude: float = None,
+                     sigma: float = None) -> dict:
     """The headline workload's shape at another sample rate (north_star names 2.046 -- "2.048" -- Msps beside 8.184): B streams, one
     32-satellite scan per 10 s of signal per stream + 12-channel tracking of every stream for T ms per step, IQ resident."""
     rng = np.random.default_rng(2046)
-    su = Cfg3Setup(eng, rng, B, T, 9876, fs=fs)
+    su = Cfg3Setup(eng, rng, B, T, 9876, fs=fs, amplitude=amplitude, sigma=sigma)
     A = max(1, math.ceil(B * T / 10_000))
     acq = eng.alloc(A * 32 * ACQ_RESULT.itemsize)
 
@@ -622,6 +703,7 @@ def run_batched_rate(eng, comm, fs: int, B: int = 128, T: int = 1000, steps: int
            "value": round(v, 3), "unit": "Msamples/s", "x_realtime_aggregate": round(v * 1e6 / fs, 2), "x_realtime_per_stream": round(v * 1e6 / fs / B, 3),
            "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "acquire_ms_per_step": round(acq_ms, 3), "track_ms_per_step": round(trk_ms, 3),
            "acquisition_seed_hits": f"{su.acq_ok}/{B * su.C}", "symbol_agreement_ok_fraction": su.symbol_agreement(su.records()),
+           "locked_fraction": round(float(np.mean(su.records()["locked"] != 0)), 4),
            "channels_lost": int(su.bank.state()["lost"].sum())}
     su.bank.close()
     return out
@@ -961,6 +1043,12 @@ def main() -> None:
     ap.add_argument("--grid-ms", type=int, default=64, help="ms of signal per stream per step (cfg2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-records", action="store_true", help="do not write per-ms tracking records")
+    ap.add_argument("--no-records-d2h", action="store_true", help="leave the per-ms records in HBM (r01-r04's timed region) instead of copying every "
+                                                                  "step's to page-locked host memory on a copy stream")
+    ap.add_argument("--no-telemetry", action="store_true", help="skip the untimed repetition that samples shader clock / power under load")
+    ap.add_argument("--detail-out", default=None, help="where the full record goes (every leg with its method notes; default "
+                                                       "gpurun_out/bench_detail.json); stdout carries the compact line")
+    ap.add_argument("--verbose", action="store_true", help="print the full record on stdout instead of the compact line")
     ap.add_argument("--no-extras", action="store_true", help="skip single_stream / h2d_inclusive / other_configs")
     ap.add_argument("--overlap-scan", action="store_true",
                     help="cfg3: run a step's satellite scans beside its tracking on a second HIP stream (gyp_wait_for) instead of in front "

@@ -58,12 +58,12 @@ RECORD_SIZES = {"gyp_bit_event": BIT_EVENT.itemsize, "gyp_bits_state": BITS_STAT
                 "gyp_chan_in": CHAN_IN.itemsize, "gyp_chan_out": CHAN_OUT.itemsize, "gyp_best_bin": BEST_BIN.itemsize,
                 "gyp_params": PARAMS.itemsize, "gyp_track_rec": TRACK_REC.itemsize}
 # include/gypsum_hip.h GYP_VERSION these mirrors were written against: load() refuses any other library
-GYP_VERSION = 201
+GYP_VERSION = 202
 
 EXPORTS = (
     "gyp_version gyp_create gyp_destroy gyp_last_error gyp_device_name gyp_set_stream gyp_sync gyp_wait_for gyp_timer_start "
     "gyp_timer_stop gyp_set_stream_format gyp_prn_chips gyp_prn_spectrum_lane_layout gyp_malloc gyp_free "
-    "gyp_memcpy_h2d gyp_memcpy_d2h gyp_cell_strength gyp_correlate_cells_dev gyp_correlate_cells gyp_correlate_grid_dev "
+    "gyp_memcpy_h2d gyp_memcpy_d2h gyp_memcpy_d2h_async gyp_cell_strength gyp_correlate_cells_dev gyp_correlate_cells gyp_correlate_grid_dev "
     "gyp_correlate_grid gyp_acquire_dev gyp_params_default gyp_set_params gyp_get_params gyp_search_level_dev gyp_search_level "
     "gyp_acquire gyp_track_step_dev gyp_track_step gyp_bank_create gyp_bank_destroy gyp_bank_size gyp_bank_set_channel gyp_bank_drop_channel "
     "gyp_track_block_dev gyp_track_block gyp_bank_get_state gyp_bank_keep_profiles gyp_bank_read_profiles gyp_synth_iq_dev gyp_synth_nav_bit gyp_bank_reset_dev gyp_debug_track_profile gyp_debug_fft_bench gyp_debug_spec_read gyp_debug_dll_read gyp_debug_track_timing gyp_debug_set gyp_debug_get gyp_debug_spec_redo_read gyp_debug_spec_layout gyp_device_locality "
@@ -115,6 +115,7 @@ def load() -> C.CDLL:
         "gyp_free": (C.c_int, [vp, vp]),
         "gyp_memcpy_h2d": (C.c_int, [vp, vp, vp, u64]),
         "gyp_memcpy_d2h": (C.c_int, [vp, vp, vp, u64]),
+        "gyp_memcpy_d2h_async": (C.c_int, [vp, vp, vp, u64]),
         "gyp_cell_strength": (dbl, [vp, i32]),
         "gyp_correlate_cells_dev": (C.c_int, [vp, vp, i64, i32, vp, i32, i32, vp, vp]),
         "gyp_correlate_cells": (C.c_int, [vp, vp, i32, i32, vp, i32, i32, vp, vp]),

@@ -118,6 +118,7 @@ struct gyp_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cus = 256;
+    int n_xcd = 8;             // hipDeviceAttributeNumberOfXccs (workgroup b is dispatched to XCD b % n_xcd)
     bool no_pipe = false;      // gyp_debug_set("no_pipe"): A/B switch back to the two-workgroups-per-CU cells kernel
     int track_chunk_ms = 500;     // gyp_debug_set("track_chunk_ms"): the throughput tracking kernel's launch length (0: whole blocks)
     float symbol_tau = 1e-4f;     // gyp_debug_set("symbol_tau"): |Re peak| / |peak| below which the pseudosymbol is decided in float64 (test hook: 10 = always)
@@ -347,6 +348,10 @@ int gyp_create(int device_ordinal, gyp_ctx** out) {
     gyp_ctx* ctx = new gyp_ctx();
     ctx->device = device_ordinal;
     ctx->n_cus = prop.multiProcessorCount;
+    {
+        int xccs = 0;
+        if (hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, device_ordinal) == hipSuccess && xccs > 0) ctx->n_xcd = xccs;
+    }
     // (no GYP_* environment variable is read here or anywhere else in the library except GYP_RCCL_LIB, a deployment's library path:
     // the A/B switches and test hooks below are set through gyp_debug_set by whoever wants them)
     gyp_params_default(&ctx->params);
@@ -539,6 +544,12 @@ int gyp_memcpy_d2h(gyp_ctx* ctx, void* dst_host, const void* src_dev, uint64_t b
     return GYP_OK;
 }
 
+int gyp_memcpy_d2h_async(gyp_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes) {
+    if (!ctx || (!dst_host && bytes) || (!src_dev && bytes)) return GYP_E_BAD_ARG;
+    HIP_TRY(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return GYP_OK;
+}
+
 double gyp_cell_strength(const gyp_cell* c, int32_t samples_per_ms) {
     const double pk = (double)c->peak;
     return pk / ((c->sum - (double)c->n_max * pk) / (double)(samples_per_ms - c->n_max));
@@ -590,8 +601,12 @@ static int launch_track_step(gyp_ctx* ctx, const TrackStepParams& p) {
 }
 
 template <bool PROF>
-static int launch_track_block_t(gyp_ctx* ctx, const TrackBlockParams& p, int mode) {
-    const int grid = p.n_chan;
+static int launch_track_block_t(gyp_ctx* ctx, const TrackBlockParams& p_in, int mode) {
+    const int grid = p_in.n_chan;
+    TrackBlockParams p = p_in;
+    // gyp_debug_set "prof_wave" names a wavefront of workgroup 0: kernels with fewer wavefronts (K = 2 has two, K = 4 four in MODE 0) would
+    // leave gyp_debug_track_profile's counters stale -- the last wavefront the launch has stamps them instead
+    p.prof_wave = std::min(p.prof_wave, (mode == 2 ? 512 : threads_for(ctx->k)) / 64 - 1);
     if (mode == 2) {   // 512 threads whatever the rate (launch_k's block size follows its rate argument: 8 -> 512)
         if (ctx->k == 2) return launch_k(ctx, track_block_kernel<2, PROF, 2>, 8, grid, p, lds_bytes_spec<2>());
         if (ctx->k == 16) return launch_k(ctx, track_block_kernel<16, PROF, 2>, 8, grid, p, lds_bytes_spec<16>());
@@ -618,9 +633,9 @@ static int launch_track_verify(gyp_ctx* ctx, const TrackVerifyParams& p, hipStre
         // for it to drain, every round (0.3 us per ms-step of a 12-channel bank).  One workgroup per CU on all but the CUs the channels
         // need (workgroup b goes to XCD b % 8; inside an XCD the dispatcher fills the emptiest CU first) leaves those CUs empty.
         // (K = 2: the same with 46 KB / 8 x 212 registers against up to eight 2-wavefront verify workgroups per CU.)
-        const int per_xcd = ctx->n_cus / 8, need = (p.n_chan + 7) / 8 + 1;
-        grid = 8 * std::max(4, per_xcd - need);
-        grid = std::max(8, std::min(grid, n_units & ~7));
+        const int X = ctx->n_xcd, per_xcd = ctx->n_cus / X, need = (p.n_chan + X - 1) / X + 1;
+        grid = X * std::max(4, per_xcd - need);
+        grid = std::max(X, std::min(grid, n_units / X * X));
     }
     if (ctx->k == 2) {
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(track_verify_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -641,7 +656,9 @@ static int launch_track_verify(gyp_ctx* ctx, const TrackVerifyParams& p, hipStre
 
 // tracker.py:297 in float64 for every (channel, millisecond) of [ms_begin, ms_end), then the code loop re-integrated from it
 static int launch_dll_exact(gyp_ctx* ctx, const DllExactParams& p, hipStream_t stream) {
-    const int n_units = p.n_chan * (p.ms_end - p.ms_begin);
+    // (round protocol: a round holds at most one sub-block per channel -- the kernels walk n_chan * round_length() units -- so the grid is
+    // sized by the longest sub-block like launch_track_verify's, not by the whole block)
+    const int n_units = p.n_chan * (p.trk_round ? p.sub.longest : p.ms_end - p.ms_begin);
     if (n_units <= 0) return GYP_OK;
     switch (ctx->k) {
 #define X(K)                                                                                                                   \
@@ -1343,17 +1360,19 @@ static SubLayout spec_layout(int n_ms, int n_sub) {
 }
 static int ensure_spec_buffers(gyp_bank* bank, int n_sub, int rounds) {
     gyp_ctx* ctx = bank->ctx;
-    if (!bank->verify_stream) {
-        HIP_TRY(ctx, hipMalloc((void**)&bank->d_bad, (size_t)bank->n_chan * sizeof(int32_t)));
-        HIP_TRY(ctx, hipMalloc((void**)&bank->d_bad_from, (size_t)bank->n_chan * sizeof(int32_t)));
-        HIP_TRY(ctx, hipMalloc((void**)&bank->d_ctl, (size_t)bank->n_chan * sizeof(SpecCtl)));
+    // each resource under its own check: a HIP failure part way through leaves what exists in place for the retry (and for gyp_bank_destroy)
+    if (!bank->d_bad) HIP_TRY(ctx, hipMalloc((void**)&bank->d_bad, (size_t)bank->n_chan * sizeof(int32_t)));
+    if (!bank->d_bad_from) HIP_TRY(ctx, hipMalloc((void**)&bank->d_bad_from, (size_t)bank->n_chan * sizeof(int32_t)));
+    if (!bank->d_ctl) HIP_TRY(ctx, hipMalloc((void**)&bank->d_ctl, (size_t)bank->n_chan * sizeof(SpecCtl)));
+    if (!bank->d_redo_stats) {
         HIP_TRY(ctx, hipMalloc((void**)&bank->d_redo_stats, 4 * sizeof(int32_t)));
         HIP_TRY(ctx, hipMemset(bank->d_redo_stats, 0, 4 * sizeof(int32_t)));
-        HIP_TRY(ctx, hipStreamCreateWithFlags(&bank->verify_stream, hipStreamNonBlocking));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&bank->ev_spec, hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&bank->ev_verify, hipEventDisableTiming));
-        for (auto& e : bank->ev_vring) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
+    if (!bank->verify_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&bank->verify_stream, hipStreamNonBlocking));
+    if (!bank->ev_spec) HIP_TRY(ctx, hipEventCreateWithFlags(&bank->ev_spec, hipEventDisableTiming));
+    if (!bank->ev_verify) HIP_TRY(ctx, hipEventCreateWithFlags(&bank->ev_verify, hipEventDisableTiming));
+    for (auto& e : bank->ev_vring)
+        if (!e) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (bank->ckpt_cap < n_sub) {   // state checkpoints (18 KB per channel and sub-block): as many as this block uses
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(bank->verify_stream));
@@ -1459,6 +1478,8 @@ static int track_block_speculative_rerun(gyp_bank* bank, TrackBlockParams p) {
     HIP_TRY(ctx, hipEventRecord(bank->ev_verify, bank->verify_stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, bank->ev_verify, 0));
     join_on_error.armed = false;
+    // gyp_debug_spec_redo_read's out4[3]: how many channels the transform kernel finishes (the round protocol's spec_finalize_kernel counts its own)
+    hipLaunchKernelGGL(count_nonzero_kernel, dim3(1), dim3(64), 0, ctx->stream, bank->d_bad, bank->n_chan, bank->d_redo_stats + 3);
     // channels whose window maximum was not the global one somewhere (any count is handled): again from the checkpoint of the
     // sub-block in which that happened, through the transform kernel, their code loop re-integrated behind it
     p.dbg = nullptr;
@@ -2230,7 +2251,15 @@ int gyp_device_locality(gyp_ctx* ctx, int32_t* numa_node_out, char* cpulist_out,
     if (!ctx) return GYP_E_BAD_ARG;
     const HostLocality loc = device_locality(ctx->device);
     if (numa_node_out) *numa_node_out = loc.numa_node;
-    if (cpulist_out && cap > 0) std::snprintf(cpulist_out, (size_t)cap, "%s", loc.cpulist.c_str());
+    if (cpulist_out && cap > 0) {
+        // a list that does not fit is cut at a comma, never in the middle of a range (a truncated "128-1" would bind to the wrong CPUs)
+        std::string text = loc.cpulist;
+        if ((int)text.size() >= cap) {
+            const size_t cut = text.rfind(',', (size_t)cap - 1);
+            text = cut == std::string::npos ? std::string() : text.substr(0, cut);
+        }
+        std::snprintf(cpulist_out, (size_t)cap, "%s", text.c_str());
+    }
     return GYP_OK;
 }
 

@@ -62,9 +62,9 @@ static std::string read_small_file(const std::string& path) {
     std::string out;
     if (FILE* f = std::fopen(path.c_str(), "r")) {
         char buf[512];
-        const size_t n = std::fread(buf, 1, sizeof(buf) - 1, f);
+        size_t n;
+        while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) out.append(buf, n);   // (a many-core host's cpulist can exceed one buffer)
         std::fclose(f);
-        out.assign(buf, n);
         while (!out.empty() && (out.back() == '\n' || out.back() == ' ')) out.pop_back();
     }
     return out;

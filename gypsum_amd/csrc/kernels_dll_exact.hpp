@@ -552,6 +552,13 @@ __global__ __launch_bounds__(256) void spec_finalize_kernel(SpecFinalizeParams p
 }
 
 // {a, b, c, d} -> p[0..3] on the stream (telemetry headers: no host buffer has to outlive the call)
+// out[0] = how many of v[0 .. n) are non-zero (one wavefront)
+__global__ void count_nonzero_kernel(const int32_t* __restrict__ v, int32_t n, int32_t* __restrict__ out) {
+    int c = 0;
+    for (int i = threadIdx.x; i < n; i += 64) c += v[i] != 0 ? 1 : 0;
+    for (int off = 32; off; off >>= 1) c += __shfl_xor(c, off, 64);
+    if (threadIdx.x == 0) out[0] = c;
+}
 __global__ void set4_kernel(int32_t* p, int32_t a, int32_t b, int32_t c, int32_t d) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 }

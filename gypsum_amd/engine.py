@@ -121,8 +121,8 @@ class GypsumEngine:
     def locality(self) -> Dict[str, object]:
         """NUMA node of this engine's GPU and that node's CPUs (gyp_device_locality); node -1 / empty list where the host does not say."""
         node = C.c_int32(-1)
-        buf = C.create_string_buffer(512)
-        self._check(self.lib.gyp_device_locality(self.ctx, C.byref(node), buf, 512))
+        buf = C.create_string_buffer(8192)
+        self._check(self.lib.gyp_device_locality(self.ctx, C.byref(node), buf, 8192))
         text = buf.value.decode()
         cpus = []
         for part in filter(None, text.split(",")):
@@ -180,6 +180,10 @@ class GypsumEngine:
     def memcpy_h2d_async(self, dst_ptr: int, host: np.ndarray) -> None:
         """Enqueue a host-to-device copy on the engine's stream (asynchronous for page-locked `host`)."""
         self._check(self.lib.gyp_memcpy_h2d(self.ctx, C.c_void_p(dst_ptr), ptr(host), host.nbytes))
+
+    def memcpy_d2h_async(self, host: np.ndarray, src_ptr: int, nbytes: Optional[int] = None) -> None:
+        """Enqueue a device-to-host copy on the engine's stream without waiting for it (page-locked `host`; read it after sync())."""
+        self._check(self.lib.gyp_memcpy_d2h_async(self.ctx, ptr(host), C.c_void_p(src_ptr), int(host.nbytes if nbytes is None else nbytes)))
 
     def widen_iq_dev(self, fmt: int, raw_ptr: int, n_words: int, out_ptr: int, scale: float = 1.0) -> None:
         self._check(self.lib.gyp_widen_iq_dev(self.ctx, int(fmt), C.c_void_p(raw_ptr), int(n_words), float(scale), C.c_void_p(out_ptr)))

@@ -28,10 +28,11 @@
 extern "C" {
 #endif
 
-/* 201: gyp_debug_set / gyp_debug_get / gyp_debug_spec_redo_read / gyp_debug_spec_layout added (the library no longer reads GYP_* environment switches).
+/* 202: gyp_memcpy_d2h_async added (per-ms records leave the device on a copy stream while the next block is tracked).
+ * 201: gyp_debug_set / gyp_debug_get / gyp_debug_spec_redo_read / gyp_debug_spec_layout added (the library no longer reads GYP_* environment switches).
  * 200: gyp_chan_out carries the float64 early/late pair (80 bytes), gyp_track_rec::path_info, gyp_debug_track_profile writes
  * 16 values, gyp_params grew; a binding written against another value must not load the library (gypsum_amd/_lib.py checks). */
-#define GYP_VERSION 201 /* 0.2.1 */
+#define GYP_VERSION 202 /* 0.2.2 */
 
 enum {
     GYP_OK = 0,
@@ -137,6 +138,11 @@ int gyp_malloc(gyp_ctx* ctx, uint64_t bytes, void** dptr);
 int gyp_free(gyp_ctx* ctx, void* dptr);
 int gyp_memcpy_h2d(gyp_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes); /* async on the stream */
 int gyp_memcpy_d2h(gyp_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes); /* synchronises */
+/* The same enqueued on the context's stream without waiting for it (dst_host page-locked, gyp_host_alloc, for the copy to overlap
+ * anything): how a receiver takes a block's gyp_track_rec records -- the EmittedPseudosymbol stream of tracker.py:389 and the
+ * code phases receiver.py:110-115 reads -- off the device while the next block is being tracked.  The caller orders it against the
+ * producer with gyp_wait_for and reads dst_host after gyp_sync of this context. */
+int gyp_memcpy_d2h_async(gyp_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
 
 /* ---------------------------------------------------------------- correlation cells ------------------- */
 /* One (stream, satellite, Doppler) cell of the search grid = one call of

@@ -311,6 +311,7 @@ class TrackStepRecord:
     start_of_pseudosymbol: float
     end_of_pseudosymbol: float
     nudged: bool = False        # the circularity watchdog changed Doppler / carrier phase after this millisecond
+    lock_margin: float = math.inf   # min(lock_margins()) at the moment is_locked() was asked (Tracker.record_margins; test infrastructure)
 
 
 class TrackingState:
@@ -352,6 +353,30 @@ class TrackingState:
         return bool(var_ok and i_ok and rot_ok)
 
 
+def lock_margins(state: "TrackingState") -> Tuple[float, float, float]:
+    """Test infrastructure (no counterpart upstream): how far the three comparisons of is_locked() (tracker.py:171,192,197) are from
+    their thresholds, as relative distances |x - threshold| / threshold of the quantities the reference compares -- the variance of
+    the last 250 I*Q errors against 900, the mean pole variance of I against 2, the centred constellation angle against 6 degrees.
+    (inf, inf, inf) while the window is not full.  A lock flag can only depend on float32-level rounding of the prompt peaks where
+    one of these is of the order of 1e-6: the surveys use it to tell a knife-edge verdict from a defect."""
+    w = LOCK_WINDOW_MS
+    if len(state.carrier_wave_phase_errors) < w:
+        return (math.inf, math.inf, math.inf)
+    errs = np.array(list(state.carrier_wave_phase_errors)[-w:])
+    m_err = abs(float(np.var(errs)) - LOCK_MAX_PHASE_ERROR_VARIANCE) / LOCK_MAX_PHASE_ERROR_VARIANCE
+    peaks = np.array(list(state.correlation_peaks_rolling_buffer)[-w:])
+    neg = peaks[peaks.real < 0]
+    pos = peaks[peaks.real >= 0]
+    mean_neg = np.mean(neg) if len(neg) >= 2 else 0
+    nvar = np.var(neg.real) if len(neg) >= 2 else 0
+    pvar = np.var(pos.real) if len(pos) >= 2 else 0
+    m_i = abs((nvar + pvar) / 2.0 - LOCK_MAX_I_VARIANCE) / LOCK_MAX_I_VARIANCE
+    angle = 180 - (((np.arctan2(np.imag(mean_neg), np.real(mean_neg)) / TAU) * 360) % 180)
+    centered = angle if angle < 90 else 180 - angle
+    m_rot = abs(centered - LOCK_MAX_ROTATION_DEG) / LOCK_MAX_ROTATION_DEG
+    return (float(m_err), float(m_i), float(m_rot))
+
+
 def pll_gains(bandwidth_hz: float, fs: int) -> Tuple[float, float]:
     """tracker.py:227-244: alpha = 4*zeta*B/fs, beta = 4*B^2/fs, zeta = 1/sqrt(2)."""
     dt = 1.0 / fs
@@ -370,6 +395,7 @@ class Tracker:
         self.phase = state.current_prn_code_phase_shift                  # tracker.py:224
         self.accumulator = 0                                             # tracker.py:223
         self._last_circularity_check = 0.0                               # tracker.py:222
+        self.record_margins = False       # test infrastructure: fill TrackStepRecord.lock_margin (costs a second pass over the window)
 
     def process_samples(self, samples: np.ndarray, start_time: float, end_time: float) -> TrackStepRecord:
         s = self.s
@@ -406,6 +432,7 @@ class Tracker:
         # --- carrier loop, tracker.py:246-262
         err = peak.real * peak.imag
         locked = s.is_locked()
+        margin = min(lock_margins(s)) if self.record_margins else math.inf
         alpha, beta = pll_gains(PLL_BW_LOCKED if locked else PLL_BW_UNLOCKED, self.fs)
         s.current_carrier_wave_phase_shift += err * alpha
         s.current_carrier_wave_phase_shift %= TAU
@@ -421,7 +448,7 @@ class Tracker:
             doppler_used=float(f_used), carrier_phase_used=float(phi_used),
             doppler_after=float(s.current_doppler_shift),
             carrier_phase_after=float(s.current_carrier_wave_phase_shift),
-            start_of_pseudosymbol=start_time + delay, end_of_pseudosymbol=end_time + delay,
+            start_of_pseudosymbol=start_time + delay, end_of_pseudosymbol=end_time + delay, lock_margin=margin,
         )
         # --- 6-second circularity watchdog, tracker.py:370-387
         if start_time - self._last_circularity_check >= WATCHDOG_PERIOD_S:

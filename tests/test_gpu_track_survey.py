@@ -52,6 +52,48 @@ SEED_OFFSET = _fresh_seed_offset()
 print(f"[survey seeds] SEED_OFFSET = {SEED_OFFSET} (replay with GYP_SURVEY_SEED={SEED_OFFSET})")
 
 
+KNIFE_EDGE = 1e-5      # relative distance of an is_locked() comparison from its threshold below which float32 peaks may decide it
+
+
+def _sync_horizon(g, r, where, tally):
+    """Lock regime: how many leading milliseconds of a channel are held to "every integer equal".
+
+    Two things can legitimately end that, and both are properties of the REFERENCE's arithmetic, not of this device:
+    * a knife-edge lock verdict: is_locked() compares var(last 250 I*Q) with 900, the pole variance of I with 2 and the constellation
+      angle with 6 degrees (tracker.py:171,192,197); a channel that flaps between the 3-Hz and the 6-Hz loop crosses those thresholds
+      thousands of times, and where the reference's own float64 quantity sits within ~1e-6 (relative) of the threshold the device's
+      float32 prompt peaks (3e-7) can land on the other side.  Accepted only if the ORACLE's margin at that millisecond is below
+      KNIFE_EDGE; the loop bandwidth then differs for a millisecond and the trajectories are no longer the same experiment.
+    * an unlocked loop's sensitivity: a channel that has not locked for the whole preceding window (e.g. started 120 Hz off) is not
+      contracting -- it amplifies rounding differences (the Doppler difference grows from 1e-9 to 1e-3 Hz over seconds before any
+      integer differs).  Accepted only after >= 1000 ms, with the oracle unlocked throughout the preceding 250 ms and the two Doppler
+      estimates already measurably apart (> 1e-5 Hz) on the millisecond before.
+    A pseudosymbol whose peak has |Re| < 2e-4 |peak| in a channel that is not locked is the float32 floor documented in r03 (counted,
+    does not end the comparison).  Anything else is `unexplained` and fails the test."""
+    sym = g["pseudosymbol"] != r[:, 0].astype(np.int64)
+    lk = r[:, 3] != 0
+    zero_real = sym & (r[:, 8] < 2e-4) & ~lk
+    hard = (sym & ~zero_real) | (g["code_phase"] != r[:, 1].astype(np.int64)) | (g["peak_offset"] != r[:, 2].astype(np.int64)) | \
+           (g["locked"].astype(bool) != lk)
+    if not hard.any():
+        return len(r)
+    j = int(np.argmax(hard))
+    ddop = float(abs(g["doppler_hz"][j - 1] - r[j - 1, 4])) if j else 0.0
+    what = f"{where} ms {9 + j}: lock gpu {int(g['locked'][j])} oracle {int(lk[j])} (oracle margin {r[j, 7]:.2e}), pseudosymbol gpu " \
+           f"{int(g['pseudosymbol'][j])} oracle {int(r[j, 0])}, code phase gpu {int(g['code_phase'][j])} oracle {int(r[j, 1])}, Doppler " \
+           f"difference the ms before {ddop:.2e} Hz"
+    if (g["locked"].astype(bool) != lk)[j] and r[j, 7] < KNIFE_EDGE:
+        tally["knife_edge"] += 1
+        tally["events"].append("knife-edge lock verdict: " + what)
+    elif j + 9 >= 1000 and not lk[max(0, j - 250):j + 1].any() and ddop > 1e-5:
+        tally["unlocked_divergence"] += 1
+        tally["events"].append("unlocked loop separated: " + what)
+    else:
+        tally["unexplained"] += 1
+        tally["events"].append("UNEXPLAINED: " + what)
+    return j
+
+
 def _compare(eng, seed, path, inits, traj, n_ms, tally, label, FS=FS, N=N):
     iq = np.load(path)
     init_rec = np.zeros(len(inits), dtype=_lib.CHAN_INIT)
@@ -64,6 +106,10 @@ def _compare(eng, seed, path, inits, traj, n_ms, tally, label, FS=FS, N=N):
     for i, rows in enumerate(traj):
         alive = rows[:, 5] == 0
         k = int(alive.sum())
+        k_all = k
+        if tally.get("regime") == "lock":
+            k = _sync_horizon(rec[i, :k], rows[:k], f"{label} seed {seed} ch {i}", tally)
+            tally["n_after_event"] += k_all - k
         g = rec[i, :k]
         r = rows[:k]
         tally["n"] += k
@@ -92,13 +138,13 @@ def _compare(eng, seed, path, inits, traj, n_ms, tally, label, FS=FS, N=N):
         if r.shape[1] > 6:
             tally["nudges"] += int(np.sum(r[:, 6] != 0))
             tally["nudge_bad"] += int(np.sum((g["nudged"] != 0) != (r[:, 6] != 0)))
-        tally["lost"] += int(k < len(rows))
+        tally["lost"] += int(k_all < len(rows))
         tally["dop"] = max(tally["dop"], float(np.max(np.abs(g["doppler_hz"] - r[:, 4]))) if k else 0.0)
         tally["fast"] += int(np.sum((g["path_info"] & 3) == 1))
         if bad_cp.any() and len(tally["first"]) < 5:
             j = int(np.argmax(bad_cp))
             tally["first"].append(f"{label} seed {seed} ch {i} ms {9 + j}: gpu {int(g['code_phase'][j])} oracle {int(r[j, 1])}")
-        if k < len(rows):     # the oracle raised LostSatelliteLockError at row k
+        if k_all < len(rows) and k == k_all:     # the oracle raised LostSatelliteLockError at row k (and the channel was in step until then)
             assert rec[i, k]["status"] == 1, (label, seed, i, k)
 
 
@@ -109,7 +155,8 @@ def _survey(engine, seeds, n_ms, n_sats, label, FS=FS, N=N, regime="pull-in", lo
     procs = max(1, min(64, (os.cpu_count() or 2) - 2, len(seeds)))
     tally = {"n": 0, "sym": 0, "cp": 0, "off": 0, "lock": 0, "dop": 0.0, "fast": 0, "first": [], "sym_locked": 0, "sym_never_locked": 0,
              "ch_locked": 0, "ch_never_locked": 0, "n_locked": 0, "bad_locked": 0, "bad_unlocked": 0, "transitions": 0, "nudges": 0,
-             "nudge_bad": 0, "lost": 0, "seed_offset": SEED_OFFSET}
+             "nudge_bad": 0, "lost": 0, "seed_offset": SEED_OFFSET, "regime": regime, "knife_edge": 0, "unlocked_divergence": 0,
+             "unexplained": 0, "n_after_event": 0, "events": []}
     t_start = time.time()
     ctx = mp.get_context("spawn")      # the parent holds a HIP context: never fork it
     jobs = [(FS, long_ms if i >= len(seeds) - long_scenes else n_ms, n_sats, s, None, regime) for i, s in enumerate(seeds)]
@@ -125,7 +172,11 @@ def _survey(engine, seeds, n_ms, n_sats, label, FS=FS, N=N, regime="pull-in", lo
         print(f"[{label}] lock regime, seed offset {SEED_OFFSET}: {tally['n_locked']} of {tally['n']} channel-ms with locked = 1 "
               f"({tally['n_locked'] / max(1, tally['n']):.1%}), {tally['transitions']} lock <-> unlock transitions, "
               f"{tally['nudges']} watchdog nudges (flag mismatches {tally['nudge_bad']}), {tally['lost']} channels dropped by the "
-              f"watchdog; mismatching ms while locked {tally['bad_locked']}, while unlocked {tally['bad_unlocked']}")
+              f"watchdog; mismatching ms while locked {tally['bad_locked']}, while unlocked {tally['bad_unlocked']}; channels taken out of "
+              f"the comparison by a knife-edge lock verdict {tally['knife_edge']}, by an unlocked loop's separation "
+              f"{tally['unlocked_divergence']}, UNEXPLAINED {tally['unexplained']} ({tally['n_after_event']} channel-ms behind such events not compared)")
+        for line in tally["events"]:
+            print("   ", line)
     print(f"[{label}] {tally['n']} channel-ms over {len(seeds)} scenes at {FS / 1e6:.3f} Msps in {time.time() - t_start:.0f} s "
           f"({procs} oracle processes): pseudosymbol mismatches {tally['sym']}, code-phase {tally['cp']}, peak-offset "
           f"{tally['off']}, lock-flag {tally['lock']}; worst Doppler difference {tally['dop']:.2e} Hz; "
@@ -307,7 +358,8 @@ def test_tracking_survey_16368_throughput_kernel():
 
 
 # ------------------------------------------------------------------ the locked regime
-LOCK_TOTALS = {"n": 0, "n_locked": 0, "transitions": 0, "nudges": 0, "lost": 0, "runs": 0}
+LOCK_TOTALS = {"n": 0, "n_locked": 0, "transitions": 0, "nudges": 0, "lost": 0, "runs": 0, "knife_edge": 0, "unlocked_divergence": 0,
+               "n_after_event": 0}
 
 
 def _engine_for(fs, n, kernel, engine_factory):
@@ -327,34 +379,37 @@ def _engine_for(fs, n, kernel, engine_factory):
 
 
 @pytest.mark.parametrize("fs,kernel,n_scenes,long_scenes,seed0", [
-    (8_184_000, "speculative", 66, 2, 410000), (8_184_000, "throughput", 37, 1, 420000),
+    (8_184_000, "speculative", 50, 2, 410000), (8_184_000, "throughput", 28, 1, 420000),
     (2_046_000, "speculative", 42, 2, 430000), (2_046_000, "throughput", 21, 1, 440000),
-    (16_368_000, "speculative", 21, 1, 450000), (16_368_000, "throughput", 11, 1, 460000)])
+    (16_368_000, "speculative", 15, 1, 450000), (16_368_000, "throughput", 9, 1, 460000)])
 def test_locked_regime_survey(engine_factory, fs, kernel, n_scenes, long_scenes, seed0):
     """The regime a receiver that reaches a position fix lives in: channels that LOCK (tracker.py:157-203), so that the 3-Hz loop
     (tracker.py:251-256), the device's sliding-sum lock detector under lock, lock <-> unlock flapping near the thresholds and the
     speculative tracker's lock verdict are under the same statistical net as the pull-in regime of the surveys above (whose
-    sigma = 6a makes lock unreachable: VERDICT r04).  2-4 channels x 2500 ms per scene (the 250-ms window fills after a tenth of
-    it), a few scenes of 6300 ms whose channels start up to 250 Hz off in Doppler for the 6-second watchdog (nudge / drop).  Both
+    sigma = 6a makes lock unreachable: VERDICT r04).  2-4 channels x 2500 / 3500 / 4500 ms per scene by rate, a few scenes of 6300 ms whose channels start up to 250 Hz off in Doppler for the 6-second watchdog (nudge / drop).  Both
     tracking kernels, the reference's three recording rates.  Every integer equal, lock flag and watchdog nudge included."""
     n = fs // 1000
     eng, owned = _engine_for(fs, n, kernel, engine_factory)
     try:
-        t = _survey(eng, list(range(seed0, seed0 + n_scenes)), 2509, 0, f"lock regime, {kernel} {fs / 1e6:.3f} Msps", fs, n,
+        # (the reference's loop gains go with 1 / fs, tracker.py:227-244: pull-in takes ~0.3 s at 2.046 Msps, ~1.2 s at 8.184, ~2 s at 16.368)
+        n_ms = {2046: 2509, 8184: 3509, 16368: 4509}[n]
+        t = _survey(eng, list(range(seed0, seed0 + n_scenes)), n_ms, 0, f"lock regime, {kernel} {fs / 1e6:.3f} Msps", fs, n,
                     regime="lock", long_scenes=long_scenes)
     finally:
         if owned:
             eng.close()
-    msg = (t["first"], f"GYP_SURVEY_SEED={SEED_OFFSET}")
-    assert t["cp"] == 0 and t["off"] == 0 and t["lock"] == 0 and t["nudge_bad"] == 0, msg
+    msg = (t["first"], t["events"], f"GYP_SURVEY_SEED={SEED_OFFSET}")
+    assert t["unexplained"] == 0, msg
+    assert t["cp"] == 0 and t["off"] == 0 and t["lock"] == 0 and t["nudge_bad"] == 0, msg     # (of the milliseconds held to it: _sync_horizon)
     assert t["sym_locked"] == 0 and t["bad_locked"] == 0, msg
     assert t["sym_never_locked"] <= 2, msg       # float32 floor of an unlocked Costas loop (DESIGN section 5), counted, not hidden
+    assert t["knife_edge"] <= 3 and t["n_after_event"] <= 0.10 * t["n"], msg
     assert t["n_locked"] >= 0.4 * t["n"], (t["n_locked"], t["n"])      # the scenes really are in the regime they are named after
     if kernel == "throughput":
         assert t["fast"] == 0
     else:
         assert t["fast"] > 0.5 * t["n"]
-    for k in ("n", "n_locked", "transitions", "nudges", "lost"):
+    for k in ("n", "n_locked", "transitions", "nudges", "lost", "knife_edge", "unlocked_divergence", "n_after_event"):
         LOCK_TOTALS[k] += t[k]
     LOCK_TOTALS["runs"] += 1
 
@@ -365,7 +420,9 @@ def test_locked_regime_totals():
         pytest.skip("the six locked-regime surveys did not all run in this session")
     print(f"[lock regime, all six surveys] {LOCK_TOTALS['n']} channel-ms, {LOCK_TOTALS['n_locked']} with locked = 1 "
           f"({LOCK_TOTALS['n_locked'] / LOCK_TOTALS['n']:.1%}), {LOCK_TOTALS['transitions']} lock <-> unlock transitions, "
-          f"{LOCK_TOTALS['nudges']} watchdog nudges, {LOCK_TOTALS['lost']} channels dropped; seed offset {SEED_OFFSET}")
+          f"{LOCK_TOTALS['nudges']} watchdog nudges, {LOCK_TOTALS['lost']} channels dropped; knife-edge lock verdicts "
+          f"{LOCK_TOTALS['knife_edge']}, unlocked loops separated {LOCK_TOTALS['unlocked_divergence']} ({LOCK_TOTALS['n_after_event']} channel-ms "
+          f"behind them not compared); seed offset {SEED_OFFSET}")
     assert LOCK_TOTALS["n"] >= 1_000_000
     assert LOCK_TOTALS["n_locked"] >= 0.5 * LOCK_TOTALS["n"]
     assert LOCK_TOTALS["transitions"] >= 100

@@ -28,8 +28,8 @@ if __name__ == "__main__":
     regime = sys.argv[5] if len(sys.argv) > 5 else "pull-in"
     long_scenes = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     if regime == "lock":
-        t = ts._survey(eng, list(range(seed0, seed0 + n)), 2509, 0, "lock regime, " + (env or "speculative") + f" {fs / 1e6:.3f} Msps",
+        t = ts._survey(eng, list(range(seed0, seed0 + n)), {2046: 2509, 8184: 3509, 16368: 4509}.get(fs // 1000, 2509), 0, "lock regime, " + (env or "speculative") + f" {fs / 1e6:.3f} Msps",
                        fs, fs // 1000, regime="lock", long_scenes=long_scenes)
     else:
         t = ts._survey(eng, list(range(seed0, seed0 + n)), 1009, 12, (env or "speculative") + f" {fs / 1e6:.3f} Msps", fs, fs // 1000)
-    print({k: v for k, v in t.items() if k != "first"})
+    print({k: v for k, v in t.items() if k not in ("first", "events")})
