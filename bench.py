@@ -159,15 +159,23 @@ class Comm:
         self.dist.all_gather_object(out, float(x))
         return out
 
+    def gather_objects(self, x) -> list:
+        if self.dist is None:
+            return [x]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, x)
+        return out
+
     def close(self) -> None:
         if self.dist is not None:
             self.dist.destroy_process_group()
 
 
 class GpuTelemetry:
-    """Shader clock and package power while the timed region runs, from `rocm-smi --json` polled on a background thread (about one
-    sample per second; the driver's fresh box has measured ~6 % under the builder's lease at the same code -- this says whether
-    the clock explains it).  Reporting only: any failure ends up in the record as an error string."""
+    """Shader clock and package power under the benchmark's load, from `rocm-smi --json` polled on a background thread (about one
+    sample per second) while the SAME steps run once more, untimed, behind the timed region (r04 polled inside it: a fork / exec every
+    half second on the launching thread).  The driver's fresh box has measured ~6 % under the builder's lease at the same
+    code -- this says whether the clock explains it.  Reporting only: any failure ends up in the record as an error string."""
 
     def __init__(self, device: int, enabled: bool = True) -> None:
         import shutil
@@ -213,7 +221,7 @@ class GpuTelemetry:
             self._thr.join(timeout=25)
 
     def summary(self) -> dict:
-        out = {"samples": len(self.samples), "source": "rocm-smi --showclocks --showpower --json, polled during the timed region"}
+        out = {"samples": len(self.samples), "source": "rocm-smi --showclocks --showpower --json, polled during an untimed repetition of the same steps"}
         for key in ("sclk_mhz", "mclk_mhz", "power_w"):
             vals = [x[key] for x in self.samples if key in x]
             if vals:
@@ -262,6 +270,15 @@ def reference_bookkeeping_overheads(n: int) -> dict:
     return {"tracker_ms_overhead_s": per_ms, "acquisition_call_overhead_s": per_corr}
 
 
+def port_calibration(fs: int):
+    """profiles/r05_port_calibration.json: port throughput / reference throughput on cfg3's 10-s duty cycle at this rate, or None."""
+    try:
+        rec = json.loads((REPO / "profiles" / "r05_port_calibration.json").read_text())
+        return rec["rates"][str(fs)]["port_over_reference"]
+    except Exception:
+        return None
+
+
 def cpu_baseline_cfg3(fs: int, n: int) -> dict:
     """One host core, bounded sample of the same workload, median of three."""
     from gypsum_amd import synth
@@ -291,9 +308,15 @@ def cpu_baseline_cfg3(fs: int, n: int) -> dict:
     acq_ref, trk_ref = acq_s + ov["acquisition_call_overhead_s"] * n_calls, trk_s + ov["tracker_ms_overhead_s"]
     t_10s = 32 * acq_s + 10_000 * 12 * trk_s               # 10 s of one stream: one 32-sat scan + 10 000 ms x 12 channels
     t_10s_ref = 32 * acq_ref + 10_000 * 12 * trk_ref
+    cal = port_calibration(fs)
     return {
         "value": round(10.0 * fs / t_10s / 1e6, 5), "unit": "Msamples/s", "cores": 1, "kind": "port",
         "x_realtime": round(10.0 / t_10s, 5),
+        # throughput of this port / throughput of the unmodified reference, measured side by side in the build container
+        # (tools/calibrate_port.py -> profiles/r05_port_calibration.json): value / port_over_reference reads as a reference figure
+        "port_over_reference": cal,
+        "acq_s_per_sat": round(acq_s, 4), "track_ms_per_channel_ms": round(trk_s * 1e3, 4),
+        "sample_short": f"32 sats x {acq_s:.3f} s + 12 ch x 1e4 ms x {trk_s * 1e3:.3f} ms; 3 sats / 120 ms sampled, median of 3",
         "value_with_reference_bookkeeping": round(10.0 * fs / t_10s_ref / 1e6, 5),
         "sample": f"numpy oracle (reference algorithm, float64 pocketfft), median of 3: full 10-level acquisition "
                   f"{acq_s:.3f} s/sat, tracker {trk_s * 1e3:.3f} ms/channel-ms over 120 ms, at {fs / 1e6:.3f} Msps, scaled to "
@@ -497,17 +520,15 @@ def run_cfg3(eng, comm, args, rng, eng_scan=None) -> dict:
     elapsed = timed_steps(eng, comm, step, args.warmup, args.steps, extra_sync=others)
     # the same steps again, untimed, with rocm-smi polled beside them: shader clock and power UNDER this load without a fork / exec
     # every half second inside the metric; and a short pair with / without the D2H of the records
-    with GpuTelemetry(eng.device, enabled=comm.rank == 0 and not args.no_telemetry) as tele:      # (rank 0 only)
-        if comm.rank == 0 and not args.no_telemetry:
-            t_end = time.perf_counter() + 2.5
-            k = 0
-            while time.perf_counter() < t_end:
-                step(k); k += 1
-                if k % 4 == 0:
-                    eng.sync()
-            eng.sync()
-            for e in others:
-                e.sync()
+    n_tele = 0 if args.no_telemetry else max(2, int(math.ceil(2.5 / max(1e-3, comm.max(elapsed) / args.steps))))   # ~2.5 s, the same count on every rank
+    with GpuTelemetry(eng.device, enabled=comm.rank == 0 and not args.no_telemetry) as tele:      # (only rank 0 polls)
+        for k in range(n_tele):
+            step(k)
+            if k % 4 == 3:
+                eng.sync()
+        eng.sync()
+        for e in others:
+            e.sync()
     d2h_pair = None
     if d2h:
         reps_pair = max(2, min(args.steps, 4))
@@ -561,6 +582,15 @@ def run_cfg3(eng, comm, args, rng, eng_scan=None) -> dict:
     sym_ok = None
     state = su.bank.state()
     repairs = su.bank.dll_repairs()     # of the last tracking call (HIP-event loop above): the exact code loop's repair steps
+    import hashlib
+    eng.acquire_dev(su.iq.ptr.value, A, su.stride, 10, ALL_IDS, acq_send.ptr.value)
+    comm.allgather(acq_send, acq_recv, acq_bytes)
+    eng.sync()
+    mine = hashlib.sha256(acq_send.download(np.uint8, acq_bytes).tobytes()).hexdigest()[:16]
+    got = acq_recv.download(np.uint8, comm.world * acq_bytes)
+    slots = [hashlib.sha256(got[r_ * acq_bytes:(r_ + 1) * acq_bytes].tobytes()).hexdigest()[:16] for r_ in range(comm.world)]
+    sent = comm.gather_objects(mine)
+    acq_sha = {"sent_by_rank": sent, "received_on_rank0": slots, "gathered_equals_sent": slots == sent}
     locked_fraction = None
     if su.rec_dev is not None:
         rec_all = su.records()
@@ -574,16 +604,14 @@ def run_cfg3(eng, comm, args, rng, eng_scan=None) -> dict:
     return {
         "_su": su,
         "workload_name": "cfg3",
-        "config": {"workload": f"cfg3: synthetic IQ {fs / 1e6:.3f} Msps, {B} streams/GPU, 32-sat acquisition "
-                               f"({A} stream(s)/step = 1 scan per 10 s per stream) + 12-channel E-P-L tracking, "
-                               f"{T} ms of signal per stream per step; IQ resident in HBM (see h2d_inclusive for host-fed "
-                               f"figures and single_stream for the strict one-stream configuration)",
+        "config": {"workload": f"cfg3 {fs / 1e6:.3f}Msps x{B} streams/GPU: 32-sat acquire ({A} scans/step) + 12-ch E-P-L track {T}ms/step",
+                   "iq": "resident in HBM (host-fed: legs.h2d)", "records_d2h_in_timed_region": bool(d2h),
                    "sample_rate_hz": fs, "streams_per_gpu": B, "tracking_channels_per_stream": C_,
                    "track_ms_per_step": T, "acquisitions_per_step": A, "satellites_searched": 32,
-                   "parallelism": f"streams sharded over {comm.world} GPU(s), one ncclAllGather of acquisition records per step "
-                                  f"issued by the library (gyp_allgather_dev)"},
+                   "scene": "SURVEY d2: a*N=41, sigma=6a (lock unreachable; lock-regime legs: *_lock)",
+                   "parallelism": f"streams sharded over {comm.world} GPU(s), one ncclAllGather/step (gyp_allgather_dev)"},
         "samples_per_step": B * T * n, "elapsed": elapsed, "fs": fs, "streams_total": B * comm.world,
-        "telemetry": tele.summary(),
+        "telemetry": tele.summary(), "per_rank_acq_sha": acq_sha,
         "allgather": {"bytes_per_rank": acq_bytes, "ms_median_of_5": round(statistics.median(ag_ms), 4), "ms_first": round(ag_ms[0], 4),
                       "how": "hipEvents on the library's stream around gyp_allgather_dev alone, after a barrier, outside the timed region"},
         # per LAUNCH, like the rocprofv3 summary under profiles/ (a step's tracking is n_launch launches of T / n_launch ms each)
@@ -918,7 +946,11 @@ def run_cfg5(eng, comm, args, steps: int, warmup: int) -> dict:
                    "parallelism": f"Doppler bins (x 32 satellites) sharded over {comm.world} GPU(s), one ncclAllGather of cell records"},
         "samples_per_step": n_streams * n_ms * n, "elapsed": elapsed, "fs": fs, "streams_total": n_streams,
         "dominant": {"kernel": "grid_wipe_kernel<48, true> + grid_boxcar_kernel<48> + grid_cells_wave_shared_kernel<48, 8>", "ms": k_ms,
-                     "flops": n_mine * (n_ms * 6 * n + 2 * fft_flops(n) + 5 * n), "bytes": 8 * n * n_ms * n_streams + 32 * n_mine},
+                     # SURVEY section 8 d5 with the coherent pre-fold: the wipe-off is per (stream, bin, ms), the forward transform per
+                     # (stream, bin) -- shared by the 32 satellites -- and per cell one spectrum product, one inverse transform and the
+                     # magnitude pass: 29.2 GFLOP per stream for the full 200-bin grid
+                     "flops": n_streams * len(my_bins) * (n_ms * 6 * n + fft_flops(n)) + n_mine * (6 * n + fft_flops(n) + 5 * n),
+                     "bytes": 8 * n * n_ms * n_streams + 32 * n_mine},
         "extra": {"planted_sats_found_stream0": f"{hits}/8"},
     }
 
@@ -980,6 +1012,91 @@ def measured_traffic(workload: str):
         return rec.get("hbm_bytes_per_launch"), rec
     except Exception:
         return None, {}
+
+
+def _r(x, nd=3):
+    return round(float(x), nd) if isinstance(x, (int, float)) and not isinstance(x, bool) else x
+
+
+def compact_line(d: dict) -> dict:
+    """The one JSON line of stdout: every number DESIGN section 6 quotes, no prose (keys explained in profiles/BENCH_NOTES.md; the
+    full record with the method notes is the --detail-out file).  The driver's record keeps `roofline`, `cpu_baseline` and `config`
+    whole and a ~3 KB tail of the line: the legs come last."""
+    c = {k: d[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                           "dtype", "data")}
+    cfg = d["config"]
+    c["config"] = {k: (v if not isinstance(v, str) else v[:118]) for k, v in cfg.items()}
+    c["x_realtime_aggregate"], c["x_realtime_per_stream"] = d["x_realtime_aggregate"], d["x_realtime_per_stream"]
+    c["roofline"] = {k: v for k, v in d["roofline"].items() if k not in ("unit_per_launch", "algorithmic_flop_per_launch")}
+    cb = d.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "x_realtime", "port_over_reference", "acq_s_per_sat",
+                                                "track_ms_per_channel_ms") if k in cb}
+        c["cpu_baseline"]["sample"] = cb.get("sample_short", str(cb.get("sample", ""))[:110])
+    else:
+        c["cpu_baseline"] = None
+    ca = d.get("cpu_baseline_all_cores") or {}
+    if "value" in ca:
+        c["cpu_all_cores"] = {"value": ca["value"], "cores": ca["cores"], "sym_ok_f64_oracle": ca.get("symbol_agreement_ok_fraction_float64_oracle")}
+    if "acquire_ms_per_step" in d:
+        c["step_ms"] = {"acquire": d["acquire_ms_per_step"], "track": d["track_ms_per_step"],
+                        "acquire_no_reuse": d.get("acquire_ms_per_step_without_level_record_reuse"),
+                        "reuse_identical": d.get("level_record_reuse_gives_identical_results")}
+        c["sym_ok"], c["locked_fraction"] = d.get("symbol_agreement_ok_fraction"), d.get("locked_fraction")
+        c["acq_hits"], c["lost"] = d.get("acquisition_seed_hits"), d.get("channels_lost")
+        rp = d.get("dll_repair_steps") or {}
+        c["dll_repairs"] = rp.get("total")
+        if d.get("records_d2h"):
+            c["records_d2h"] = {"in_value": d.get("records_d2h_in_timed_region"), **{k: d["records_d2h"][k] for k in ("with_ms", "without_ms", "ratio")},
+                                "MB": round(d["records_d2h"]["bytes_per_step"] / 1e6, 1)}
+    t = d.get("gpu_telemetry_rank0") or {}
+    if t.get("samples"):
+        c["gpu"] = {k.split("_")[0]: [t[k]["min"], t[k]["median"], t[k]["max"]] for k in ("sclk_mhz", "power_w") if k in t}
+    co = d.get("collective", {})
+    c["collective"] = {k: co[k] for k in ("rank", "world", "uses_rccl", "ranks_launched", "fallback") if k in co}
+    if "allgather" in co:
+        c["collective"]["allgather_ms"] = co["allgather"]["ms_median_of_5"]
+        c["collective"]["bytes_per_rank"] = co["allgather"]["bytes_per_rank"]
+    if len(d["per_rank"]["ms_per_step"]) > 1:
+        c["per_rank"] = d["per_rank"]
+        c["cpu_baseline_note"] = d.get("cpu_baseline_note")
+    legs = {}
+
+    def single(name, key):
+        r = d.get(key)
+        if isinstance(r, dict) and "x_realtime" in r:
+            legs[name] = {"x": r["x_realtime"], "us_ms": r["us_per_ms_step"], "fast": _r(r["speculative_fast_path_fraction"], 4),
+                          "lk": r.get("locked_fraction"), "sym": _r(r.get("symbol_agreement_ok_fraction"), 3),
+                          "redo": (r.get("speculation_redo") or {}).get("sub_block_redos")}
+        elif isinstance(r, dict) and "error" in r:
+            legs[name] = {"error": r["error"][:80]}
+    for name, key in (("s8184", "single_stream"), ("s8184_lock", "single_stream_locked"), ("s2046", "single_stream_2046"),
+                      ("s2046_lock", "single_stream_2046_locked"), ("s16368", "single_stream_16368"), ("s16368_lock", "single_stream_16368_locked")):
+        single(name, key)
+    if isinstance(d.get("single_stream_snr"), list):
+        legs["snr_x"] = {str(p_["aN"]): p_["x_realtime"] for p_ in d["single_stream_snr"]}
+    for name, key in (("b2046", "batched_2046"), ("b8184_lock", "batched_locked")):
+        r = d.get(key)
+        if isinstance(r, dict) and "value" in r:
+            legs[name] = {"v": r["value"], "ms": r["ms_per_step"], "lk": r.get("locked_fraction"), "sym": _r(r.get("symbol_agreement_ok_fraction"), 3)}
+    h = d.get("h2d_inclusive")
+    if isinstance(h, dict) and "int8" in h:
+        legs["h2d"] = {"int8": h["int8"]["value"], "f32": h["float32"]["value"], "resident": h["resident"]["value"],
+                       "int8_over_resident": h["int8_over_resident"], "pcie_GBps": h["pinned_h2d_GBps"]}
+    oc = d.get("other_configs")
+    if isinstance(oc, dict):
+        for name in ("cfg2", "cfg5"):
+            r = oc.get(name)
+            if isinstance(r, dict) and "value" in r:
+                tr = (r.get("roofline_hbm") or {}).get("traffic")
+                legs[name] = {"v": r["value"], "ms": r["ms_per_step"], "valu": r["roofline_valu_frac"], "traffic_GB": _r(tr / 1e9, 3) if tr else None}
+        r = oc.get("cfg4_full_sky_acquisition")
+        if isinstance(r, dict) and "ms_per_scan_of_all_streams" in r:
+            legs["cfg4_scan64_ms"] = r["ms_per_scan_of_all_streams"]
+    if legs:
+        c["legs"] = legs
+    c["notes"] = "profiles/BENCH_NOTES.md"
+    return c
 
 
 def spawn_ranks(n: int, argv: list) -> int:
@@ -1087,14 +1204,16 @@ def main() -> None:
         # libgypsum_hip so that the process holds ONE ROCm stack.  The other order leaves RCCL talking to a second,
         # uninitialised HSA runtime (ncclCommInitRank: "no ROCm-capable device is detected").  INTEGRATION.md section 6.
         import torch  # noqa: F401
-    eng = GypsumEngine(local_rank)
+    dev_map = os.environ.get("GYP_BENCH_DEVICE_MAP")       # e.g. "0,0": two ranks on device 0 (tests/test_gpu_bench_n2.py; RCCL refuses
+    device = int(dev_map.split(",")[local_rank]) if dev_map else local_rank   # duplicate devices, so this goes with --allow-host-gather)
+    eng = GypsumEngine(device)
     # one process per GPU: this rank's host thread (launches, pinned staging buffers) belongs on its GPU's NUMA node
     host_bound = eng.bind_host_thread_to_gpu_node() if world > 1 else False
     comm = Comm(eng, rank, world, force_dist, args.allow_host_gather)
     rng = np.random.default_rng(20260925 + 7919 * rank)
 
     if args.workload == "cfg3":
-        eng_scan = GypsumEngine(local_rank) if args.overlap_scan else None
+        eng_scan = GypsumEngine(device) if args.overlap_scan else None
         result = run_cfg3(eng, comm, args, rng, eng_scan)
     elif args.workload == "cfg5":
         result = run_cfg5(eng, comm, args, args.steps, args.warmup)
@@ -1104,7 +1223,7 @@ def main() -> None:
     extras = {}
     solo = rank == 0 and world == 1
     if solo and args.workload == "cfg3" and not args.no_extras:
-        eng2 = GypsumEngine(local_rank)
+        eng2 = GypsumEngine(device)
 
         def snr_points():
             # the strict single stream against signal level (sigma = 0.03 fixed; a*N = 41 is the headline scene): where verifications
@@ -1123,7 +1242,17 @@ def main() -> None:
                 # the reference's third recording format (radio_input.py:111, 16x): same scene rule as tools/rate_probe.py (a N = 41, sigma = 6 a)
                 ("single_stream_16368", lambda: run_single_stream(eng, eng2, steps=3, warmup=1, fs=16_368_000, amplitude=41.0 / 16368,
                                                                   sigma=6 * 41.0 / 16368)),
-                ("single_stream_snr", snr_points))
+                ("single_stream_snr", snr_points),
+                # the regime a receiver that reaches a fix lives in: channels LOCKED (3-Hz loop, lock detector under lock); VERDICT r04 item 1
+                ("single_stream_locked", lambda: run_single_stream(eng, eng2, steps=4, warmup=1, seed=5151,
+                                                                   **dict(zip(("amplitude", "sigma"), lock_regime_amplitudes(8184))))),
+                ("single_stream_2046_locked", lambda: run_single_stream(eng, eng2, steps=4, warmup=1, fs=2_046_000, seed=5152,
+                                                                        **dict(zip(("amplitude", "sigma"), lock_regime_amplitudes(2046))))),
+                ("single_stream_16368_locked", lambda: run_single_stream(eng, eng2, steps=2, warmup=1, fs=16_368_000, seed=5153,
+                                                                         **dict(zip(("amplitude", "sigma"), lock_regime_amplitudes(16368))))),
+                # (the headline's samples per step as 32 streams x 4000 ms: channels are re-seeded every step and pull-in takes ~1.2 s at 8.184 Msps)
+                ("batched_locked", lambda: run_batched_rate(eng, comm, 8_184_000, B=32, T=4000,
+                                                            **dict(zip(("amplitude", "sigma"), lock_regime_amplitudes(8184))))))
         for name, fn in legs:
             try:
                 extras[name] = fn()
@@ -1159,54 +1288,69 @@ def main() -> None:
         value = total_samples / elapsed / 1e6
         dom = result["dominant"]
         traffic, traffic_rec = measured_traffic(result["workload_name"])
-        line = {
+        hbm_gbps = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+        valu_tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        extra = result["extra"]
+        k_ms = extra.get("track_kernels_ms_per_step", {})
+        k_vals = [v for v in k_ms.values() if isinstance(v, (int, float))]
+        # `roofline` names the BINDING resource (FP32 vector issue, not HBM, not MFMA) and carries the HBM view
+        # north_star asks for inside the same dict (the driver's record keeps this dict whole)
+        roofline = {"bound": "fp32_valu", "kernel": dom["kernel"], "achieved": round(valu_tf, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(valu_tf / VALU_PEAK_TFLOPS, 5),
+                    "valu_frac": round(valu_tf / VALU_PEAK_TFLOPS, 5), "valu_achieved_tflops": round(valu_tf, 3),
+                    "hbm_frac": round(hbm_gbps / HBM_PEAK_GBS, 5), "hbm_achieved_gbps": round(hbm_gbps, 2), "hbm_peak_gbps": HBM_PEAK_GBS,
+                    "algorithmic_flop_per_launch": dom["flops"], "algorithmic_bytes_per_launch": dom["bytes"],
+                    "traffic": traffic,
+                    "traffic_over_algorithmic": round(traffic / dom["bytes"], 3) if traffic else None,
+                    "traffic_stale": (bool(traffic_rec.get("kernel_ms_during_counter_pass")) and
+                                      abs(traffic_rec["kernel_ms_during_counter_pass"] / dom["ms"] - 1.0) > 0.15) if traffic_rec else None,
+                    "kernel_ms_per_launch": round(dom["ms"], 4),
+                    **({"launches_per_step": dom["launches_per_step"], "unit_per_launch": dom["unit_per_launch"]}
+                       if "launches_per_step" in dom else {}),
+                    **({"kernel_ms_per_step": {"track_block": k_vals[0], "dll_exact": k_vals[1], "dll_scan": k_vals[2]}} if len(k_vals) >= 3 else {})}
+        detail = {
             "metric": "iq_msamples_per_s_32sat_acquire_plus_track" if result["workload_name"] == "cfg3" else "iq_msamples_per_s_32sat_acquisition_grid",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": result.get("scaling", "weak"),
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic (generated on device; no recording ships with the reference)",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": result["config"],
             "x_realtime_aggregate": round(value * 1e6 / result["fs"], 2),
             "x_realtime_per_stream": round(value * 1e6 / result["fs"] / max(1, result["streams_total"]), 3),
-            "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 3),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "algorithmic_bytes_per_launch": dom["bytes"], "kernel_ms_per_launch": round(dom["ms"], 4),
-                         **({"launches_per_step": dom["launches_per_step"], "unit_per_launch": dom["unit_per_launch"]}
-                            if "launches_per_step" in dom else {}),
-                         "traffic": traffic,
-                         "traffic_source": "profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload "
-                                           "(tools/gpu_visit.sh pmc), counters corrected by the factors tools/fetch_calib.hip measured for "
-                                           "this access pattern; not collected inside this run",
-                         "traffic_record": {k: traffic_rec.get(k) for k in ("commit", "kernel_ms_during_counter_pass", "fetch_factor", "write_factor")},
-                         "traffic_stale": (bool(traffic_rec.get("kernel_ms_during_counter_pass")) and
-                                           abs(traffic_rec["kernel_ms_during_counter_pass"] / dom["ms"] - 1.0) > 0.15) if traffic_rec else None,
-                         "note": "algorithmic bytes (IQ read once + result records) / kernel time; this FFT/pointwise path "
-                                 "is FP32-VALU/LDS bound, see roofline_valu"},
-            "roofline_valu": {"bound": "fp32_valu", "kernel": dom["kernel"],
-                              "achieved": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12, 3), "peak": VALU_PEAK_TFLOPS,
-                              "unit": "TFLOP/s", "frac": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 5),
-                              "kernel_ms_per_launch": round(dom["ms"], 4)},
+            "roofline": roofline,
+            "roofline_notes": {"traffic_source": "profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload "
+                                                 "(tools/gpu_visit.sh pmc), counters corrected by the factors tools/fetch_calib.hip measured for "
+                                                 "this access pattern; not collected inside this run",
+                               "traffic_record": {k: traffic_rec.get(k) for k in ("commit", "kernel_ms_during_counter_pass", "fetch_factor", "write_factor")}},
             "collective": {**eng.comm_info(), "ranks_launched": world, **({"fallback": comm.fallback} if comm.fallback else {}),
-                           "device_ordinal_of_rank0": local_rank,
+                           "device_ordinal_of_rank0": device, **({"device_map": dev_map} if dev_map else {}),
                            "rank0_gpu_locality": {**{k: v for k, v in eng.locality().items() if k != "cpus"}, "host_thread_bound_to_it": host_bound},
                            "visible_devices_env": {k: os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")
                                                    if os.environ.get(k) is not None},
                            **({"allgather": result["allgather"]} if "allgather" in result else {})},
             "per_rank": {"ms_per_step": [round(t / args.steps * 1e3, 4) for t in per_rank_s],
                          "ms_per_step_min_max": [round(min(per_rank_s) / args.steps * 1e3, 4), round(max(per_rank_s) / args.steps * 1e3, 4)],
-                         "dominant_kernel_ms_per_launch": [round(t, 4) for t in per_rank_kernel_ms]},
+                         "dominant_kernel_ms_per_launch": [round(t, 4) for t in per_rank_kernel_ms],
+                         **({"acquisition_records_sha16": result["per_rank_acq_sha"]} if "per_rank_acq_sha" in result else {})},
             "gpu_telemetry_rank0": result.get("telemetry"),
-            **result["extra"], **extras,
+            **extra, **extras,
         }
         for k in ("cpu_baseline", "cpu_baseline_all_cores"):
             if k in result:
-                line[k] = result[k]
+                detail[k] = result[k]
         if world > 1:
-            line["cpu_baseline"] = None
-            line["cpu_baseline_note"] = ("measured on rank 0 at N = 1 only (the bench contract): the host-core baseline of this workload is "
-                                         "in the N = 1 line of the same round")
-        os.write(result_fd, (json.dumps(line) + "\n").encode())
+            detail["cpu_baseline"] = None
+            detail["cpu_baseline_note"] = "measured on rank 0 at N = 1 only (the bench contract)"
+        # the full record (every leg with its method notes) goes to a file; stdout carries the compact line, whose keys
+        # profiles/BENCH_NOTES.md explains, short enough for the driver's record to hold it whole
+        detail_path = Path(args.detail_out) if args.detail_out else REPO / "gpurun_out" / "bench_detail.json"
+        try:
+            detail_path.parent.mkdir(parents=True, exist_ok=True)
+            detail_path.write_text(json.dumps(detail, indent=1) + "\n")
+        except OSError as e:
+            print(f"bench.py: could not write {detail_path}: {e}", file=sys.stderr)
+        line = detail if args.verbose else compact_line(detail)
+        os.write(result_fd, (json.dumps(line, separators=(",", ":") if not args.verbose else None) + "\n").encode())
     comm.close()
 
 

@@ -1,6 +1,7 @@
 #!/bin/bash
 # One GPU visit (through gpurun), steps chosen by name:
 #   gpurun --timeout 1500 -- 'bash tools/gpu_visit.sh <tag> step [step ...]'
+# r05 steps: locktests  locksurveys  n2  bench5
 # steps: probe64  quick  newtests  abexact  tests  bench  benchfast  kt  pmc  pmcgrid  surveys  single  singleab  rate16  prof16  survey16  find4092  lanes  phases  acqtl
 set -u
 export GYP_TEST_HOOKS=1   # GypsumEngine forwards GYP_* switches (gyp_debug_set) only under this opt-in
@@ -79,6 +80,11 @@ l=json.loads(sys.stdin.read()); print({k:l[k] for k in ('value','ms_per_step','a
     locktests)
       timeout 900 python -m pytest tests/test_gpu_track_survey.py -x -q -m gpu -s -k "locked_regime" > $O/pytest_lock.log 2>&1
       echo "pytest rc=$?" >> $O/pytest_lock.log; grep -v "^$" $O/pytest_lock.log | cut -c1-600 | tail -40 ;;
+    n2)
+      timeout 900 python -m pytest tests/test_gpu_bench_n2.py -x -q -m gpu -rxXs > $O/pytest_n2.log 2>&1
+      echo "pytest rc=$?" >> $O/pytest_n2.log; grep -v "^$" $O/pytest_n2.log | cut -c1-400 | tail -25 ;;
+    bench5)
+      timeout 900 python bench.py --detail-out $O/bench_detail.json > $O/bench_cfg3.json 2> $O/bench_cfg3.err; echo "bench rc=$?"; wc -c $O/bench_cfg3.json; cat $O/bench_cfg3.json; tail -5 $O/bench_cfg3.err ;;
     locksurveys)
       # fresh seeds in the LOCK regime (synth.lock_regime_scene) through both tracking kernels at the reference's three recording rates
       export GYP_SURVEY_SEED=${LOCK_SEED_BASE:-0}
