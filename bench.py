@@ -648,8 +648,11 @@ def run_cfg3(eng, comm, args, rng, eng_scan=None) -> dict:
 def lock_regime_amplitudes(n: int) -> tuple:
     """(a, sigma) of a scene in which a 12-satellite stream LOCKS: is_locked() compares absolute variances of the
     un-normalised prompt peaks (var(I*Q) < 900, pole variance of I < 2, tracker.py:170-186); with eleven interfering satellites that
-    needs a*N ~ 16 and sigma^2 N ~ 0.3 (the oracle's channels lock 0.3-0.5 s into such a scene: tools/lock_scene_probe.py)."""
-    return 16.0 / n, math.sqrt(0.3 / n)
+    is interference-limited -- eleven equal-power satellites put ~ (a*N)^2 * 11 / 2046 on var(I), whatever sigma is -- and the loop
+    gains go with (a*N)^2 / fs (un-normalised Costas error, tracker.py:246-262): a*N = 18, sigma^2 N = 0.1 is where the float64 oracle's
+    channels lock soonest (tools/lock_scene_probe.py: two of four channels lock for good within 0.5-1 s at 8.184 Msps, the other two
+    flap between the 3-Hz and the 6-Hz loop 50-65 % locked)."""
+    return 18.0 / n, math.sqrt(0.1 / n)
 
 
 def run_single_stream(eng, eng2, steps: int = 10, warmup: int = 2, fs: int = 8_184_000, amplitude: float = None, sigma: float = None,
@@ -661,18 +664,21 @@ def run_single_stream(eng, eng2, steps: int = 10, warmup: int = 2, fs: int = 8_1
     su = Cfg3Setup(eng, rng, 1, T, seed, amplitude=amplitude, sigma=sigma, fs=fs)
     eng2.set_stream_format(su.fs, su.n)
     scan = eng2.alloc(32 * ACQ_RESULT.itemsize)
-    eng_copy = GypsumEngine(eng.device)
 
     def step(i: int) -> None:
+        # The records go out on the SCAN's stream, behind the scan of this step: a stream of its own for them would be the process's
+        # fifth busy HIP stream (tracking, verify, scan, scan helper), and with four hardware queues two of them then share one --
+        # measured: the scan no longer overlapped the tracking (44.0 ms per step against 41.0).  Slot i % 2 was copied out two steps
+        # ago; the wait (for copy i - 1, 0.13 ms of PCIe) comes BEFORE this step's scan is enqueued so that it does not wait for it.
+        eng.wait_for(eng2)
         eng2.acquire_dev(su.iq.ptr.value, 1, su.stride, 10, ALL_IDS, scan.ptr.value)
-        eng.wait_for(eng_copy)
         su.track(slot=i)
-        su.records_to_host(eng_copy, slot=i)
+        su.records_to_host(eng2, slot=i)
 
     class _NoComm:
         def barrier(self):
             pass
-    elapsed = timed_steps(eng, _NoComm(), step, warmup, steps, extra_sync=(eng2, eng_copy))
+    elapsed = timed_steps(eng, _NoComm(), step, warmup, steps, extra_sync=(eng2,))
     eng.timer_start(); su.track(); trk_ms = eng.timer_stop()
     eng2.timer_start(); eng2.acquire_dev(su.iq.ptr.value, 1, su.stride, 10, ALL_IDS, scan.ptr.value); acq_ms = eng2.timer_stop()
     rec = su.records()
@@ -697,7 +703,6 @@ def run_single_stream(eng, eng2, steps: int = 10, warmup: int = 2, fs: int = 8_1
         "channels_lost": int(su.bank.state()["lost"].sum()),
     }
     su.free_host()
-    eng_copy.close()
     su.bank.close()
     return out
 

@@ -1,7 +1,7 @@
 """Not a test: which (a*N, sigma^2 N) let a 12-SATELLITE stream lock?  The float64 oracle tracker (CPU) on scenes of twelve satellites:
 fraction of milliseconds with is_locked() and the number of lock <-> unlock transitions per channel.  bench.py's lock-regime legs
 (lock_regime_amplitudes: a*N = 16, sigma^2 N = 0.3) come from this table.
-    python tools/lock_scene_probe.py <fs> <n_ms>"""
+    python tools/lock_scene_probe.py <fs> <n_ms> [aN,aN,...] [v,v,...]"""
 import os, sys
 os.environ["OPENBLAS_NUM_THREADS"]="1"
 from pathlib import Path
@@ -30,6 +30,8 @@ def run(args):
     return (aN,v,ch,l.mean(), int(np.abs(np.diff(l)).sum()))
 if __name__=="__main__":
     fs=int(sys.argv[1]); n_ms=int(sys.argv[2])
-    jobs=[(fs,aN,v,12,77,n_ms,ch) for aN in (10,12,14,16) for v in (0.2,0.5) for ch in range(4)]
+    grid_a = [float(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else (10, 12, 14, 16)
+    grid_v = [float(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else (0.2, 0.5)
+    jobs=[(fs,aN,v,12,77,n_ms,ch) for aN in grid_a for v in grid_v for ch in range(4)]
     with mp.Pool(8) as p:
         for r in p.imap(run,jobs): print(r,flush=True)
