@@ -123,6 +123,8 @@ struct gyp_ctx {
     int track_chunk_ms = 500;     // gyp_debug_set("track_chunk_ms"): the throughput tracking kernel's launch length (0: whole blocks)
     float symbol_tau = 1e-4f;     // gyp_debug_set("symbol_tau"): |Re peak| / |peak| below which the pseudosymbol is decided in float64 (test hook: 10 = always)
     bool no_shared_fwd = false;   // gyp_debug_set("no_shared_fwd"): A/B switch: flat grids transform every cell's rows themselves again
+    int reserve_cus_per_xcc = 0;  // gyp_debug_set("reserve_cus_per_xcc", n): this context's own stream leaves the first n CUs of every XCC alone
+    bool no_grid_parts = false;   // gyp_debug_set("no_grid_parts"): A/B switch: flat-grid work items take whole units (no branch runs + merge)
     std::string err;
     // stream format
     int64_t fs = 0;
@@ -160,7 +162,7 @@ struct gyp_ctx {
     int track_launches = 0;     // launches of the tracking kernel behind the last timed call   // the events below have been recorded since timing was switched on (the speculative path records none)
     hipEvent_t ev_track[4] = {nullptr, nullptr, nullptr, nullptr};
     // growable scratch for the host-buffer entry points and the acquisition driver
-    static constexpr int kScratchSlots = 10;
+    static constexpr int kScratchSlots = 11;
     void* scratch[kScratchSlots] = {};
     size_t scratch_cap[kScratchSlots] = {};
 };
@@ -794,6 +796,7 @@ int gyp_correlate_grid_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams,
     p.replica_table = ctx->d_replicas;
     p.tw_tables = ctx->d_tw;
     p.inv_fs = 1.0 / (double)ctx->fs;
+    p.parts = 1; p.partial = nullptr;
     const int n_cells = n_streams * n_sats * n_bins;
     const int grid = std::max(1, std::min(n_cells, ctx->n_cus * blocks_per_cu(ctx->k)) & ~7);
     switch (ctx->k) {
@@ -827,12 +830,37 @@ int gyp_correlate_grid_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams,
         }                                                                                                                     \
         if (n_blk == 1 && gs_best > 1 && !ctx->no_pipe && !ctx->no_shared_fwd) { /* one wavefront per (unit, gs satellites) */ \
             const size_t lds = 2 * kTablesBytes + 8 * kXchWaveBytes + 8 * 8 * sizeof(SatStat);                                 \
-            const int n_groups = n_units * ((n_sats + gs_best - 1) / gs_best);                                                 \
+            int n_groups = n_units * ((n_sats + gs_best - 1) / gs_best);                                                       \
+            /* a chip the items do not fill runs a last round that is partly empty (config 5 on one GPU: 3200 items of 48 branches on  \
+               2048 wavefront slots, the second round 44 % empty): cut the K branches of a unit into `parts` runs -- the forward      \
+               transforms stay shared -- so that the rounds are shorter and the last one costs less; partial statistics are merged   \
+               by grid_merge_parts_kernel.  Rounds x branches per item, smallest wins, ties to fewer parts */                        \
+            int parts = 1;                                                                                                    \
+            if (!ctx->no_grid_parts) {                                                                                        \
+                const double slots = ctx->n_cus * 8.0;                                                                         \
+                double best = std::ceil(n_groups / slots) * K;                                                                  \
+                for (int pp = 2; pp <= K && pp <= 16; ++pp) {                                                                  \
+                    if (K % pp) continue;                                                                                      \
+                    const double t = std::ceil((double)n_groups * pp / slots) * (K / pp) + 0.25; /* (+: a merge launch) */       \
+                    if (t < best * 0.97) { best = t; parts = pp; }                                                             \
+                }                                                                                                             \
+            }                                                                                                                 \
+            p.parts = parts;                                                                                                  \
+            if (parts > 1) {                                                                                                  \
+                int rcp;                                                                                                      \
+                if ((rcp = ensure_scratch(ctx, 10, (size_t)n_cells * parts * sizeof(GridPartial)))) return rcp;                  \
+                p.partial = (GridPartial*)ctx->scratch[10];                                                                     \
+                n_groups *= parts;                                                                                            \
+            }                                                                                                                 \
             const int wgrid = std::max(1, std::min((n_groups + 7) / 8, ctx->n_cus));                                           \
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(grid_cells_wave_shared_kernel<K, 8>),              \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
             hipLaunchKernelGGL((grid_cells_wave_shared_kernel<K, 8>), dim3(wgrid), dim3(512), lds, ctx->stream, p, gs_best);  \
             HIP_TRY(ctx, hipGetLastError());                                                                                  \
+            if (parts > 1) {                                                                                                  \
+                hipLaunchKernelGGL(grid_merge_parts_kernel, dim3((n_cells + 255) / 256), dim3(256), 0, ctx->stream, p, n_cells); \
+                HIP_TRY(ctx, hipGetLastError());                                                                              \
+            }                                                                                                                 \
             return GYP_OK;                                                                                                    \
         }                                                                                                                     \
         if (n_blk == 1 && K % 2 == 0 && !ctx->no_pipe) { /* one wavefront per cell, 256 VGPRs, next row prefetched */              \
@@ -1862,15 +1890,45 @@ const DebugKnob kDebugKnobs[] = {
     {"no_pipe", 0, 1, true}, {"no_shared_fwd", 0, 1, true}, {"no_acq_split", 0, 1, true}, {"no_spec", 0, 1, true},
     {"spec_debug", 0, 1, true}, {"acq_lanes", 1, gyp_ctx::kMaxAcqLanes, true}, {"track_chunk_ms", 0, 1e6, true},
     {"symbol_tau", 0, 100, false}, {"dll_prov_bias", -1e6, 1e6, false}, {"spec_fail_at", -1, 2147483647.0, true},
-    {"spec_redo", 0, 1, true}, {"exact_prefetch", 0, 1, true}, {"prof_wave", 0, 7, true},
+    {"spec_redo", 0, 1, true}, {"exact_prefetch", 0, 1, true}, {"prof_wave", 0, 7, true}, {"no_grid_parts", 0, 1, true}, {"reserve_cus_per_xcc", 0, 16, true},
 };
 }  // namespace
+// "reserve_cus_per_xcc" n: the context's OWN stream is re-created with a CU mask (hipExtStreamCreateWithCUMask) that leaves CU 0 .. n-1 of
+// every XCC out.  Mask bit i is CU i / n_xcd of XCC i % n_xcd, and a mask that leaves an XCC without a CU is ignored
+// (tools/cu_mask_probe.hip).  What it is for: a receiver runs its 10-second satellite scan on a second context beside the twelve
+// one-CU-per-channel tracking workgroups; the scan's big launches take every CU they can (one 155-KB workgroup each), and a tracking
+// launch -- one per round, 97-148 KB of LDS per workgroup -- then waits for one of them to drain.  A scan stream that keeps off two CUs
+// per XCC (16 CUs for 12 channels) never holds a CU the channels need.
+static int apply_cu_reservation(gyp_ctx* ctx, int n) {
+    const int per_xcd = ctx->n_cus / ctx->n_xcd;
+    if (n < 0 || n >= per_xcd) return fail(ctx, GYP_E_BAD_ARG, "gyp_debug_set: reserve_cus_per_xcc must leave every XCC at least one CU");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t fresh = nullptr;
+    if (n == 0) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+    } else {
+        std::vector<uint32_t> mask((size_t)(ctx->n_cus + 31) / 32, 0u);
+        for (int i = n * ctx->n_xcd; i < ctx->n_cus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+        HIP_TRY(ctx, hipExtStreamCreateWithCUMask(&fresh, (uint32_t)mask.size(), mask.data()));
+    }
+    const bool was_own = ctx->stream == ctx->own_stream;
+    if (ctx->own_stream) {
+        (void)hipStreamSynchronize(ctx->own_stream);
+        (void)hipStreamDestroy(ctx->own_stream);
+    }
+    ctx->own_stream = fresh;
+    if (was_own) ctx->stream = fresh;
+    ctx->reserve_cus_per_xcc = n;
+    return GYP_OK;
+}
 static int debug_apply(gyp_ctx* ctx, const char* name, double v, bool set, double* out) {
     auto is = [&](const char* n) { return std::strcmp(name, n) == 0; };
 #define GYP_KNOB_BOOL(N, FIELD) if (is(N)) { if (set) ctx->FIELD = v != 0.0; else *out = ctx->FIELD ? 1.0 : 0.0; return GYP_OK; }
 #define GYP_KNOB_NUM(N, FIELD, T) if (is(N)) { if (set) ctx->FIELD = (T)v; else *out = (double)ctx->FIELD; return GYP_OK; }
     GYP_KNOB_BOOL("no_pipe", no_pipe)
     GYP_KNOB_BOOL("no_shared_fwd", no_shared_fwd)
+    GYP_KNOB_BOOL("no_grid_parts", no_grid_parts)
+    if (is("reserve_cus_per_xcc")) { if (set) return apply_cu_reservation(ctx, (int)v); *out = (double)ctx->reserve_cus_per_xcc; return GYP_OK; }
     GYP_KNOB_BOOL("no_acq_split", no_acq_split)
     GYP_KNOB_BOOL("no_spec", no_spec)
     GYP_KNOB_BOOL("spec_debug", spec_debug)

@@ -23,7 +23,12 @@ struct GridParams {
     const cf* replica_table;
     const cf* tw_tables;
     double inv_fs;
+    // grid_cells_wave_shared_kernel on a chip the grid does not fill: a unit's K polyphase branches are cut into `parts` runs, one work
+    // item each; the items write per-satellite partial statistics (GridPartial) which grid_merge_parts_kernel folds in branch order
+    int32_t parts;              // 1: whole units per item, results straight into `out`
+    struct GridPartial* partial;   // [n_streams][n_sats][n_bins][parts]
 };
+struct GridPartial { float v; int32_t key; int32_t cnt; int32_t pad; double sum; };
 
 // grid: (n_streams*n_bins, n_blk, R); block: 64*W threads
 template <int K, bool COHERENT>
@@ -330,17 +335,20 @@ __global__ __launch_bounds__(512, 2) void grid_cells_wave_shared_kernel(GridPara
     SatStat* stats = reinterpret_cast<SatStat*>(tiles + 8 * kXchWave) + wave * G;
     const LdsTables t{tw1024, tw2048};
     const int n_sg = (p.n_sats + gs - 1) / gs;
-    const int n_groups = p.n_streams * p.n_bins * n_sg;
+    const int parts = p.parts > 1 ? p.parts : 1;                 // runs of K / parts polyphase branches (the host picks a divisor of K)
+    const int n_groups = p.n_streams * p.n_bins * n_sg * parts;
     for (int v = blockIdx.x * 8 + wave; v < n_groups; v += gridDim.x * 8) {
-        // satellite groups vary fastest: the groups of one unit run back to back inside one XCD's slice (its rows leave HBM once)
-        const int grp = (n_groups & 7) ? v : xcd_contiguous(v >> 3, n_groups >> 3) * 8 + (v & 7);
+        // parts, then satellite groups vary fastest: the items of one unit run back to back inside one XCD's slice (its rows leave HBM once)
+        const int item = (n_groups & 7) ? v : xcd_contiguous(v >> 3, n_groups >> 3) * 8 + (v & 7);
+        const int part = item % parts, grp = item / parts;
         const int sg = grp % n_sg, unit_i = grp / n_sg;
         const int bin = unit_i % p.n_bins, stream = unit_i / p.n_bins;
         const int g_n = min(gs, p.n_sats - sg * gs);
         const cf* unit = p.folded + (int64_t)unit_i * K * 1024 + launder(l);
         if (lane < G) { SatStat z; z.v = -1.0f; z.key = 0x7fffffff; z.cnt = 0; z.pad = 0; z.sum = 0.0; stats[lane] = z; }
+        const int r_begin = part * (K / parts), r_end = r_begin + K / parts;
 #pragma unroll 1
-        for (int r = 0; r < K; ++r) {
+        for (int r = r_begin; r < r_end; ++r) {
             cf x[32];
             {
                 const cf* yw = unit + (int64_t)r * 1024;
@@ -386,11 +394,36 @@ __global__ __launch_bounds__(512, 2) void grid_cells_wave_shared_kernel(GridPara
         }
         if (lane < g_n) {
             const SatStat a = stats[lane];
-            gyp_cell o;
-            o.peak = a.v; o.argmax = a.key; o.sum = a.sum; o.n_max = a.cnt; o.reserved = 0; o.tap_re = 0.f; o.tap_im = 0.f;
-            p.out[(stream * p.n_sats + sg * gs + lane) * p.n_bins + bin] = o;
+            const int cell = (stream * p.n_sats + sg * gs + lane) * p.n_bins + bin;
+            if (parts == 1) {
+                gyp_cell o;
+                o.peak = a.v; o.argmax = a.key; o.sum = a.sum; o.n_max = a.cnt; o.reserved = 0; o.tap_re = 0.f; o.tap_im = 0.f;
+                p.out[cell] = o;
+            } else {
+                GridPartial o;
+                o.v = a.v; o.key = a.key; o.cnt = a.cnt; o.pad = 0; o.sum = a.sum;
+                p.partial[(int64_t)cell * parts + part] = o;
+            }
         }
     }
+}
+
+// The partial statistics of a cell's branch runs, folded in branch order exactly as the running statistics fold branches inside one
+// item (utils.py:111-116: max, first arg-max, sum, count of the max).  One thread per cell.
+__global__ void grid_merge_parts_kernel(GridParams p, int n_cells) {
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= n_cells) return;
+    const GridPartial* q = p.partial + (int64_t)cell * p.parts;
+    GridPartial a = q[0];
+    for (int i = 1; i < p.parts; ++i) {
+        const GridPartial b = q[i];
+        a.sum += b.sum;
+        if (b.v > a.v) { a.v = b.v; a.key = b.key; a.cnt = b.cnt; }
+        else if (b.v == a.v) { a.cnt += b.cnt; a.key = b.key < a.key ? b.key : a.key; }
+    }
+    gyp_cell o;
+    o.peak = a.v; o.argmax = a.key; o.sum = a.sum; o.n_max = a.cnt; o.reserved = 0; o.tap_re = 0.f; o.tap_im = 0.f;
+    p.out[cell] = o;
 }
 
 }  // namespace gyp

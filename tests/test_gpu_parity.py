@@ -326,6 +326,16 @@ def test_shared_forward_grid_kernel(engine_factory, fs):
         assert np.array_equal(g["n_max"], c["n_max"])
         np.testing.assert_allclose(g["peak"], c["peak"], rtol=3e-6)
         np.testing.assert_allclose(g["sum"], c["sum"], rtol=3e-6)
+        # r05: on a chip the grid does not fill, a unit's polyphase branches are cut into runs (one work item each) whose partial
+        # statistics grid_merge_parts_kernel folds in branch order: the same cells with whole units per item ("no_grid_parts")
+        eng.debug_set("no_grid_parts", 1)
+        try:
+            whole = eng.correlate_grid(two, 2, n_ms, sats, dopp, integ)
+        finally:
+            eng.debug_set("no_grid_parts", 0)
+        for f in ("argmax", "n_max", "peak"):
+            assert np.array_equal(g[f], whole[f]), f
+        np.testing.assert_allclose(g["sum"], whole["sum"], rtol=1e-12)
         for si in (0, 7, 8, 10):          # first group, its last satellite, the ragged group's first and last
             ref = np.abs(orc.integrate_correlation(kind, two[:n_ms * n], fs, n, dopp[0], orc.prn_as_complex(chips[sats[si] - 1], n)))
             assert g["argmax"][0, si, 0] == int(np.argmax(ref)), (si, integ)

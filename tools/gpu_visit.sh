@@ -80,6 +80,25 @@ l=json.loads(sys.stdin.read()); print({k:l[k] for k in ('value','ms_per_step','a
     locktests)
       timeout 900 python -m pytest tests/test_gpu_track_survey.py -x -q -m gpu -s -k "locked_regime" > $O/pytest_lock.log 2>&1
       echo "pytest rc=$?" >> $O/pytest_lock.log; grep -v "^$" $O/pytest_lock.log | cut -c1-600 | tail -40 ;;
+    gridparts)
+      timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "grid or config5" 2>&1 | tail -4
+      for v in 1 0; do
+        echo "== GYP_NO_GRID_PARTS=$v"
+        for W in cfg5 cfg2; do
+          GYP_NO_GRID_PARTS=$v timeout 300 python bench.py --workload $W --no-cpu-baseline --steps 10 --warmup 2 --verbose 2>/dev/null | python -c "
+import json,sys
+l=json.loads(sys.stdin.read()); print('$W', {k:l[k] for k in ('value','ms_per_step')}, l['roofline']['kernel_ms_per_launch'], l['roofline']['valu_frac'])"
+        done
+      done ;;
+    scanreserve)
+      for v in 0 2; do
+        echo "== GYP_BENCH_SCAN_RESERVE=$v"
+        GYP_BENCH_SCAN_RESERVE=$v timeout 600 python bench.py --no-cpu-baseline --steps 3 --warmup 1 --detail-out $O/bench_reserve$v.json 2>/dev/null | python -c "
+import json,sys
+l=json.loads(sys.stdin.read()); print({k:v for k,v in l['legs'].items() if k.startswith('s')})"
+      done ;;
+    knife2046)
+      GYP_SURVEY_SEED=0 timeout 600 python tools/big_survey.py 300 GYP_NO_SPEC 2046000 5300000 lock 3 2>&1 | grep -v "^$" | cut -c1-900 | tail -8 | tee $O/knife2046.txt ;;
     n2)
       timeout 900 python -m pytest tests/test_gpu_bench_n2.py -x -q -m gpu -rxXs > $O/pytest_n2.log 2>&1
       echo "pytest rc=$?" >> $O/pytest_n2.log; grep -v "^$" $O/pytest_n2.log | cut -c1-400 | tail -25 ;;
