@@ -57,7 +57,6 @@ from gypsum_amd.engine import GypsumEngine  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured achievable)
 VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector peak
 ALL_IDS = list(range(1, 33))
-SCAN_RESERVE_CUS = int(os.environ.get("GYP_BENCH_SCAN_RESERVE", "2"))   # single-stream legs: CUs per XCC the scan's stream leaves to the trackers
 
 
 def fft_flops(n: int) -> float:
@@ -665,9 +664,6 @@ def run_single_stream(eng, eng2, steps: int = 10, warmup: int = 2, fs: int = 8_1
     su = Cfg3Setup(eng, rng, 1, T, seed, amplitude=amplitude, sigma=sigma, fs=fs)
     eng2.set_stream_format(su.fs, su.n)
     scan = eng2.alloc(32 * ACQ_RESULT.itemsize)
-    # the scan's stream keeps off two CUs per XCC (gyp_debug_set "reserve_cus_per_xcc": 16 CUs for the 12 one-CU-per-channel tracking
-    # workgroups), so that a tracking round never waits for one of the scan's whole-CU workgroups to drain
-    eng2.debug_set("reserve_cus_per_xcc", SCAN_RESERVE_CUS)
 
     def step(i: int) -> None:
         # The records go out on the SCAN's stream, behind the scan of this step: a stream of its own for them would be the process's
@@ -706,8 +702,6 @@ def run_single_stream(eng, eng2, steps: int = 10, warmup: int = 2, fs: int = 8_1
         "records_d2h_in_timed_region": True,
         "channels_lost": int(su.bank.state()["lost"].sum()),
     }
-    out["scan_stream_reserved_cus_per_xcc"] = SCAN_RESERVE_CUS
-    eng2.debug_set("reserve_cus_per_xcc", 0)
     su.free_host()
     su.bank.close()
     return out

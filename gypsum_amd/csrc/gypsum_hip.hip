@@ -123,7 +123,6 @@ struct gyp_ctx {
     int track_chunk_ms = 500;     // gyp_debug_set("track_chunk_ms"): the throughput tracking kernel's launch length (0: whole blocks)
     float symbol_tau = 1e-4f;     // gyp_debug_set("symbol_tau"): |Re peak| / |peak| below which the pseudosymbol is decided in float64 (test hook: 10 = always)
     bool no_shared_fwd = false;   // gyp_debug_set("no_shared_fwd"): A/B switch: flat grids transform every cell's rows themselves again
-    int reserve_cus_per_xcc = 0;  // gyp_debug_set("reserve_cus_per_xcc", n): this context's own stream leaves the first n CUs of every XCC alone
     bool no_grid_parts = false;   // gyp_debug_set("no_grid_parts"): A/B switch: flat-grid work items take whole units (no branch runs + merge)
     std::string err;
     // stream format
@@ -1890,37 +1889,9 @@ const DebugKnob kDebugKnobs[] = {
     {"no_pipe", 0, 1, true}, {"no_shared_fwd", 0, 1, true}, {"no_acq_split", 0, 1, true}, {"no_spec", 0, 1, true},
     {"spec_debug", 0, 1, true}, {"acq_lanes", 1, gyp_ctx::kMaxAcqLanes, true}, {"track_chunk_ms", 0, 1e6, true},
     {"symbol_tau", 0, 100, false}, {"dll_prov_bias", -1e6, 1e6, false}, {"spec_fail_at", -1, 2147483647.0, true},
-    {"spec_redo", 0, 1, true}, {"exact_prefetch", 0, 1, true}, {"prof_wave", 0, 7, true}, {"no_grid_parts", 0, 1, true}, {"reserve_cus_per_xcc", 0, 16, true},
+    {"spec_redo", 0, 1, true}, {"exact_prefetch", 0, 1, true}, {"prof_wave", 0, 7, true}, {"no_grid_parts", 0, 1, true},
 };
 }  // namespace
-// "reserve_cus_per_xcc" n: the context's OWN stream is re-created with a CU mask (hipExtStreamCreateWithCUMask) that leaves CU 0 .. n-1 of
-// every XCC out.  Mask bit i is CU i / n_xcd of XCC i % n_xcd, and a mask that leaves an XCC without a CU is ignored
-// (tools/cu_mask_probe.hip).  What it is for: a receiver runs its 10-second satellite scan on a second context beside the twelve
-// one-CU-per-channel tracking workgroups; the scan's big launches take every CU they can (one 155-KB workgroup each), and a tracking
-// launch -- one per round, 97-148 KB of LDS per workgroup -- then waits for one of them to drain.  A scan stream that keeps off two CUs
-// per XCC (16 CUs for 12 channels) never holds a CU the channels need.
-static int apply_cu_reservation(gyp_ctx* ctx, int n) {
-    const int per_xcd = ctx->n_cus / ctx->n_xcd;
-    if (n < 0 || n >= per_xcd) return fail(ctx, GYP_E_BAD_ARG, "gyp_debug_set: reserve_cus_per_xcc must leave every XCC at least one CU");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t fresh = nullptr;
-    if (n == 0) {
-        HIP_TRY(ctx, hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
-    } else {
-        std::vector<uint32_t> mask((size_t)(ctx->n_cus + 31) / 32, 0u);
-        for (int i = n * ctx->n_xcd; i < ctx->n_cus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
-        HIP_TRY(ctx, hipExtStreamCreateWithCUMask(&fresh, (uint32_t)mask.size(), mask.data()));
-    }
-    const bool was_own = ctx->stream == ctx->own_stream;
-    if (ctx->own_stream) {
-        (void)hipStreamSynchronize(ctx->own_stream);
-        (void)hipStreamDestroy(ctx->own_stream);
-    }
-    ctx->own_stream = fresh;
-    if (was_own) ctx->stream = fresh;
-    ctx->reserve_cus_per_xcc = n;
-    return GYP_OK;
-}
 static int debug_apply(gyp_ctx* ctx, const char* name, double v, bool set, double* out) {
     auto is = [&](const char* n) { return std::strcmp(name, n) == 0; };
 #define GYP_KNOB_BOOL(N, FIELD) if (is(N)) { if (set) ctx->FIELD = v != 0.0; else *out = ctx->FIELD ? 1.0 : 0.0; return GYP_OK; }
@@ -1928,7 +1899,6 @@ static int debug_apply(gyp_ctx* ctx, const char* name, double v, bool set, doubl
     GYP_KNOB_BOOL("no_pipe", no_pipe)
     GYP_KNOB_BOOL("no_shared_fwd", no_shared_fwd)
     GYP_KNOB_BOOL("no_grid_parts", no_grid_parts)
-    if (is("reserve_cus_per_xcc")) { if (set) return apply_cu_reservation(ctx, (int)v); *out = (double)ctx->reserve_cus_per_xcc; return GYP_OK; }
     GYP_KNOB_BOOL("no_acq_split", no_acq_split)
     GYP_KNOB_BOOL("no_spec", no_spec)
     GYP_KNOB_BOOL("spec_debug", spec_debug)

@@ -3,6 +3,9 @@
 #pragma once
 #include "kernels_track_step.hpp"
 
+#ifndef GYP_EXPERIMENT_LEAVE_PF
+#define GYP_EXPERIMENT_LEAVE_PF 0   // 1 (r05 experiment, profiles/r05_experiments.txt): the throughput kernel's leaving ring entries prefetched a millisecond ahead by an idle wavefront
+#endif
 #ifndef GYP_EXPERIMENT_SKIP_UPDATE
 #define GYP_EXPERIMENT_SKIP_UPDATE 0   // 1 (development builds only): the throughput kernel without its Costas / lock-detector update -- how much of the kernel's time the serial update costs
 #endif
@@ -1017,6 +1020,8 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
     WinCache wcache;
     wcache.q = -1; wcache.qe = -1; wcache.ql = -1;
     bool have_prev = false;   // speculative mode: the previous millisecond's record (and possibly its histories) await completion
+    const int64_t n_first = GYP_EXPERIMENT_LEAVE_PF ? launder_lds(sm.red)->loop.n_steps : 0;   // (uniform: steps taken before this launch)
+    if (GYP_EXPERIMENT_LEAVE_PF && threadIdx.x == 0) sm.red->leave_for_ms = -1;
     for (int ms = ms_first; ms < ms_last; ++ms) {   // ([ms_first, ms_last) == [p.ms_begin, p.ms_end) except in a re-run from a later checkpoint and under the round protocol)
         gyp_track_rec* rec = p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + ms : nullptr;
         // (speculative mode: a load issued here would be waited for -- a few hundred cycles -- by the first carrier of the
@@ -1226,7 +1231,11 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
             constexpr int kW = Geom<K>::W;          // (rates whose workgroup has fewer than three wavefronts double up)
             if (wave == 0 && !GYP_EXPERIMENT_SKIP_UPDATE) {
                 const long long u0_ = prof ? (long long)__builtin_readcyclecounter() : 0;
-                fetch_leaving(st, red, leave);
+                if (GYP_EXPERIMENT_LEAVE_PF && kW >= 4 && red->leave_for_ms == ms) {
+                    leave[0] = red->leave_next[0]; leave[1] = red->leave_next[1]; leave[2] = red->leave_next[2];
+                } else {
+                    fetch_leaving(st, red, leave);
+                }
                 if (prof) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const long long u1_ = prof ? (long long)__builtin_readcyclecounter() : 0;
                 costas_update<K, false>(red->kc, st, red, t0, lane, m, leave);
@@ -1234,6 +1243,19 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
             }
             if (wave == (kW >= 2 ? 1 : 0)) dll_update(red, m.disc, lane, red->kc.lp);
             if (wave == (kW >= 3 ? 2 : 0)) spec_record_fields<K>(red, m, lane);
+            if (GYP_EXPERIMENT_LEAVE_PF && kW >= 4 && wave == 3 && ms + 1 < ms_last) {
+                // what fetch_leaving will want in the next millisecond's update (positions follow from the step count: the prologue
+                // derives them the same way), asked for now: the load's latency passes under wavefront 0's update and the next
+                // millisecond's transforms instead of at the head of the serial section
+                const int64_t n1 = n_first + (ms - ms_first) + 1;
+                double e = 0.0, pr_ = 0.0, pi_ = 0.0;
+                if (n1 >= kLockWindow) {
+                    const int pe = (int)(n1 % kLockWindow), pp = (int)(n1 % kPeakHistory);
+                    const int pl = pp >= kLockWindow ? pp - kLockWindow : pp - kLockWindow + kPeakHistory;
+                    e = st->err_ring[pe]; pr_ = st->peak_re[pl]; pi_ = st->peak_im[pl];
+                }
+                if (lane == 0) { red->leave_next[0] = e; red->leave_next[1] = pr_; red->leave_next[2] = pi_; red->leave_for_ms = ms + 1; }
+            }
             if constexpr (PRE) {   // (wavefront 0 gets here behind its update; a channel the watchdog has just dropped asks for samples nobody uses)
                 if (ms + 1 < ms_last) stage_fetch_own<K>(stream + (int64_t)(ms + 1) * N, pre, launder(threadIdx.x));
             }

@@ -508,8 +508,6 @@ int gyp_ingest_times(const gyp_ingest* ing, int64_t first_ms, int32_t n_ms, doub
  *                               launch partly empty (default: a unit's polyphase branches are cut into runs, merged afterwards)
  *   "no_acq_split" 0/1 (0)      a multi-stream scan runs on the caller's stream alone
  *   "acq_lanes" 1..4 (2)        parts a multi-stream scan is split into
- *   "reserve_cus_per_xcc" 0..(CUs per XCC - 1) (0)   the context's own stream is re-created with a CU mask that leaves the first n CUs of every
- *                               XCC alone (a scan context beside a receiver's one-CU-per-channel tracking: n = 2 keeps 16 CUs free); synchronises
  *   "no_spec" 0/1 (0)           lightly loaded banks use the throughput kernel too
  *   "spec_redo" 0/1 (1)         0: a failed speculation is re-run on the throughput kernel (r03 behaviour)
  *   "spec_debug" 0/1 (0)        per-ms window dump for gyp_debug_spec_read
