@@ -3,8 +3,9 @@
 Same public names as the reference (`GpsSatelliteId`, `GpsReplicaPrnSignal`,
 `generate_replica_prn_signals`, gps_ca_prn_codes.py:33-52,134-250) so receiver-side
 code can import either.  The device library generates the identical table
-internally (`gyp_get_prn_chips`); `tests/test_prn.py` checks the two against each
-other and against the frozen sha256 of SURVEY section 8(c5).
+internally (`gyp_prn_chips`); `tests/test_abi_and_host.py` checks the two against each
+other, against the reference's own table (`tests/golden/prn_chips.npz`) and against the
+frozen sha256 of SURVEY section 8(c5).
 
 Generator: two 10-stage LFSRs, both seeded all-ones.  G1 = x^10 + x^3 + 1,
 G2 = x^10 + x^9 + x^8 + x^6 + x^3 + x^2 + 1; chip = G1[10] ^ G2[tap_a] ^ G2[tap_b]
