@@ -161,8 +161,8 @@ struct RedScratch {
     // speculative tracker under the round protocol (SpecCtl, kernels_track_block.hpp): what this channel does in this launch
     int32_t ctl_sub, ctl_restore, ctl_nforce, ctl_pad;
     int32_t force_ms[8];   // milliseconds of the block that take the transform path whatever the window says (a verification failed there)
-    // GYP_EXPERIMENT_LEAVE_PF (r05 experiment, throughput kernel): the ring entries leaving the lock windows in the NEXT millisecond's
-    // update, fetched by an idle wavefront during this one's
+    // throughput kernel (GYP_EXPERIMENT_LEAVE_PF, kernels_track_block.hpp): the ring entries leaving the lock windows in the NEXT
+    // millisecond's update, fetched by an idle wavefront during this one's
     double leave_next[3];
     int32_t leave_for_ms, pad4;
 };

@@ -312,6 +312,7 @@ class TrackStepRecord:
     end_of_pseudosymbol: float
     nudged: bool = False        # the circularity watchdog changed Doppler / carrier phase after this millisecond
     lock_margin: float = math.inf   # min(lock_margins()) at the moment is_locked() was asked (Tracker.record_margins; test infrastructure)
+    argmax_margin: float = math.inf  # (largest - second largest) / largest of the prompt magnitudes (Tracker.record_margins): np.argmax's own margin
 
 
 class TrackingState:
@@ -420,6 +421,10 @@ class Tracker:
         mag = np.abs(c)
         s.non_coherent_correlation_profiles.append(mag)
         k = int(np.argmax(mag))
+        amargin = math.inf
+        if self.record_margins:            # test infrastructure: how close the second-largest magnitude comes (float32 peaks cannot split < ~1e-6)
+            top2 = np.partition(mag, -2)[-2:]
+            amargin = float((top2[1] - top2[0]) / top2[1]) if top2[1] > 0 else 0.0
         strength = float(peak_strength(mag))
         peak = complex(c[k])
         symbol = int(np.sign(peak.real))
@@ -448,7 +453,7 @@ class Tracker:
             doppler_used=float(f_used), carrier_phase_used=float(phi_used),
             doppler_after=float(s.current_doppler_shift),
             carrier_phase_after=float(s.current_carrier_wave_phase_shift),
-            start_of_pseudosymbol=start_time + delay, end_of_pseudosymbol=end_time + delay, lock_margin=margin,
+            start_of_pseudosymbol=start_time + delay, end_of_pseudosymbol=end_time + delay, lock_margin=margin, argmax_margin=amargin,
         )
         # --- 6-second circularity watchdog, tracker.py:370-387
         if start_time - self._last_circularity_check >= WATCHDOG_PERIOD_S:

@@ -39,7 +39,7 @@ def scene_inits(scene, rng):
 def run_scene(args):
     """args = (fs, n_ms, n_sats, seed, keep_iq_dir[, regime]).  Returns (seed, iq_path, inits, traj) with traj[ch] an int64/float64
     array of per-ms rows (pseudosymbol, code_phase_after, peak_offset, locked, doppler_after, lost_flag, nudged, lock_margin,
-    |Re peak| / |peak|)."""
+    |Re peak| / |peak|, argmax_margin)."""
     fs, n_ms, n_sats, seed, iq_dir = args[:5]
     regime = args[5] if len(args) > 5 else "pull-in"
     from gypsum_amd import synth
@@ -64,7 +64,7 @@ def run_scene(args):
     traj = []
     for sv, dop, phi, cp in inits:
         trk = orc.Tracker(orc.TrackingState(dop, phi, cp), orc.prn_as_complex(chips[sv - 1], n), fs, n)
-        rows = np.zeros((len(times), 9), dtype=np.float64)
+        rows = np.zeros((len(times), 10), dtype=np.float64)
         trk.record_margins = regime == "lock"
         for j, (st, en) in enumerate(times):
             ms = 9 + j
@@ -74,7 +74,7 @@ def run_scene(args):
                 rows[j:, 5] = 1.0
                 break
             rows[j] = (r.pseudosymbol, r.code_phase_after, r.peak_offset, float(r.locked), r.doppler_after, 0.0, float(r.nudged),
-                       r.lock_margin, abs(r.peak.real) / max(abs(r.peak), 1e-300))
+                       r.lock_margin, abs(r.peak.real) / max(abs(r.peak), 1e-300), r.argmax_margin)
         traj.append(rows)
     base = iq_dir or ("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir())
     path = os.path.join(base, f"gyp_survey_{os.getpid()}_{seed}.npy")

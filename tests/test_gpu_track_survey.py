@@ -53,6 +53,7 @@ print(f"[survey seeds] SEED_OFFSET = {SEED_OFFSET} (replay with GYP_SURVEY_SEED=
 
 
 KNIFE_EDGE = 1e-5      # relative distance of an is_locked() comparison from its threshold below which float32 peaks may decide it
+ARGMAX_EDGE = 2e-6     # relative gap between the two largest prompt magnitudes below which float32 magnitudes may order them differently
 
 
 def _sync_horizon(g, r, where, tally):
@@ -64,6 +65,10 @@ def _sync_horizon(g, r, where, tally):
       thousands of times, and where the reference's own float64 quantity sits within ~1e-6 (relative) of the threshold the device's
       float32 prompt peaks (3e-7) can land on the other side.  Accepted only if the ORACLE's margin at that millisecond is below
       KNIFE_EDGE; the loop bandwidth then differs for a millisecond and the trajectories are no longer the same experiment.
+    * a knife-edge arg-max: np.argmax over the prompt magnitudes (tracker.py:311), where the reference's two largest float64 magnitudes
+      differ by less than ARGMAX_EDGE (relative) -- adjacent lags on the flat top of a 16-samples-per-chip correlation in a low-noise
+      scene -- and the device's float32 magnitudes (3e-7) order them the other way.  The Costas loop then runs on the neighbouring
+      lag's (almost equal) peak.  Accepted only with the oracle's own gap below ARGMAX_EDGE.
     * an unlocked loop's sensitivity: a channel that has not locked for the whole preceding window (e.g. started 120 Hz off) is not
       contracting -- it amplifies rounding differences (the Doppler difference grows from 1e-9 to 1e-3 Hz over seconds before any
       integer differs).  Accepted only after >= 1000 ms, with the oracle unlocked throughout the preceding 250 ms and the two Doppler
@@ -79,12 +84,16 @@ def _sync_horizon(g, r, where, tally):
         return len(r)
     j = int(np.argmax(hard))
     ddop = float(abs(g["doppler_hz"][j - 1] - r[j - 1, 4])) if j else 0.0
-    what = f"{where} ms {9 + j}: lock gpu {int(g['locked'][j])} oracle {int(lk[j])} (oracle margin {r[j, 7]:.2e}), pseudosymbol gpu " \
+    what = f"{where} ms {9 + j}: lock gpu {int(g['locked'][j])} oracle {int(lk[j])} (oracle margin {r[j, 7]:.2e}), peak offset gpu " \
+           f"{int(g['peak_offset'][j])} oracle {int(r[j, 2])} (oracle's top-two gap {r[j, 9]:.2e}), pseudosymbol gpu " \
            f"{int(g['pseudosymbol'][j])} oracle {int(r[j, 0])}, code phase gpu {int(g['code_phase'][j])} oracle {int(r[j, 1])}, Doppler " \
            f"difference the ms before {ddop:.2e} Hz"
     if (g["locked"].astype(bool) != lk)[j] and r[j, 7] < KNIFE_EDGE:
         tally["knife_edge"] += 1
         tally["events"].append("knife-edge lock verdict: " + what)
+    elif g["peak_offset"][j] != int(r[j, 2]) and r[j, 9] < ARGMAX_EDGE:
+        tally["knife_edge_argmax"] += 1
+        tally["events"].append("knife-edge arg-max: " + what)
     elif j + 9 >= 1000 and not lk[max(0, j - 250):j + 1].any() and ddop > 1e-5:
         tally["unlocked_divergence"] += 1
         tally["events"].append("unlocked loop separated: " + what)
@@ -155,7 +164,7 @@ def _survey(engine, seeds, n_ms, n_sats, label, FS=FS, N=N, regime="pull-in", lo
     procs = max(1, min(64, (os.cpu_count() or 2) - 2, len(seeds)))
     tally = {"n": 0, "sym": 0, "cp": 0, "off": 0, "lock": 0, "dop": 0.0, "fast": 0, "first": [], "sym_locked": 0, "sym_never_locked": 0,
              "ch_locked": 0, "ch_never_locked": 0, "n_locked": 0, "bad_locked": 0, "bad_unlocked": 0, "transitions": 0, "nudges": 0,
-             "nudge_bad": 0, "lost": 0, "seed_offset": SEED_OFFSET, "regime": regime, "knife_edge": 0, "unlocked_divergence": 0,
+             "nudge_bad": 0, "lost": 0, "seed_offset": SEED_OFFSET, "regime": regime, "knife_edge": 0, "knife_edge_argmax": 0, "unlocked_divergence": 0,
              "unexplained": 0, "n_after_event": 0, "events": []}
     t_start = time.time()
     ctx = mp.get_context("spawn")      # the parent holds a HIP context: never fork it
@@ -173,7 +182,7 @@ def _survey(engine, seeds, n_ms, n_sats, label, FS=FS, N=N, regime="pull-in", lo
               f"({tally['n_locked'] / max(1, tally['n']):.1%}), {tally['transitions']} lock <-> unlock transitions, "
               f"{tally['nudges']} watchdog nudges (flag mismatches {tally['nudge_bad']}), {tally['lost']} channels dropped by the "
               f"watchdog; mismatching ms while locked {tally['bad_locked']}, while unlocked {tally['bad_unlocked']}; channels taken out of "
-              f"the comparison by a knife-edge lock verdict {tally['knife_edge']}, by an unlocked loop's separation "
+              f"the comparison by a knife-edge lock verdict {tally['knife_edge']}, by a knife-edge arg-max {tally['knife_edge_argmax']}, by an unlocked loop's separation "
               f"{tally['unlocked_divergence']}, UNEXPLAINED {tally['unexplained']} ({tally['n_after_event']} channel-ms behind such events not compared)")
         for line in tally["events"]:
             print("   ", line)
@@ -358,7 +367,7 @@ def test_tracking_survey_16368_throughput_kernel():
 
 
 # ------------------------------------------------------------------ the locked regime
-LOCK_TOTALS = {"n": 0, "n_locked": 0, "transitions": 0, "nudges": 0, "lost": 0, "runs": 0, "knife_edge": 0, "unlocked_divergence": 0,
+LOCK_TOTALS = {"n": 0, "n_locked": 0, "transitions": 0, "nudges": 0, "lost": 0, "runs": 0, "knife_edge": 0, "knife_edge_argmax": 0, "unlocked_divergence": 0,
                "n_after_event": 0}
 
 
@@ -403,13 +412,13 @@ def test_locked_regime_survey(engine_factory, fs, kernel, n_scenes, long_scenes,
     assert t["cp"] == 0 and t["off"] == 0 and t["lock"] == 0 and t["nudge_bad"] == 0, msg     # (of the milliseconds held to it: _sync_horizon)
     assert t["sym_locked"] == 0 and t["bad_locked"] == 0, msg
     assert t["sym_never_locked"] <= 2, msg       # float32 floor of an unlocked Costas loop, counted, not hidden
-    assert t["knife_edge"] <= 3 and t["n_after_event"] <= 0.10 * t["n"], msg
+    assert t["knife_edge"] + t["knife_edge_argmax"] <= 3 and t["n_after_event"] <= 0.10 * t["n"], msg
     assert t["n_locked"] >= 0.25 * t["n"], (t["n_locked"], t["n"])     # the scenes really are in the regime they are named after (all six: >= 50 %)
     if kernel == "throughput":
         assert t["fast"] == 0
     else:
         assert t["fast"] > 0.5 * t["n"]
-    for k in ("n", "n_locked", "transitions", "nudges", "lost", "knife_edge", "unlocked_divergence", "n_after_event"):
+    for k in ("n", "n_locked", "transitions", "nudges", "lost", "knife_edge", "knife_edge_argmax", "unlocked_divergence", "n_after_event"):
         LOCK_TOTALS[k] += t[k]
     LOCK_TOTALS["runs"] += 1
 
@@ -421,7 +430,7 @@ def test_locked_regime_totals():
     print(f"[lock regime, all six surveys] {LOCK_TOTALS['n']} channel-ms, {LOCK_TOTALS['n_locked']} with locked = 1 "
           f"({LOCK_TOTALS['n_locked'] / LOCK_TOTALS['n']:.1%}), {LOCK_TOTALS['transitions']} lock <-> unlock transitions, "
           f"{LOCK_TOTALS['nudges']} watchdog nudges, {LOCK_TOTALS['lost']} channels dropped; knife-edge lock verdicts "
-          f"{LOCK_TOTALS['knife_edge']}, unlocked loops separated {LOCK_TOTALS['unlocked_divergence']} ({LOCK_TOTALS['n_after_event']} channel-ms "
+          f"{LOCK_TOTALS['knife_edge']}, knife-edge arg-maxima {LOCK_TOTALS['knife_edge_argmax']}, unlocked loops separated {LOCK_TOTALS['unlocked_divergence']} ({LOCK_TOTALS['n_after_event']} channel-ms "
           f"behind them not compared); seed offset {SEED_OFFSET}")
     assert LOCK_TOTALS["n"] >= 1_000_000
     assert LOCK_TOTALS["n_locked"] >= 0.5 * LOCK_TOTALS["n"]

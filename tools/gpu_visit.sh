@@ -90,6 +90,17 @@ import json,sys
 l=json.loads(sys.stdin.read()); print('$W', {k:l[k] for k in ('value','ms_per_step')}, l['roofline']['kernel_ms_per_launch'], l['roofline']['valu_frac'])"
         done
       done ;;
+    thrtests)
+      # the throughput tracking kernel (MODE 0) through every survey and parity test that reaches it
+      timeout 900 python -m pytest tests/test_gpu_track_survey.py tests/test_gpu_parity.py tests/test_gpu_dll_exact.py tests/test_gpu_profiles.py -x -q -m gpu -s -k "throughput or no_pipe or excursions or parity or dll_exact or profiles or scene_26" > $O/pytest_thr.log 2>&1
+      echo "pytest rc=$?" >> $O/pytest_thr.log; grep -v "^$" $O/pytest_thr.log | cut -c1-500 | grep "^\[\|passed\|failed\|rc=\|UNEXPL\|knife" | tail -30 ;;
+    replay16)
+      GYP_SURVEY_SEED=7866000000 timeout 600 python -m pytest tests/test_gpu_track_survey.py -x -q -m gpu -s -k "16368000-speculative" 2>&1 | grep -v "^$" | cut -c1-700 | grep "^\[lock\|^    \|passed\|failed" | tail -8 ;;
+    cfg5)
+      timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "grid or config5" 2>&1 | tail -2
+      timeout 300 python bench.py --workload cfg5 --no-cpu-baseline --steps 10 --warmup 2 --verbose 2>/dev/null | python -c "
+import json,sys
+l=json.loads(sys.stdin.read()); print('cfg5', {k:l[k] for k in ('value','ms_per_step')}, l['roofline']['kernel_ms_per_launch'], l['roofline']['valu_frac'])" ;;
     knife2046)
       GYP_SURVEY_SEED=0 timeout 600 python tools/big_survey.py 300 GYP_NO_SPEC 2046000 5300000 lock 3 2>&1 | grep -v "^$" | cut -c1-900 | tail -8 | tee $O/knife2046.txt ;;
     n2)
