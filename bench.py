@@ -950,7 +950,7 @@ def run_cfg5(eng, comm, args, steps: int, warmup: int) -> dict:
                    "sample_rate_hz": fs, "streams_total": n_streams, "cells_total": int(n_total),
                    "parallelism": f"Doppler bins (x 32 satellites) sharded over {comm.world} GPU(s), one ncclAllGather of cell records"},
         "samples_per_step": n_streams * n_ms * n, "elapsed": elapsed, "fs": fs, "streams_total": n_streams,
-        "dominant": {"kernel": "grid_wipe_boxcar_kernel<48, true> + grid_cells_wave_shared_kernel<48, 8> (+ grid_merge_parts_kernel)", "ms": k_ms,
+        "dominant": {"kernel": "grid_wipe_kernel<48, true> + grid_boxcar_kernel<48> + grid_cells_wave_shared_kernel<48, 8> + grid_merge_parts_kernel", "ms": k_ms,
                      # SURVEY section 8 d5 with the coherent pre-fold: the wipe-off is per (stream, bin, ms), the forward transform per
                      # (stream, bin) -- shared by the 32 satellites -- and per cell one spectrum product, one inverse transform and the
                      # magnitude pass: 29.2 GFLOP per stream for the full 200-bin grid

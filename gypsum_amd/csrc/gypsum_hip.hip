@@ -801,10 +801,17 @@ int gyp_correlate_grid_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams,
     switch (ctx->k) {
 #define X(K)                                                                                                                  \
     case K: {                                                                                                                 \
-        if (K > 8) { /* wide rates: coalesced wipe-off into an LDS tile, the K-sample boxcar out of it (one kernel since r05) */ \
-            const dim3 wgrid(8, (unsigned)n_blk, (unsigned)n_units);                                                           \
-            if (coh) hipLaunchKernelGGL((grid_wipe_boxcar_kernel<K, true>), wgrid, dim3(128), 0, ctx->stream, p);            \
-            else hipLaunchKernelGGL((grid_wipe_boxcar_kernel<K, false>), wgrid, dim3(128), 0, ctx->stream, p);               \
+        if (K > 8) { /* wide rates: coalesced wipe-off into z, then the K-sample boxcar out of LDS tiles */                 \
+            const size_t zbytes = (size_t)n_units * n_blk * (K * kChips) * sizeof(cf);                                         \
+            int rcz;                                                                                                           \
+            if ((rcz = ensure_scratch(ctx, 6, zbytes))) return rcz;                                                            \
+            cf* zbuf = (cf*)ctx->scratch[6];                                                                                    \
+            const dim3 wgrid((unsigned)((K * kChips + 255) / 256), (unsigned)n_blk, (unsigned)n_units);                        \
+            if (coh) hipLaunchKernelGGL((grid_wipe_kernel<K, true>), wgrid, dim3(256), 0, ctx->stream, p, zbuf);              \
+            else hipLaunchKernelGGL((grid_wipe_kernel<K, false>), wgrid, dim3(256), 0, ctx->stream, p, zbuf);                 \
+            HIP_TRY(ctx, hipGetLastError());                                                                                  \
+            hipLaunchKernelGGL(grid_boxcar_kernel<K>, dim3(8, (unsigned)n_blk, (unsigned)n_units), dim3(128), 0, ctx->stream,   \
+                               p, (const cf*)zbuf, n_blk);                                                                     \
             HIP_TRY(ctx, hipGetLastError());                                                                                  \
         } else {                                                                                                              \
             const dim3 fgrid((unsigned)n_units, (unsigned)n_blk, (unsigned)Geom<K>::R);                                        \

@@ -54,39 +54,46 @@ __global__ __launch_bounds__(Geom<K>::kThreads) void grid_fold_kernel(GridParams
 
 // Wide rates (K > 8: 16.368 and 49.104 Msps).  The per-chip staging of stage_general reads K + 7 samples per chip and
 // round with an 8K-byte lane stride -- every 8-byte load pulls its own cache line, 6.9x over 6 rounds at K = 48.  The
-// fold is therefore a streaming kernel of its own, in two steps over an LDS tile of 128 chips (+ 1: chip 1023 is chip 0 again):
-//   wipe    z[n] = sum_b x_b[n] * carrier_b(n)        one sample per thread and pass, consecutive threads consecutive samples
-//           (perfectly coalesced); the block carriers follow from the first by one rotation per block (coherent: b over all n_ms)
-//   boxcar  y_r[m] = sum_{j<K} z[(K*m + r + j) mod N]  one thread per chip out of the tile (padded to K+1 complex per chip:
-//           conflict-free), as T(m) + sum_{i<r} (z_{m+1}[i] - z_m[i])
-// r01-r04 ran the two steps as two kernels with z in HBM between them (written once, read once: 0.63 GB of config 5's 1.28 GB per
-// step); fused, z never leaves the CU (the tile's one halo chip is wiped twice: 0.8 % more wipe-off).
-// grid: (8 tiles of 128 chips, n_blk, n_units); block 128
+// fold is therefore split in two streaming kernels:
+//   grid_wipe_kernel    z[n] = sum_b x_b[n] * carrier_b(n)        one thread per sample, perfectly coalesced; the block
+//                       carriers follow from the first by one rotation per block (coherent: b over all n_ms blocks)
+//   grid_boxcar_kernel  y_r[m] = sum_{j<K} z[(K*m + r + j) mod N]  one thread per chip out of an LDS tile of z (padded
+//                       to K+1 complex per chip: conflict-free), as T(m) + sum_{i<r} (z_{m+1}[i] - z_m[i])
+// grid: (ceil(N/256), n_blk, n_units); block 256.  zbuf: [unit][blk][N]
 template <int K, bool COHERENT>
-__global__ __launch_bounds__(128) void grid_wipe_boxcar_kernel(GridParams p) {
+__global__ __launch_bounds__(256) void grid_wipe_kernel(GridParams p, cf* __restrict__ zbuf) {
     constexpr int N = K * kChips;
-    constexpr int kTile = 128, kPitch = K + 1;
-    __shared__ cf tile[(kTile + 1) * kPitch];
-    const int unit = blockIdx.z, blk = blockIdx.y, m0 = blockIdx.x * kTile;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int unit = blockIdx.z, blk = blockIdx.y;
     const int stream = unit / p.n_bins, bin = unit % p.n_bins;
     const int n_blk = COHERENT ? 1 : p.n_ms;
     const double f = p.doppler[bin];
     const double du = f * p.inv_fs;
     const double u0_step = f * ((double)N * p.inv_fs);   // carrier cycles per block (utils.py:92-96)
-    const cf* src = p.iq + (int64_t)stream * p.stream_stride + (COHERENT ? 0 : (int64_t)blk * N);
+    const cf* src = p.iq + (int64_t)stream * p.stream_stride + (COHERENT ? 0 : (int64_t)blk * N) + n;
+    cf car = carrier_from_cycles_fast((COHERENT ? 0.0 : u0_step * (double)blk) + du * (double)n);
     const cf rot_blk = carrier_from_cycles_fast(u0_step);
-    const double u_blk = COHERENT ? 0.0 : u0_step * (double)blk;
+    cf acc = make_float2(0.f, 0.f);
     const int nb = COHERENT ? p.n_ms : 1;
-    for (int e = threadIdx.x; e < (kTile + 1) * K; e += kTile) {
+    for (int b = 0; b < nb; ++b) {
+        acc = cadd(acc, cmul(src[(int64_t)b * N], car));
+        car = cmul(car, rot_blk);
+    }
+    zbuf[((int64_t)unit * n_blk + blk) * N + n] = acc;
+}
+// grid: (8 tiles of 128 chips, n_blk, n_units); block 128
+template <int K>
+__global__ __launch_bounds__(128) void grid_boxcar_kernel(GridParams p, const cf* __restrict__ zbuf, int n_blk) {
+    constexpr int N = K * kChips;
+    constexpr int kTile = 128, kPitch = K + 1;
+    __shared__ cf tile[(kTile + 1) * kPitch];
+    const int unit = blockIdx.z, blk = blockIdx.y, m0 = blockIdx.x * kTile;
+    const cf* z = zbuf + ((int64_t)unit * n_blk + blk) * N;
+    for (int e = threadIdx.x; e < (kTile + 1) * K; e += kTile) {   // coalesced; chip 1023 is chip 0 again (circular)
         int g = K * m0 + e;
         g = g >= N ? g - N : g;
-        cf car = carrier_from_cycles_fast(u_blk + du * (double)g);
-        cf acc = make_float2(0.f, 0.f);
-        for (int b = 0; b < nb; ++b) {
-            acc = cadd(acc, cmul(src[(int64_t)b * N + g], car));
-            car = cmul(car, rot_blk);
-        }
-        tile[(e / K) * kPitch + (e % K)] = acc;
+        tile[(e / K) * kPitch + (e % K)] = z[g];
     }
     __syncthreads();
     const int m = m0 + threadIdx.x;
@@ -109,6 +116,9 @@ __global__ __launch_bounds__(128) void grid_wipe_boxcar_kernel(GridParams p) {
         out[(int64_t)r * 1024] = cadd(total, d);
     }
 }
+// (r05 measured the two steps FUSED -- wipe into the LDS tile, boxcar out of it, z never in HBM: config 5 went from 4.03 to 5.25 ms per
+// step.  The tile's 50 KB of LDS leave three 2-wavefront workgroups per CU, and a thread's ten dependent-address block loads per sample
+// then have nothing to hide behind; as a kernel of its own the wipe-off runs at full occupancy.  profiles/r05_experiments.txt item 6.)
 
 // grid-stride over cells (stream, sat, bin); block: 64*W threads
 template <int K, bool COHERENT>

@@ -11,7 +11,11 @@
 #define GYP_EXPERIMENT_LEAVE_PF 1
 #endif
 #ifndef GYP_MODE0_CANDIDATES
-#define GYP_MODE0_CANDIDATES 1   // 0 for an A/B build: the throughput kernel's whole Costas update on wavefront 0 again (costas_update)
+// 1 for an A/B build: the throughput kernel's Costas candidates on two more wavefronts, only the lock verdict serial (mode0_candidate /
+// mode0_verdict below, the speculative kernel's arrangement).  Measured in r05 (profiles/r05_experiments.txt item 7): same records (the
+// 83 throughput-kernel GPU tests pass), 30.92 ms per launch against 30.81 without it -- the shorter serial section is paid for with
+// three more spilled registers (9 against 6 at the 128-register budget) -- so the default stays 0 (costas_update on wavefront 0).
+#define GYP_MODE0_CANDIDATES 0
 #endif
 #ifndef GYP_EXPERIMENT_SKIP_UPDATE
 #define GYP_EXPERIMENT_SKIP_UPDATE 0   // 1 (development builds only): the throughput kernel without its Costas / lock-detector update -- how much of the kernel's time the serial update costs
