@@ -38,11 +38,11 @@ l=json.loads(sys.stdin.read()); print({k:l[k] for k in ('value','ms_per_step','a
     benchfast)
       timeout 600 python bench.py --no-cpu-baseline --no-extras > $O/bench_fast.json 2> $O/bench_fast.err; echo "benchfast rc=$?"; head -c 4000 $O/bench_fast.json; echo ;;
     kt)
-      timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_cfg3 -o bench -- python bench.py --no-cpu-baseline --no-extras > $O/kt_cfg3.log 2>&1
+      timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_cfg3 -o bench -- python bench.py --no-cpu-baseline --no-extras --no-telemetry > $O/kt_cfg3.log 2>&1
       rm -f $O/kt_cfg3/bench_kernel_trace.csv $O/kt_cfg3/*/bench_kernel_trace.csv $O/kt_cfg3/bench_agent_info.csv
       head -12 $O/kt_cfg3/bench_kernel_stats.csv | cut -c1-200 ;;
     pmc)
-      B="python bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1"
+      B="python bench.py --no-cpu-baseline --no-extras --no-telemetry --steps 2 --warmup 1"
       for c in FETCH_SIZE WRITE_SIZE; do
         timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${c} -o bench -- $B > $O/pmc_${c}.log 2>&1
       done
@@ -52,8 +52,8 @@ l=json.loads(sys.stdin.read()); print({k:l[k] for k in ('value','ms_per_step','a
       ls $O ;;
     pmcgrid)
       # other_configs' kernels: per-kernel times and HBM counters of the flat-grid workloads (each counter in a pass of its own)
-      for W in cfg2 cfg5; do
-        B="python bench.py --workload $W --no-cpu-baseline --steps 2 --warmup 1"
+      for W in ${GRID_WORKLOADS:-cfg2 cfg5}; do
+        B="python bench.py --workload $W --no-cpu-baseline --no-telemetry --steps 2 --warmup 1"
         timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$W -o bench -- $B > $O/kt_$W.log 2>&1
         rm -f $O/kt_$W/bench_kernel_trace.csv $O/kt_$W/*/bench_kernel_trace.csv $O/kt_$W/bench_agent_info.csv $O/kt_$W/*/bench_agent_info.csv
         for c in FETCH_SIZE WRITE_SIZE; do
