@@ -1266,8 +1266,8 @@ def main() -> None:
         try:
             small = argparse.Namespace(**{**vars(args), "streams": 128, "grid_ms": 64})
             extras["other_configs"] = {
-                "cfg2": summarise(run_grid(eng, comm, small, np.random.default_rng(5), "cfg2", 2, 1), 1, 2),
-                "cfg5": summarise(run_cfg5(eng, comm, small, 2, 1), 1, 2),
+                "cfg2": summarise(run_grid(eng, comm, small, np.random.default_rng(5), "cfg2", 4, 2), 1, 4),
+                "cfg5": summarise(run_cfg5(eng, comm, small, 8, 3), 1, 8),
                 "cfg4_full_sky_acquisition": run_full_sky_acquisition(eng)}
         except Exception as e:
             extras["other_configs"] = {"error": repr(e)}
