@@ -57,6 +57,7 @@ from gypsum_amd.engine import GypsumEngine  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured achievable)
 VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector peak
 ALL_IDS = list(range(1, 33))
+SCAN_CU_RESERVE = int(os.environ.get("GYP_BENCH_SCAN_CU_RESERVE", "16"))   # one-stream legs: CUs the scan's launches leave to the trackers
 
 
 def fft_flops(n: int) -> float:
@@ -664,6 +665,9 @@ def run_single_stream(eng, eng2, steps: int = 10, warmup: int = 2, fs: int = 8_1
     su = Cfg3Setup(eng, rng, 1, T, seed, amplitude=amplitude, sigma=sigma, fs=fs)
     eng2.set_stream_format(su.fs, su.n)
     scan = eng2.alloc(32 * ACQ_RESULT.itemsize)
+    # the scan's persistent launches leave two CUs per XCD to the twelve one-CU-per-channel tracking workgroups (gyp_debug_set
+    # "cells_cu_reserve"), so that a tracking round never waits for one of the scan's whole-CU workgroups to drain
+    eng2.debug_set("cells_cu_reserve", SCAN_CU_RESERVE)
 
     def step(i: int) -> None:
         # The records go out on the SCAN's stream, behind the scan of this step: a stream of its own for them would be the process's
@@ -702,6 +706,8 @@ def run_single_stream(eng, eng2, steps: int = 10, warmup: int = 2, fs: int = 8_1
         "records_d2h_in_timed_region": True,
         "channels_lost": int(su.bank.state()["lost"].sum()),
     }
+    out["scan_cu_reserve"] = SCAN_CU_RESERVE
+    eng2.debug_set("cells_cu_reserve", 0)
     su.free_host()
     su.bank.close()
     return out

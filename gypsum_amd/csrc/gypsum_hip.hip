@@ -123,6 +123,7 @@ struct gyp_ctx {
     int track_chunk_ms = 500;     // gyp_debug_set("track_chunk_ms"): the throughput tracking kernel's launch length (0: whole blocks)
     float symbol_tau = 1e-4f;     // gyp_debug_set("symbol_tau"): |Re peak| / |peak| below which the pseudosymbol is decided in float64 (test hook: 10 = always)
     bool no_shared_fwd = false;   // gyp_debug_set("no_shared_fwd"): A/B switch: flat grids transform every cell's rows themselves again
+    int cells_cu_reserve = 0;     // gyp_debug_set("cells_cu_reserve", n): CUs the correlation-cell launches leave free (see launch_cells)
     bool no_grid_parts = false;   // gyp_debug_set("no_grid_parts"): A/B switch: flat-grid work items take whole units (no branch runs + merge)
     std::string err;
     // stream format
@@ -575,10 +576,16 @@ static int launch_k(gyp_ctx* ctx, KernelT kernel, int k, int grid, const ParamsT
 
 
 static int launch_cells(gyp_ctx* ctx, const CellsParams& p, int integration) {
-    const int grid = std::max(1, std::min(p.n_cells, ctx->n_cus * blocks_per_cu(ctx->k)) & ~7);
+    // gyp_debug_set "cells_cu_reserve" n: the correlation-cell launches of this context (acquisition levels, gyp_correlate_cells) size
+    // their persistent grids for n fewer CUs.  A receiver's scan context sets it: the scan's workgroups take a whole CU each (155 KB of
+    // LDS) and hold it for the length of the launch, so a tracking round of the bank -- one 97-148 KB workgroup per channel, launched
+    // every few hundred microseconds -- otherwise waits for one of them to drain; with 16 CUs (two per XCD: workgroup b runs on XCD
+    // b % 8) never taken by the scan the trackers always find room.  The cells are walked grid-stride: same results.
+    const int cus = std::max(ctx->n_xcd, ctx->n_cus - ctx->cells_cu_reserve);
+    const int grid = std::max(1, std::min(p.n_cells, cus * blocks_per_cu(ctx->k)) & ~7);
     const bool coh = integration == GYP_COHERENT;
     if (!coh && ctx->k == 8 && !ctx->no_pipe) {   // one pipelined workgroup per CU (256 VGPRs, double-buffered LDS)
-        const int grid1 = std::max(1, std::min(p.n_cells, ctx->n_cus) & ~7);
+        const int grid1 = std::max(1, std::min(p.n_cells, cus) & ~7);
         return p.prof ? launch_k(ctx, corr_cells_pipe_kernel<8, true>, 8, grid1, p, lds_bytes_pipe<8>())
                       : launch_k(ctx, corr_cells_pipe_kernel<8, false>, 8, grid1, p, lds_bytes_pipe<8>());
     }
@@ -1032,7 +1039,7 @@ static gyp_ctx* acquire_helper(gyp_ctx* ctx, int which) {
         if (gyp_set_stream_format(h, ctx->fs, ctx->n) != GYP_OK) return nullptr;
     h->params = ctx->params;
     // the helper runs under the caller's switches (it never read an environment of its own)
-    h->no_pipe = ctx->no_pipe; h->no_shared_fwd = ctx->no_shared_fwd; h->symbol_tau = ctx->symbol_tau;
+    h->no_pipe = ctx->no_pipe; h->no_shared_fwd = ctx->no_shared_fwd; h->symbol_tau = ctx->symbol_tau; h->cells_cu_reserve = ctx->cells_cu_reserve;
     h->track_chunk_ms = ctx->track_chunk_ms; h->no_spec = ctx->no_spec;
     return h;
 }
@@ -1889,7 +1896,7 @@ const DebugKnob kDebugKnobs[] = {
     {"no_pipe", 0, 1, true}, {"no_shared_fwd", 0, 1, true}, {"no_acq_split", 0, 1, true}, {"no_spec", 0, 1, true},
     {"spec_debug", 0, 1, true}, {"acq_lanes", 1, gyp_ctx::kMaxAcqLanes, true}, {"track_chunk_ms", 0, 1e6, true},
     {"symbol_tau", 0, 100, false}, {"dll_prov_bias", -1e6, 1e6, false}, {"spec_fail_at", -1, 2147483647.0, true},
-    {"spec_redo", 0, 1, true}, {"exact_prefetch", 0, 1, true}, {"prof_wave", 0, 7, true}, {"no_grid_parts", 0, 1, true},
+    {"spec_redo", 0, 1, true}, {"exact_prefetch", 0, 1, true}, {"prof_wave", 0, 7, true}, {"no_grid_parts", 0, 1, true}, {"cells_cu_reserve", 0, 128, true},
 };
 }  // namespace
 static int debug_apply(gyp_ctx* ctx, const char* name, double v, bool set, double* out) {
@@ -1899,6 +1906,7 @@ static int debug_apply(gyp_ctx* ctx, const char* name, double v, bool set, doubl
     GYP_KNOB_BOOL("no_pipe", no_pipe)
     GYP_KNOB_BOOL("no_shared_fwd", no_shared_fwd)
     GYP_KNOB_BOOL("no_grid_parts", no_grid_parts)
+    GYP_KNOB_NUM("cells_cu_reserve", cells_cu_reserve, int)
     GYP_KNOB_BOOL("no_acq_split", no_acq_split)
     GYP_KNOB_BOOL("no_spec", no_spec)
     GYP_KNOB_BOOL("spec_debug", spec_debug)

@@ -508,6 +508,8 @@ int gyp_ingest_times(const gyp_ingest* ing, int64_t first_ms, int32_t n_ms, doub
  *                               launch partly empty (default: a unit's polyphase branches are cut into runs, merged afterwards)
  *   "no_acq_split" 0/1 (0)      a multi-stream scan runs on the caller's stream alone
  *   "acq_lanes" 1..4 (2)        parts a multi-stream scan is split into
+ *   "cells_cu_reserve" 0..128 (0)  CUs the correlation-cell launches of this context leave free (a receiver's scan context beside its
+ *                               one-CU-per-channel trackers: 16 = two per XCD); same results, the cells are walked grid-stride
  *   "no_spec" 0/1 (0)           lightly loaded banks use the throughput kernel too
  *   "spec_redo" 0/1 (1)         0: a failed speculation is re-run on the throughput kernel (r03 behaviour)
  *   "spec_debug" 0/1 (0)        per-ms window dump for gyp_debug_spec_read
