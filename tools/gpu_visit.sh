@@ -101,6 +101,13 @@ l=json.loads(sys.stdin.read()); print('$W', {k:l[k] for k in ('value','ms_per_st
       timeout 300 python bench.py --workload cfg5 --no-cpu-baseline --steps 10 --warmup 2 --verbose 2>/dev/null | python -c "
 import json,sys
 l=json.loads(sys.stdin.read()); print('cfg5', {k:l[k] for k in ('value','ms_per_step')}, l['roofline']['kernel_ms_per_launch'], l['roofline']['valu_frac'])" ;;
+    scanab)
+      for v in 0 16 32; do
+        echo "== GYP_BENCH_SCAN_CU_RESERVE=$v"
+        GYP_BENCH_SCAN_CU_RESERVE=$v timeout 300 python bench.py --no-cpu-baseline --steps 3 --warmup 1 --detail-out $O/bench_scanab$v.json 2>/dev/null | python -c "
+import json,sys
+l=json.loads(sys.stdin.read()); print({k:(v['x'], v['us_ms']) for k,v in l['legs'].items() if k.startswith('s') and isinstance(v, dict) and 'x' in v}, l['legs'].get('snr_x'))"
+      done ;;
     knife2046)
       GYP_SURVEY_SEED=0 timeout 600 python tools/big_survey.py 300 GYP_NO_SPEC 2046000 5300000 lock 3 2>&1 | grep -v "^$" | cut -c1-900 | tail -8 | tee $O/knife2046.txt ;;
     n2)
