@@ -16,12 +16,16 @@ Workload cfg3 (default; BASELINE.json configs[2], the configuration the >= 200x 
       (pseudosymbol, peak, Doppler, ...) written for every channel.
   N > 1: every rank owns B streams (weak scaling); the only exchange is one all-gather of the acquisition records per
   step, ncclAllGather over RCCL issued by the library on its own stream (gyp_allgather_dev), no host synchronisation.
-`value` is the batched figure with the IQ resident in HBM.  On one GPU the JSON line also carries
-  single_stream   the STRICT configs[2]: ONE 8.184 Msps stream, one 32-satellite scan per 10 s of signal (on a second
-                  HIP stream, beside the tracking) + 12-channel tracking, per-ms records, in steps of 10 s of signal;
-  h2d_inclusive   the same tracking + acquisition fed from page-locked host memory every step (float32 as the
-                  reference's files hold it, and int8 widened on the device), upload overlapped with compute;
-  other_configs   one-launch figures of configs[1] (cfg2) and configs[4] (cfg5).
+`value` is the batched figure with the IQ resident in HBM and -- from r05 on -- every step's per-ms records copied to page-locked host
+memory inside the timed region (gyp_memcpy_d2h_async on a copy stream; --no-records-d2h leaves them in HBM).  stdout carries ONE compact JSON
+line (keys: profiles/BENCH_NOTES.md); the full record goes to --detail-out.  On one GPU the line's `legs` also carry
+  s8184 / s2046 / s16368        the STRICT configs[2] at the reference's three recording rates: ONE stream, one 32-satellite scan per 10 s of
+                                signal (on a second HIP stream, beside the tracking) + 12-channel tracking, per-ms records copied to the host,
+                                in steps of 10 s of signal; *_lock: the same on scenes in which the channels LOCK (lock_regime_amplitudes);
+  h2d                           the headline batch fed from page-locked host memory every step (int8 widened on the device, and float32 as
+                                the reference's files hold it), upload overlapped with compute;
+  b2046 / b8184_lock            the headline's shape at 2.046 Msps / on lock-regime scenes;
+  cfg2 / cfg5 / cfg4_scan64_ms  one-launch figures of the flat-grid configurations and the 64-stream full-sky acquisition.
 Workload cfg2 (configs[1]): 2.046 Msps, 32 satellites x range(-5000, 5000, 500) Hz x 1 ms flat grid.
 Workload cfg4 (configs[3]): the cfg2 grid on 64 concurrent streams in total, streams sharded over the ranks (strong
   scaling); per (stream-ms, satellite) the best bin is selected on the device (acquisition.py:180-189) and ONE
@@ -29,9 +33,9 @@ Workload cfg4 (configs[3]): the cfg2 grid on 64 concurrent streams in total, str
 Workload cfg5 (configs[4]): 49.104 Msps, 32 satellites x range(-10000, 10000, 100) Hz, 10 ms coherent; the Doppler axis
   (x 32 satellites = 6400 cells) is sharded over the ranks (strong scaling), one all-gather of the cell records.
 
-`roofline` is the HBM view north_star asks for, `roofline_valu` the FP32 vector view (the resource that actually binds
-this FFT/pointwise path); `cpu_baseline` is the numpy oracle -- the reference's algorithm -- timed on this
-box's host cores on a bounded sample.
+`roofline` names the BINDING resource (`bound: fp32_valu`: FP32 vector issue) and carries the HBM view
+north_star asks for in the same dict (`hbm_frac`, `hbm_achieved_gbps`, `traffic`); `cpu_baseline` is the numpy oracle -- the reference's
+algorithm -- timed on this box's host cores on a bounded sample, with `port_over_reference` from tools/calibrate_port.py.
 """
 from __future__ import annotations
 
