@@ -61,7 +61,7 @@ from gypsum_amd.engine import GypsumEngine  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured achievable)
 VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector peak
 ALL_IDS = list(range(1, 33))
-SCAN_CU_RESERVE = int(os.environ.get("GYP_BENCH_SCAN_CU_RESERVE", "16"))   # one-stream legs: CUs the scan's launches leave to the trackers
+SCAN_CU_RESERVE = int(os.environ.get("GYP_BENCH_SCAN_CU_RESERVE", "64"))   # one-stream legs: CUs the scan's launches leave to the trackers and their verify kernels
 
 
 def fft_flops(n: int) -> float:
@@ -669,8 +669,9 @@ def run_single_stream(eng, eng2, steps: int = 10, warmup: int = 2, fs: int = 8_1
     su = Cfg3Setup(eng, rng, 1, T, seed, amplitude=amplitude, sigma=sigma, fs=fs)
     eng2.set_stream_format(su.fs, su.n)
     scan = eng2.alloc(32 * ACQ_RESULT.itemsize)
-    # the scan's persistent launches leave two CUs per XCD to the twelve one-CU-per-channel tracking workgroups (gyp_debug_set
-    # "cells_cu_reserve"), so that a tracking round never waits for one of the scan's whole-CU workgroups to drain
+    # the scan's persistent launches leave eight CUs per XCD to the twelve one-CU-per-channel tracking workgroups and the verify kernels of
+    # their rounds (gyp_debug_set "cells_cu_reserve"), so that neither waits for one of the scan's whole-CU workgroups to drain
+    # (profiles/r05_experiments.txt item 8: 0 / 16 / 64 / 128 measured)
     eng2.debug_set("cells_cu_reserve", SCAN_CU_RESERVE)
 
     def step(i: int) -> None:
@@ -1255,7 +1256,7 @@ def main() -> None:
                 ("single_stream_2046", lambda: run_single_stream(eng, eng2, fs=2_046_000)),
                 ("batched_2046", lambda: run_batched_rate(eng, comm, 2_046_000)),
                 # the reference's third recording format (radio_input.py:111, 16x): same scene rule as tools/rate_probe.py (a N = 41, sigma = 6 a)
-                ("single_stream_16368", lambda: run_single_stream(eng, eng2, steps=3, warmup=1, fs=16_368_000, amplitude=41.0 / 16368,
+                ("single_stream_16368", lambda: run_single_stream(eng, eng2, steps=5, warmup=2, fs=16_368_000, amplitude=41.0 / 16368,
                                                                   sigma=6 * 41.0 / 16368)),
                 ("single_stream_snr", snr_points),
                 # the regime a receiver that reaches a fix lives in: channels LOCKED (3-Hz loop, lock detector under lock); VERDICT r04 item 1
@@ -1263,7 +1264,7 @@ def main() -> None:
                                                                    **dict(zip(("amplitude", "sigma"), lock_regime_amplitudes(8184))))),
                 ("single_stream_2046_locked", lambda: run_single_stream(eng, eng2, steps=4, warmup=1, fs=2_046_000, seed=5152,
                                                                         **dict(zip(("amplitude", "sigma"), lock_regime_amplitudes(2046))))),
-                ("single_stream_16368_locked", lambda: run_single_stream(eng, eng2, steps=2, warmup=1, fs=16_368_000, seed=5153,
+                ("single_stream_16368_locked", lambda: run_single_stream(eng, eng2, steps=4, warmup=2, fs=16_368_000, seed=5153,
                                                                          **dict(zip(("amplitude", "sigma"), lock_regime_amplitudes(16368))))),
                 # (the headline's samples per step as 32 streams x 4000 ms: channels are re-seeded every step and pull-in takes ~1.2 s at 8.184 Msps)
                 ("batched_locked", lambda: run_batched_rate(eng, comm, 8_184_000, B=32, T=4000,
