@@ -1181,6 +1181,8 @@ def main() -> None:
     ap.add_argument("--no-telemetry", action="store_true", help="skip the untimed repetition that samples shader clock / power under load")
     ap.add_argument("--detail-out", default=None, help="where the full record goes (every leg with its method notes; default "
                                                        "gpurun_out/bench_detail.json); stdout carries the compact line")
+    ap.add_argument("--only-legs", default=None, help="comma-separated subset of the extra legs (single_stream, h2d_inclusive, single_stream_2046, "
+                                                      "batched_2046, single_stream_16368, single_stream_snr, single_stream_locked, ...)")
     ap.add_argument("--verbose", action="store_true", help="print the full record on stdout instead of the compact line")
     ap.add_argument("--no-extras", action="store_true", help="skip single_stream / h2d_inclusive / other_configs")
     ap.add_argument("--overlap-scan", action="store_true",
@@ -1228,19 +1230,21 @@ def main() -> None:
     comm = Comm(eng, rank, world, force_dist, args.allow_host_gather)
     rng = np.random.default_rng(20260925 + 7919 * rank)
 
-    if args.workload == "cfg3":
-        eng_scan = GypsumEngine(device) if args.overlap_scan else None
-        result = run_cfg3(eng, comm, args, rng, eng_scan)
-    elif args.workload == "cfg5":
-        result = run_cfg5(eng, comm, args, args.steps, args.warmup)
-    else:
-        result = run_grid(eng, comm, args, rng, args.workload, args.steps, args.warmup)
-
     extras = {}
     solo = rank == 0 and world == 1
-    if solo and args.workload == "cfg3" and not args.no_extras:
-        eng2 = GypsumEngine(device)
+    with_extras = solo and args.workload == "cfg3" and not args.no_extras
+    eng2 = GypsumEngine(device) if with_extras else None
 
+    def run_legs(legs) -> None:
+        for name, fn in legs:
+            if args.only_legs and name not in args.only_legs.split(","):
+                continue
+            try:
+                extras[name] = fn()
+            except Exception as e:       # a reported extra, never a reason to lose the bench line
+                extras[name] = {"error": repr(e)}
+
+    if with_extras:
         def snr_points():
             # the strict single stream against signal level (sigma = 0.03 fixed; a*N = 41 is the headline scene): where verifications
             # start to fail, sub-blocks are tracked again -- profiles/r03_snr_sweep.txt has the full sweep of the r03 code
@@ -1251,29 +1255,38 @@ def main() -> None:
                                                             "speculation_redo", "acquisition_seed_hits", "channels_lost")}})
             return out
 
-        legs = (("single_stream", lambda: {**run_single_stream(eng, eng2), "method": SINGLE_STREAM_METHOD}),
-                ("h2d_inclusive", lambda: run_h2d(eng, eng2, result["_su"])),
-                ("single_stream_2046", lambda: run_single_stream(eng, eng2, fs=2_046_000)),
-                ("batched_2046", lambda: run_batched_rate(eng, comm, 2_046_000)),
-                # the reference's third recording format (radio_input.py:111, 16x): same scene rule as tools/rate_probe.py (a N = 41, sigma = 6 a)
-                ("single_stream_16368", lambda: run_single_stream(eng, eng2, steps=5, warmup=2, fs=16_368_000, amplitude=41.0 / 16368,
-                                                                  sigma=6 * 41.0 / 16368)),
-                ("single_stream_snr", snr_points),
-                # the regime a receiver that reaches a fix lives in: channels LOCKED (3-Hz loop, lock detector under lock); VERDICT r04 item 1
-                ("single_stream_locked", lambda: run_single_stream(eng, eng2, steps=4, warmup=1, seed=5151,
-                                                                   **dict(zip(("amplitude", "sigma"), lock_regime_amplitudes(8184))))),
-                ("single_stream_2046_locked", lambda: run_single_stream(eng, eng2, steps=4, warmup=1, fs=2_046_000, seed=5152,
-                                                                        **dict(zip(("amplitude", "sigma"), lock_regime_amplitudes(2046))))),
-                ("single_stream_16368_locked", lambda: run_single_stream(eng, eng2, steps=4, warmup=2, fs=16_368_000, seed=5153,
-                                                                         **dict(zip(("amplitude", "sigma"), lock_regime_amplitudes(16368))))),
-                # (the headline's samples per step as 32 streams x 4000 ms: channels are re-seeded every step and pull-in takes ~1.2 s at 8.184 Msps)
-                ("batched_locked", lambda: run_batched_rate(eng, comm, 8_184_000, B=32, T=4000,
-                                                            **dict(zip(("amplitude", "sigma"), lock_regime_amplitudes(8184))))))
-        for name, fn in legs:
-            try:
-                extras[name] = fn()
-            except Exception as e:       # a reported extra, never a reason to lose the bench line
-                extras[name] = {"error": repr(e)}
+        def lock_kw(n):
+            return dict(zip(("amplitude", "sigma"), lock_regime_amplitudes(n)))
+
+        # The ONE-STREAM legs run first, before the batched ones heat the chip: a one-stream receiver keeps 12 of 256 CUs busy and finds the
+        # GPU at its idle clock, and these legs are latency-bound, so they follow the shader clock one for one -- behind the 1.2-kW batched
+        # legs (sclk 2.33-2.36 instead of 2.40 GHz) the same leg measures 3-4 % less (16.368 Msps: 144.0 x there, 150.4 x on its own;
+        # profiles/r05_experiments.txt item 9).  r01-r04 ran them behind the headline.
+        run_legs((("single_stream", lambda: {**run_single_stream(eng, eng2), "method": SINGLE_STREAM_METHOD}),
+                  ("single_stream_2046", lambda: run_single_stream(eng, eng2, fs=2_046_000)),
+                  # the reference's third recording format (radio_input.py:111, 16x): same scene rule as tools/rate_probe.py (a N = 41, sigma = 6 a)
+                  ("single_stream_16368", lambda: run_single_stream(eng, eng2, steps=5, warmup=2, fs=16_368_000, amplitude=41.0 / 16368,
+                                                                    sigma=6 * 41.0 / 16368)),
+                  ("single_stream_snr", snr_points),
+                  # the regime a receiver that reaches a fix lives in: channels LOCKED (3-Hz loop, lock detector under lock); VERDICT r04 item 1
+                  ("single_stream_locked", lambda: run_single_stream(eng, eng2, steps=4, warmup=1, seed=5151, **lock_kw(8184))),
+                  ("single_stream_2046_locked", lambda: run_single_stream(eng, eng2, steps=4, warmup=1, fs=2_046_000, seed=5152, **lock_kw(2046))),
+                  ("single_stream_16368_locked", lambda: run_single_stream(eng, eng2, steps=4, warmup=2, fs=16_368_000, seed=5153,
+                                                                           **lock_kw(16368)))))
+
+    if args.workload == "cfg3":
+        eng_scan = GypsumEngine(device) if args.overlap_scan else None
+        result = run_cfg3(eng, comm, args, rng, eng_scan)
+    elif args.workload == "cfg5":
+        result = run_cfg5(eng, comm, args, args.steps, args.warmup)
+    else:
+        result = run_grid(eng, comm, args, rng, args.workload, args.steps, args.warmup)
+
+    if with_extras:
+        run_legs((("h2d_inclusive", lambda: run_h2d(eng, eng2, result["_su"])),
+                  ("batched_2046", lambda: run_batched_rate(eng, comm, 2_046_000)),
+                  # (the headline's samples per step as 32 streams x 4000 ms: channels are re-seeded every step and pull-in takes ~1.2 s at 8.184 Msps)
+                  ("batched_locked", lambda: run_batched_rate(eng, comm, 8_184_000, B=32, T=4000, **lock_kw(8184)))))
         try:
             small = argparse.Namespace(**{**vars(args), "streams": 128, "grid_ms": 64})
             extras["other_configs"] = {

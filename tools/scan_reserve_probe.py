@@ -13,6 +13,21 @@ if __name__ == "__main__":
     fs = int(sys.argv[1])
     n = fs // 1000
     eng, eng2 = GypsumEngine(0), GypsumEngine(0)
+    import os
+    import numpy as np
+    pre = os.environ.get("GYP_PROBE_PRE", "")
+    keep = []
+    if "helper" in pre:       # what the headline run leaves behind: eng's helper contexts of a split scan (a second HIP stream)
+        eng.set_stream_format(8_184_000, 8184)
+        su0 = bench.Cfg3Setup(eng, np.random.default_rng(1), 16, 20, 1, records=False)
+        keep.append(su0)
+    if "alloc" in pre:        # ... and ~9 GB of live allocations
+        keep.append(eng.alloc(9 << 30))
+    if "bank" in pre:         # ... and a 1536-channel bank with its records
+        eng.set_stream_format(8_184_000, 8184)
+        su1 = bench.Cfg3Setup(eng, np.random.default_rng(2), 128, 100, 2)
+        su1.track(); eng.sync()
+        keep.append(su1)
     for r in [int(a) for a in sys.argv[2:]]:
         bench.SCAN_CU_RESERVE = r
         kw = dict(amplitude=41.0 / n, sigma=6 * 41.0 / n) if n == 16368 else {}
