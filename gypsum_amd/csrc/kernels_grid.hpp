@@ -341,10 +341,10 @@ __global__ __launch_bounds__(512, 2) void grid_cells_wave_shared_kernel(GridPara
     const int parts = p.parts > 1 ? p.parts : 1;                 // runs of K / parts polyphase branches (the host picks a divisor of K)
     const int n_groups = p.n_streams * p.n_bins * n_sg * parts;
     for (int v = blockIdx.x * 8 + wave; v < n_groups; v += gridDim.x * 8) {
-        // parts, then satellite groups vary fastest: the items of one unit run back to back inside one XCD's slice (its rows leave HBM once)
+        // satellite groups vary fastest, then the branch runs: the groups that read the SAME rows of a unit are neighbouring wavefronts of
+        // one workgroup (the rows come out of L1 / L2 for all but the first), and a unit's items run back to back inside one XCD's slice
         const int item = (n_groups & 7) ? v : xcd_contiguous(v >> 3, n_groups >> 3) * 8 + (v & 7);
-        const int part = item % parts, grp = item / parts;
-        const int sg = grp % n_sg, unit_i = grp / n_sg;
+        const int sg = item % n_sg, part = (item / n_sg) % parts, unit_i = item / (n_sg * parts);
         const int bin = unit_i % p.n_bins, stream = unit_i / p.n_bins;
         const int g_n = min(gs, p.n_sats - sg * gs);
         const cf* unit = p.folded + (int64_t)unit_i * K * 1024 + launder(l);
