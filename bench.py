@@ -1212,8 +1212,10 @@ def main() -> None:
         comm.barrier()
         top = comm.max(float(rank))
         seen = comm.gather_floats(float(rank))             # the per-rank figures of the N > 1 line travel this way
+        tags = comm.gather_objects(f"rank{rank}")          # ... and the per-rank record hashes (per_rank.acquisition_records_sha16)
         if rank == 0:
             os.write(result_fd, (json.dumps({"rendezvous_only": True, "n_gpus": world, "max_rank_seen": int(top), "ranks_gathered": [int(x) for x in seen],
+                                             "objects_gathered": tags,
                                              "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}) + "\n").encode())
         comm.close()
         return

@@ -36,6 +36,7 @@ def test_gpus_8_self_spawns_and_gathers_per_rank_figures():
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 8 and line["max_rank_seen"] == 7 and line["ranks_gathered"] == list(range(8))
+    assert line["objects_gathered"] == [f"rank{r}" for r in range(8)]      # (how the per-rank acquisition-record hashes reach rank 0)
 
 
 def test_launched_by_torchrun_style_environment_too():
