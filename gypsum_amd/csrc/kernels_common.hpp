@@ -163,8 +163,10 @@ struct RedScratch {
     int32_t force_ms[8];   // milliseconds of the block that take the transform path whatever the window says (a verification failed there)
     // throughput kernel (GYP_EXPERIMENT_LEAVE_PF, kernels_track_block.hpp): the ring entries leaving the lock windows in the NEXT
     // millisecond's update, fetched by an idle wavefront during this one's
-    double leave_next[3];
-    int32_t leave_for_ms, pad4;
+    // Double-buffered by the parity of the millisecond: in millisecond ms wavefront 0 reads slot ms & 1 while the fetching
+    // wavefront fills slot (ms + 1) & 1 in the same barrier interval -- the two never touch the same words.
+    double leave_next[2][3];
+    int32_t leave_for_ms[2];
 };
 static_assert(sizeof(RedScratch) <= kRedBytes, "reduction scratch too large");
 

@@ -10,13 +10,6 @@
 // track_block_kernel<8, false, 0> 29.51 -> 29.30 ms per 500-ms launch (rocprofv3, 82 launches each; profiles/r05_experiments.txt item 5)
 #define GYP_EXPERIMENT_LEAVE_PF 1
 #endif
-#ifndef GYP_MODE0_CANDIDATES
-// 1 for an A/B build: the throughput kernel's Costas candidates on two more wavefronts, only the lock verdict serial (mode0_candidate /
-// mode0_verdict below, the speculative kernel's arrangement).  Measured in r05 (profiles/r05_experiments.txt item 7): same records (the
-// 83 throughput-kernel GPU tests pass), 30.92 ms per launch against 30.81 without it -- the shorter serial section is paid for with
-// three more spilled registers (9 against 6 at the 128-register budget) -- so the default stays 0 (costas_update on wavefront 0).
-#define GYP_MODE0_CANDIDATES 0
-#endif
 #ifndef GYP_EXPERIMENT_SKIP_UPDATE
 #define GYP_EXPERIMENT_SKIP_UPDATE 0   // 1 (development builds only): the throughput kernel without its Costas / lock-detector update -- how much of the kernel's time the serial update costs
 #endif
@@ -468,96 +461,6 @@ __device__ __forceinline__ void rec_flush(const RedScratch* red, gyp_track_rec* 
     if (rec && lane < 14) reinterpret_cast<uint32_t*>(rec)[lane] = reinterpret_cast<const uint32_t*>(&red->rec)[lane];
 }
 
-// ---- the throughput kernel's update with the Costas candidates off the serial section (r05; workgroups of >= 6 wavefronts) ----------
-// costas_update does, on ONE wavefront, histories -> lock verdict -> phi / f update -> the next wipe-off's rotation constants (a float64
-// sincos).  Only the verdict needs the histories; the phi / f update and the rotation constants are formed for BOTH loop bandwidths by
-// two other wavefronts meanwhile (mode0_candidate: RedScratch::cc[0] locked, cc[1] unlocked; CostasCand::step holds rot_wrap here), and
-// the verdict merely selects one (cand_sel) -- the arrangement the speculative kernel has had since r02.  Same expressions, same values.
-template <int K>
-__device__ __forceinline__ void mode0_candidate(double inv_fs, RedScratch* red, cf peak, double f, double phi, double alpha, double beta,
-                                                int slot, int lane) {
-    const double err = (double)peak.x * (double)peak.y;
-    const double nphi = pymod_uniform(phi + err * alpha, 6.283185307179586);
-    const double nf = f + err * beta;
-    const CarrierSteps cs = tracking_steps<K>(nf * inv_fs);
-    if (lane == 0) {
-        red->cc[slot].nf = nf; red->cc[slot].nphi = nphi;
-        red->cc[slot].rot1 = cs.rot1; red->cc[slot].step = cs.rot_wrap;
-    }
-}
-// costas_update without the candidates' part: tracker.py:346-347 histories, :246-262 lock verdict (selects the candidate), :370-387
-// watchdog (a nudge forms its own candidate, cc[2], from the verdict's).  f, phi: what this millisecond was wiped with.
-template <int K>
-__device__ __forceinline__ void mode0_verdict(const LoopConst& kc, ChanState* st, RedScratch* red, double t0, int lane, const MsMeasure& r,
-                                              const double (&leave)[3], double f, double phi) {
-    int lost = 0;
-    const int64_t n = red->loop.n_steps;            // uniform: every lane reads the same words
-    double last_watchdog = red->loop.last_watchdog;
-    LockSums sums = red->loop.sums;
-    int pos_e = red->loop.pos_e, pos_p = red->loop.pos_p, pos_refresh = red->loop.pos_refresh;
-    const double leave_e = leave[0], leave_pr = leave[1], leave_pi = leave[2];
-    const double pr = (double)r.peak.x, pim = (double)r.peak.y;
-    if (lane == 0) { st->peak_re[pos_p] = pr; st->peak_im[pos_p] = pim; }
-    {   // straight-line (see lock_from_sums): the entry leaving the 250-ms window, then the new peak
-        const bool full = n >= kLockWindow;
-        const bool ln = full && leave_pr < 0.0, lp = full && !(leave_pr < 0.0);
-        sums.nr -= ln ? leave_pr : 0.0; sums.ni -= ln ? leave_pi : 0.0; sums.nrr -= ln ? leave_pr * leave_pr : 0.0; sums.cn -= ln ? 1 : 0;
-        sums.pr -= lp ? leave_pr : 0.0; sums.prr -= lp ? leave_pr * leave_pr : 0.0; sums.cp -= lp ? 1 : 0;
-        const bool nn = pr < 0.0;
-        sums.nr += nn ? pr : 0.0; sums.ni += nn ? pim : 0.0; sums.nrr += nn ? pr * pr : 0.0; sums.cn += nn ? 1 : 0;
-        sums.pr += nn ? 0.0 : pr; sums.prr += nn ? 0.0 : pr * pr; sums.cp += nn ? 0 : 1;
-    }
-    const double err = pr * pim;
-    const LoopParams& lp = kc.lp;
-    LockVerdict lv = lock_from_sums(sums, n, lp);
-    bool locked = lv.locked;
-    if (uniform(lv.marginal || pos_refresh == kLockRefresh - 1)) {
-        workgroup_mem_fence_wave();                 // lane 0's ring stores -> every lane of this wavefront
-        LockSums fresh;
-        locked = is_locked_exact_wave(st, n, n + 1, lane, fresh, lp.err_var_max, lp.i_var_max, lp.rot_deg);
-        sums = fresh;
-    }
-    // the error joins its window after is_locked() has been evaluated (tracker.py:251,261)
-    sums.se -= n >= kLockWindow ? leave_e : 0.0; sums.see -= n >= kLockWindow ? leave_e * leave_e : 0.0;
-    sums.se += err; sums.see += err * err;
-    if (lane == 0) st->err_ring[pos_e] = err;
-    pos_e = pos_e + 1 == kLockWindow ? 0 : pos_e + 1;
-    pos_p = pos_p + 1 == kPeakHistory ? 0 : pos_p + 1;
-    pos_refresh = pos_refresh + 1 == kLockRefresh ? 0 : pos_refresh + 1;
-    int sel = locked ? 0 : 1;
-    const int rec_sel = sel;                        // the record carries the values before any watchdog nudge
-    int status = 0, nudged = 0;
-    if (uniform(t0 - last_watchdog >= kc.lp.wd_period)) {
-        workgroup_mem_fence_wave();
-        double cs[3];
-        constellation_stats_wave(st, n + 1, lane, cs);
-        last_watchdog = t0;
-        if (cs[0] >= 0.0) {
-            if (cs[0] < kc.lp.wd_drop) { status = 1; lost = 1; }
-            else if (cs[0] < kc.lp.wd_nudge && cs[2] != 0.0) {
-                double nphi = pymod_uniform(phi + err * (locked ? lp.alpha_locked : lp.alpha_unlocked), 6.283185307179586);
-                double nf = f + err * (locked ? lp.beta_locked : lp.beta_unlocked);
-                const double sg = cs[1] > 0.0 ? 1.0 : (cs[1] < 0.0 ? -1.0 : 0.0);
-                nf += -sg * kc.lp.wd_nudge_hz;
-                nphi += sg * (3.141592653589793 / 2.0);
-                nudged = 1;
-                sel = 2;
-                const CarrierSteps c2 = tracking_steps<K>(nf * kc.inv_fs);
-                if (lane == 0) { red->cc[2].nf = nf; red->cc[2].nphi = nphi; red->cc[2].rot1 = c2.rot1; red->cc[2].step = c2.rot_wrap; }
-            }
-        }
-    }
-    if (lane == 0) {
-        red->loop.last_watchdog = last_watchdog; red->loop.n_steps = n + 1; red->loop.sums = sums;
-        red->loop.pos_e = pos_e; red->loop.pos_p = pos_p; red->loop.pos_refresh = pos_refresh;
-        red->istate[1] = lost;
-        red->cand_sel = sel; red->rec_sel = rec_sel;
-        gyp_track_rec& o = red->rec;                // (doppler_hz / carrier_phase are taken from cc[rec_sel] when the record is flushed)
-        o.pseudosymbol = (int8_t)(pr > 0.0 ? 1 : (pr < 0.0 ? -1 : 0));
-        o.locked = locked ? 1 : 0; o.status = (int8_t)status; o.nudged = (int8_t)nudged;
-    }
-}
-
 // The speculative tracker runs every rate it supports with eight wavefronts (one window lag each): 512 threads own the
 // 1024 chip slots two apiece whatever K is (K = 8: the workgroup the other kernels use; K = 2: four times theirs).
 constexpr int kSpecThreads = 512;
@@ -962,8 +865,6 @@ template <int K, bool PROF, int MODE = 0>
 __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 : Geom<K>::kMinWavesPerSimd) void track_block_kernel(TrackBlockParams p) {
     static_assert(MODE == 0 || MODE == 2, "r01's non-speculative latency variant (MODE 1) is gone: superseded by MODE 2");
     constexpr bool LAT = MODE == 2, SPEC = MODE == 2;
-    // throughput form with six or more wavefronts: the Costas candidates leave the serial section (mode0_candidate / mode0_verdict)
-    constexpr bool CAND = MODE == 0 && Geom<K>::W >= 6 && GYP_MODE0_CANDIDATES;
     static_assert(!LAT || kSpecRate<K>, "the speculative form exists for K = 2, 8 and 16");
     constexpr int kThreadsHere = SPEC ? kSpecThreads : Geom<K>::kThreads;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1076,7 +977,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
                                                                         // the same records however it is cut into launches
         sm.red->cc[0].nf = st->doppler; sm.red->cc[0].nphi = st->carrier_phase;
         sm.red->cc[0].rot1 = sm.red->steps.rot1;
-        sm.red->cc[0].step = CAND ? sm.red->steps.rot_wrap : carrier_from_cycles_fast(st->doppler * p.inv_fs * (double)(K * kSpecThreads));
+        sm.red->cc[0].step = carrier_from_cycles_fast(st->doppler * p.inv_fs * (double)(K * kSpecThreads));
         sm.red->cand_sel = 0; sm.red->rec_sel = 0;
         sm.red->defer = 0;
         if (SPEC && ms_first < ms_last) sm.red->t0_next = p.start_time[ms_first];
@@ -1124,7 +1025,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
     wcache.q = -1; wcache.qe = -1; wcache.ql = -1;
     bool have_prev = false;   // speculative mode: the previous millisecond's record (and possibly its histories) await completion
     const int64_t n_first = GYP_EXPERIMENT_LEAVE_PF ? launder_lds(sm.red)->loop.n_steps : 0;   // (uniform: steps taken before this launch)
-    if (GYP_EXPERIMENT_LEAVE_PF && threadIdx.x == 0) sm.red->leave_for_ms = -1;
+    if (GYP_EXPERIMENT_LEAVE_PF && threadIdx.x == 0) { sm.red->leave_for_ms[0] = -1; sm.red->leave_for_ms[1] = -1; }
     for (int ms = ms_first; ms < ms_last; ++ms) {   // ([ms_first, ms_last) == [p.ms_begin, p.ms_end) except in a re-run from a later checkpoint and under the round protocol)
         gyp_track_rec* rec = p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + ms : nullptr;
         // (speculative mode: a load issued here would be waited for -- a few hundred cycles -- by the first carrier of the
@@ -1135,8 +1036,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
         }
         if (!SPEC && have_prev) {   // the previous millisecond's record (complete since the barrier that ended it)
             if (wave == (Geom<K>::W >= 2 ? 1 : 0)) {
-                if constexpr (CAND) rec_flush_spec(sm.red, rec ? rec - 1 : nullptr, lane);
-                else rec_flush(sm.red, rec ? rec - 1 : nullptr, lane);
+                rec_flush(sm.red, rec ? rec - 1 : nullptr, lane);
             }
             have_prev = false;
         }
@@ -1149,8 +1049,8 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
                 if (rec) {
                     gyp_track_rec z = {};
                     z.status = 2; z.code_phase = sm.red->istate[0];
-                    z.doppler_hz = (SPEC || CAND) ? sm.red->cc[sm.red->cand_sel].nf : sm.red->dstate[0];
-                    z.carrier_phase = (SPEC || CAND) ? sm.red->cc[sm.red->cand_sel].nphi : sm.red->dstate[1];
+                    z.doppler_hz = SPEC ? sm.red->cc[sm.red->cand_sel].nf : sm.red->dstate[0];
+                    z.carrier_phase = SPEC ? sm.red->cc[sm.red->cand_sel].nphi : sm.red->dstate[1];
                     *rec = z;
                 }
                 if (p.spec_out) p.spec_out[(int64_t)ch * p.n_ms + ms].key = kSpecKeyLost;
@@ -1169,9 +1069,6 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
             const auto cand = sm.red->cc[sm.red->cand_sel];
             f = cand.nf; phi = cand.nphi; cs.rot1 = cand.rot1; cs.rot_wrap = make_float2(1.f, 0.f);
             half_step = cand.step;
-        } else if constexpr (CAND) {
-            const auto cand = sm.red->cc[sm.red->cand_sel];
-            f = cand.nf; phi = cand.nphi; cs.rot1 = cand.rot1; cs.rot_wrap = cand.step;
         } else {
             f = sm.red->dstate[0]; phi = sm.red->dstate[1]; cs = sm.red->steps;
         }
@@ -1338,23 +1235,19 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
             // millisecond (rec_flush by wavefront 1), off this path too.
             RedScratch* red = launder_lds(sm.red);
             constexpr int kW = Geom<K>::W;          // (rates whose workgroup has fewer than three wavefronts double up)
-            constexpr int kLeaveWave = CAND ? 5 : 3;   // the wavefront that fetches the next millisecond's leaving ring entries
+            constexpr int kLeaveWave = 3;   // the wavefront that fetches the next millisecond's leaving ring entries
             if (wave == 0 && !GYP_EXPERIMENT_SKIP_UPDATE) {
                 const long long u0_ = prof ? (long long)__builtin_readcyclecounter() : 0;
-                if (GYP_EXPERIMENT_LEAVE_PF && kW >= 4 && red->leave_for_ms == ms) {
-                    leave[0] = red->leave_next[0]; leave[1] = red->leave_next[1]; leave[2] = red->leave_next[2];
+                if (GYP_EXPERIMENT_LEAVE_PF && kW >= 4 && red->leave_for_ms[ms & 1] == ms) {
+                    const double* ln = red->leave_next[ms & 1];    // (filled during millisecond ms - 1; this millisecond's fetch goes to the other slot)
+                    leave[0] = ln[0]; leave[1] = ln[1]; leave[2] = ln[2];
                 } else {
                     fetch_leaving(st, red, leave);
                 }
                 if (prof) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const long long u1_ = prof ? (long long)__builtin_readcyclecounter() : 0;
-                if constexpr (CAND) mode0_verdict<K>(red->kc, st, red, t0, lane, m, leave, f, phi);
-                else costas_update<K, false>(red->kc, st, red, t0, lane, m, leave);
+                costas_update<K, false>(red->kc, st, red, t0, lane, m, leave);
                 if (prof) { tp[6] += u1_ - u0_; tp[8] += (long long)__builtin_readcyclecounter() - u1_; }
-            }
-            if constexpr (CAND) {
-                if (wave == 3) mode0_candidate<K>(red->kc.inv_fs, red, m.peak, f, phi, red->kc.lp.alpha_locked, red->kc.lp.beta_locked, 0, lane);
-                if (wave == 4) mode0_candidate<K>(red->kc.inv_fs, red, m.peak, f, phi, red->kc.lp.alpha_unlocked, red->kc.lp.beta_unlocked, 1, lane);
             }
             if (wave == (kW >= 2 ? 1 : 0)) dll_update(red, m.disc, lane, red->kc.lp);
             if (wave == (kW >= 3 ? 2 : 0)) spec_record_fields<K>(red, m, lane);
@@ -1369,7 +1262,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
                     const int pl = pp >= kLockWindow ? pp - kLockWindow : pp - kLockWindow + kPeakHistory;
                     e = st->err_ring[pe]; pr_ = st->peak_re[pl]; pi_ = st->peak_im[pl];
                 }
-                if (lane == 0) { red->leave_next[0] = e; red->leave_next[1] = pr_; red->leave_next[2] = pi_; red->leave_for_ms = ms + 1; }
+                if (lane == 0) { double* ln = red->leave_next[(ms + 1) & 1]; ln[0] = e; ln[1] = pr_; ln[2] = pi_; red->leave_for_ms[(ms + 1) & 1] = ms + 1; }
             }
             if constexpr (PRE) {   // (wavefront 0 gets here behind its update; a channel the watchdog has just dropped asks for samples nobody uses)
                 if (ms + 1 < ms_last) stage_fetch_own<K>(stream + (int64_t)(ms + 1) * N, pre, launder(threadIdx.x));
@@ -1400,12 +1293,11 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
     }
     if (!SPEC && have_prev && wave == (Geom<K>::W >= 2 ? 1 : 0)) {
         gyp_track_rec* last = p.rec_out ? p.rec_out + (int64_t)ch * p.n_ms + (ms_last - 1) : nullptr;
-        if constexpr (CAND) rec_flush_spec(sm.red, last, lane);
-        else rec_flush(sm.red, last, lane);
+        rec_flush(sm.red, last, lane);
     }
     if (threadIdx.x == 0) {
-        st->doppler = (SPEC || CAND) ? sm.red->cc[sm.red->cand_sel].nf : sm.red->dstate[0];
-        st->carrier_phase = (SPEC || CAND) ? sm.red->cc[sm.red->cand_sel].nphi : sm.red->dstate[1];
+        st->doppler = SPEC ? sm.red->cc[sm.red->cand_sel].nf : sm.red->dstate[0];
+        st->carrier_phase = SPEC ? sm.red->cc[sm.red->cand_sel].nphi : sm.red->dstate[1];
         st->code_phase = sm.red->istate[0]; st->lost = sm.red->istate[1];
         st->win_centre1 = SPEC ? sm.red->istate[2] + 1 : 0;
         const LoopState ls = sm.red->loop;

@@ -201,6 +201,9 @@ class BinSearchResult:
     bin_max: List[float] = field(default_factory=list)
     bin_argmax: List[int] = field(default_factory=list)
     bin_strength: List[float] = field(default_factory=list)
+    # test infrastructure (margins=True): per bin (largest - second largest) / largest of the profile -- np.argmax's own margin, which
+    # float32 magnitudes (3e-7) cannot split below ~1e-6
+    bin_gap: List[float] = field(default_factory=list)
 
 
 @dataclass
@@ -219,7 +222,7 @@ def doppler_bins(center: float, spread: float) -> range:
 
 
 def best_doppler_bin(center: float, spread: float, antenna_data: np.ndarray, fs: int, n: int,
-                     prn_replica: np.ndarray) -> BinSearchResult:
+                     prn_replica: np.ndarray, margins: bool = False) -> BinSearchResult:
     """acquisition.py:154-190 `get_best_doppler_shift_estimation`.
 
     Best bin = first bin (lowest Doppler) holding the largest profile maximum
@@ -234,6 +237,9 @@ def best_doppler_bin(center: float, spread: float, antenna_data: np.ndarray, fs:
         res.bin_max.append(float(m))
         res.bin_argmax.append(int(np.argmax(prof)))
         res.bin_strength.append(float(peak_strength(prof)))
+        if margins:
+            top2 = np.partition(prof, -2)[-2:]
+            res.bin_gap.append(float((top2[1] - top2[0]) / top2[1]))
         if best is None or m > best[0]:
             best = (m, d, prof)
     _, res.doppler_hz, res.profile = best

@@ -39,7 +39,7 @@ def scene_inits(scene, rng):
 def run_scene(args):
     """args = (fs, n_ms, n_sats, seed, keep_iq_dir[, regime]).  Returns (seed, iq_path, inits, traj) with traj[ch] an int64/float64
     array of per-ms rows (pseudosymbol, code_phase_after, peak_offset, locked, doppler_after, lost_flag, nudged, lock_margin,
-    |Re peak| / |peak|, argmax_margin)."""
+    |Re peak| / |peak|, argmax_margin, |peak|)."""
     fs, n_ms, n_sats, seed, iq_dir = args[:5]
     regime = args[5] if len(args) > 5 else "pull-in"
     from gypsum_amd import synth
@@ -64,7 +64,7 @@ def run_scene(args):
     traj = []
     for sv, dop, phi, cp in inits:
         trk = orc.Tracker(orc.TrackingState(dop, phi, cp), orc.prn_as_complex(chips[sv - 1], n), fs, n)
-        rows = np.zeros((len(times), 10), dtype=np.float64)
+        rows = np.zeros((len(times), 11), dtype=np.float64)
         trk.record_margins = regime == "lock"
         for j, (st, en) in enumerate(times):
             ms = 9 + j
@@ -74,7 +74,7 @@ def run_scene(args):
                 rows[j:, 5] = 1.0
                 break
             rows[j] = (r.pseudosymbol, r.code_phase_after, r.peak_offset, float(r.locked), r.doppler_after, 0.0, float(r.nudged),
-                       r.lock_margin, abs(r.peak.real) / max(abs(r.peak), 1e-300), r.argmax_margin)
+                       r.lock_margin, abs(r.peak.real) / max(abs(r.peak), 1e-300), r.argmax_margin, abs(r.peak))
         traj.append(rows)
     base = iq_dir or ("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir())
     path = os.path.join(base, f"gyp_survey_{os.getpid()}_{seed}.npy")
@@ -118,3 +118,39 @@ def run_full_sky_scene(args):
         r = orc.acquire_satellite(sv, iq, fs, n, orc.prn_as_complex(chips[sv - 1], n))
         out.append((sv, int(r.doppler_shift), int(r.prn_phase_shift), float(r.correlation_strength)))
     return seed, out
+
+
+def run_grid_rows(args):
+    """args = (iq_path, fs, n, n_ms, rows) with rows = [(unit, sat_id), ...]; `iq_path` a .npy of complex64[n_units, n_ms * n] (memory-mapped:
+    the whole benchmark-sized batch is shared by the pool).  Per row the oracle's flat-grid search of that unit's samples --
+    get_best_doppler_shift_estimation(0, 5000, ...) (acquisition.py:154-190) -- as (unit, sat_id, best bin index, peak index, strength,
+    per-bin maxima, per-bin arg-maxima, per-bin strengths, per-bin top-two gaps)."""
+    iq_path, fs, n, n_ms, rows = args
+    from oracle import gypsum_oracle as orc
+
+    iq = np.load(iq_path, mmap_mode="r")
+    chips = orc.generate_ca_codes()
+    out = []
+    for unit, sv in rows:
+        x = np.array(iq[unit, :n_ms * n])
+        r = orc.best_doppler_bin(0.0, 5000.0, x, fs, n, orc.prn_as_complex(chips[sv - 1], n), margins=True)
+        out.append((unit, sv, r.bins.index(r.doppler_hz), r.peak_index, r.strength, np.array(r.bin_max), np.array(r.bin_argmax),
+                    np.array(r.bin_strength), np.array(r.bin_gap)))
+    return out
+
+
+def run_coherent_cells(args):
+    """args = (iq_path, fs, n, n_ms, cells) with cells = [(stream, sat_id, doppler_hz), ...]: config 5's cell, integrate_correlation(Coherent)
+    over n_ms blocks (utils.py:77-108), as (stream, sat_id, doppler_hz, argmax |c|, max |c|, strength of |c|, top-two gap, count of the maximum)."""
+    iq_path, fs, n, n_ms, cells = args
+    from oracle import gypsum_oracle as orc
+
+    iq = np.load(iq_path, mmap_mode="r")
+    chips = orc.generate_ca_codes()
+    out = []
+    for stream, sv, d in cells:
+        ref = np.abs(orc.integrate_correlation(orc.COHERENT, np.array(iq[stream, :n_ms * n]), fs, n, d, orc.prn_as_complex(chips[sv - 1], n)))
+        top2 = np.partition(ref, -2)[-2:]
+        out.append((stream, sv, d, int(np.argmax(ref)), float(ref.max()), float(orc.peak_strength(ref)), float((top2[1] - top2[0]) / top2[1]),
+                    int(np.sum(ref == ref.max()))))
+    return out

@@ -37,10 +37,11 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
     sys.path.insert(0, str(REPO))
     sys.path.insert(0, str(REPO / "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    import torch.distributed as dist
     from oracle import gypsum_oracle as orc
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # the product's own rank plumbing (what bench.py runs): no engine on a CPU rank, so the records take RankComm's host path --
+    # the same padding / trimming / rank order as the device path, whose bytes go through gyp_allgather_dev instead
+    comm = gdist.RankComm(None, rank, world, False)
     z = gu.load("grid_kat_2046.npz")
     fs, n = int(z["fs"]), int(z["n"])
     chips = orc.generate_ca_codes()
@@ -57,17 +58,17 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
             out[i] = (m, int(prof.argmax()), prof.sum(), int((prof == m).sum()), 0, 0.0, 0.0)
         return out
 
-    table = gdist.sharded_grid_search(cells, compute)
+    table = gdist.sharded_grid_search(cells, compute, comm)
     doppler, index, strength = gdist.best_bin_per_satellite(cells, table, len(sat_ids), len(bins), n)
     # ragged record gather (acquisition results of rank-local streams)
     mine = np.zeros(2 + rank, dtype=ACQ_RESULT)
     mine["stream"] = rank
     mine["sat_id"] = np.arange(len(mine)) + 1
-    gathered = gdist.allgather_records(mine, [2 + r for r in range(world)])
+    gathered = comm.allgather_records(mine, [2 + r for r in range(world)])
     np.savez(Path(out_dir) / f"rank{rank}.npz", doppler=doppler, index=index, strength=strength,
              n_cells=len(table), gathered_stream=gathered["stream"], gathered_sat=gathered["sat_id"])
-    dist.barrier()
-    dist.destroy_process_group()
+    comm.barrier()
+    comm.close()
 
 
 def test_two_rank_grid_search_and_record_gather(tmp_path):

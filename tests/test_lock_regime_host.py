@@ -30,7 +30,7 @@ def test_the_oracle_locks_in_a_lock_regime_scene_and_reports_margins():
     seed, path, inits, traj = survey_worker.run_scene((2_046_000, 900, 0, 5000, None, "lock"))     # a*N = 15.8, sigma^2 N = 1.2, two satellites
     os.unlink(path)
     rows = traj[0]
-    assert rows.shape[1] == 10
+    assert rows.shape[1] == 11 and np.all(rows[:, 10] > 0)      # (last column: |prompt peak|, the 1e-4 bar of the surveys)
     locked = rows[:, 3] != 0
     assert locked[:240].sum() == 0 and locked.sum() > 300          # nothing before the 250-ms window has filled, then lock
     assert np.all(np.isinf(rows[:240, 7])) and np.all(np.isfinite(rows[260:, 7])) and np.all(rows[260:, 7] >= 0)
