@@ -121,22 +121,26 @@ def run_full_sky_scene(args):
 
 
 def run_grid_rows(args):
-    """args = (iq_path, fs, n, n_ms, rows) with rows = [(unit, sat_id), ...]; `iq_path` a .npy of complex64[n_units, n_ms * n] (memory-mapped:
-    the whole benchmark-sized batch is shared by the pool).  Per row the oracle's flat-grid search of that unit's samples --
-    get_best_doppler_shift_estimation(0, 5000, ...) (acquisition.py:154-190) -- as (unit, sat_id, best bin index, peak index, strength,
-    per-bin maxima, per-bin arg-maxima, per-bin strengths, per-bin top-two gaps)."""
+    """args = (iq_path, fs, n, n_ms, rows) with rows = int array [k, 2] of (unit, sat_id); `iq_path` a .npy of complex64[n_units, n_ms * n]
+    (memory-mapped: the whole benchmark-sized batch is shared by the pool).  Per row the oracle's flat-grid search of that unit's samples
+    -- get_best_doppler_shift_estimation(0, 5000, ...) (acquisition.py:154-190) -- returned as arrays over the rows: (rows, best bin index,
+    peak index, strength, per-bin maxima [k, bins], per-bin arg-maxima, per-bin strengths, per-bin top-two gaps)."""
     iq_path, fs, n, n_ms, rows = args
     from oracle import gypsum_oracle as orc
 
     iq = np.load(iq_path, mmap_mode="r")
     chips = orc.generate_ca_codes()
-    out = []
+    prn = {}
+    best, peak_index, strength, bmax, bargmax, bstrength, bgap = [], [], [], [], [], [], []
     for unit, sv in rows:
-        x = np.array(iq[unit, :n_ms * n])
-        r = orc.best_doppler_bin(0.0, 5000.0, x, fs, n, orc.prn_as_complex(chips[sv - 1], n), margins=True)
-        out.append((unit, sv, r.bins.index(r.doppler_hz), r.peak_index, r.strength, np.array(r.bin_max), np.array(r.bin_argmax),
-                    np.array(r.bin_strength), np.array(r.bin_gap)))
-    return out
+        unit, sv = int(unit), int(sv)
+        if sv not in prn:
+            prn[sv] = orc.prn_as_complex(chips[sv - 1], n)
+        r = orc.best_doppler_bin(0.0, 5000.0, np.array(iq[unit, :n_ms * n]), fs, n, prn[sv], margins=True)
+        best.append(r.bins.index(r.doppler_hz)); peak_index.append(r.peak_index); strength.append(r.strength)
+        bmax.append(r.bin_max); bargmax.append(r.bin_argmax); bstrength.append(r.bin_strength); bgap.append(r.bin_gap)
+    return (np.asarray(rows, dtype=np.int64), np.array(best, dtype=np.int64), np.array(peak_index, dtype=np.int64), np.array(strength),
+            np.array(bmax), np.array(bargmax, dtype=np.int64), np.array(bstrength), np.array(bgap))
 
 
 def run_coherent_cells(args):

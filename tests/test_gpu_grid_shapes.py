@@ -32,7 +32,7 @@ REPO = Path(__file__).resolve().parents[1]
 if str(REPO) not in sys.path:
     sys.path.insert(0, str(REPO))
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
 
 GAP = 2e-6
 ALL_IDS = list(range(1, 33))
@@ -69,49 +69,57 @@ def _noncoherent_grid(eng, B, T, seed, rng_seed):
 
 
 def _check_rows(eng, cells, best, host_iq, rows, label):
-    """`rows` = [(unit, sat_id)]: all 20 cells of each row and its best-bin record against the oracle."""
+    """`rows` = [(unit, sat_id)]: all 20 cells of each row and its best-bin record against the oracle.  The pool's results are collected
+    first and compared afterwards (an assertion inside a live imap loop would have to tear the pool down under load)."""
     fs, n = 2_046_000, 2046
+    rows = np.asarray(rows, dtype=np.int64).reshape(-1, 2)
     path = os.path.join(_shm_dir(), f"gyp_grid_{os.getpid()}.npy")
     np.save(path, host_iq)
     procs = _pool_size(max(1, len(rows) // 16))
     per = max(1, -(-len(rows) // (procs * 4)))
     jobs = [(path, fs, n, 1, rows[i:i + per]) for i in range(0, len(rows), per)]
     t0 = time.time()
-    tally = {"rows": 0, "cells": 0, "argmax_knife": 0, "bin_knife": 0, "worst_peak": 0.0, "worst_strength": 0.0}
     try:
         with mp.get_context("spawn").Pool(procs) as pool:
-            for part in pool.imap_unordered(survey_worker.run_grid_rows, jobs):
-                for unit, sv, bin_idx, peak_index, strength, bmax, bargmax, bstrength, bgap in part:
-                    c = cells[unit, sv - 1]
-                    tally["rows"] += 1
-                    tally["cells"] += len(bmax)
-                    bad = c["argmax"] != bargmax
-                    if bad.any():       # only where the reference's own two largest lags are closer than float32 can tell apart
-                        assert np.all(bgap[bad] < GAP), (label, unit, sv, c["argmax"][bad], bargmax[bad], bgap[bad])
-                        tally["argmax_knife"] += int(bad.sum())
-                    rel = np.abs(c["peak"].astype(np.float64) - bmax) / bmax
-                    tally["worst_peak"] = max(tally["worst_peak"], float(rel.max()))
-                    assert rel.max() <= 1e-4, (label, unit, sv, float(rel.max()))
-                    ok = ~bad
-                    srel = np.abs(eng.cell_strength(c)[ok] - bstrength[ok]) / bstrength[ok]
-                    if ok.any():
-                        tally["worst_strength"] = max(tally["worst_strength"], float(srel.max()))
-                        assert srel.max() <= 1e-4, (label, unit, sv, float(srel.max()))
-                    # the device's selection (grid_best_bin_kernel, acquisition.py:180-189: the first bin holding the largest maximum)
-                    g = best[unit, sv - 1]
-                    if int(g["bin"]) != bin_idx:
-                        top2 = np.sort(bmax)[-2:]
-                        assert (top2[1] - top2[0]) / top2[1] < GAP, (label, unit, sv, int(g["bin"]), bin_idx, bmax)
-                        tally["bin_knife"] += 1
-                    elif not bad[bin_idx]:
-                        assert int(g["argmax"]) == peak_index, (label, unit, sv)
-                        assert abs(float(g["strength"]) - strength) <= 1e-4 * strength, (label, unit, sv, float(g["strength"]), strength)
+            parts = pool.map(survey_worker.run_grid_rows, jobs, chunksize=1)
     finally:
         os.unlink(path)
-    print(f"[{label}] {tally['rows']} (unit, satellite) rows = {tally['cells']} cells and {tally['rows']} best-bin records against the oracle in "
-          f"{time.time() - t0:.0f} s ({procs} processes): arg-max / best bin bit-exact except {tally['argmax_knife']} cells / {tally['bin_knife']} rows where "
-          f"the reference's own top two are < {GAP:g} apart; worst peak difference {tally['worst_peak']:.1e}, worst strength difference "
-          f"{tally['worst_strength']:.1e} (bar 1e-4)")
+    t_pool = time.time() - t0
+    tally = {"rows": 0, "cells": 0, "argmax_knife": 0, "bin_knife": 0, "worst_peak": 0.0, "worst_strength": 0.0}
+    for rws, bin_idx, peak_index, strength, bmax, bargmax, bstrength, bgap in parts:
+        k, nb = bmax.shape
+        c = cells[rws[:, 0], rws[:, 1] - 1]                      # [k, bins] device records
+        tally["rows"] += k
+        tally["cells"] += k * nb
+        bad = c["argmax"] != bargmax
+        # arg-max: bit-exact, except where the reference's own two largest lags are closer than float32 can tell apart
+        assert np.all(bgap[bad] < GAP), (label, rws[bad.any(axis=1)][:3], c["argmax"][bad][:3], bargmax[bad][:3], bgap[bad][:3])
+        tally["argmax_knife"] += int(bad.sum())
+        rel = np.abs(c["peak"].astype(np.float64) - bmax) / bmax
+        tally["worst_peak"] = max(tally["worst_peak"], float(rel.max()))
+        assert rel.max() <= 1e-4, (label, rws[np.unravel_index(int(rel.argmax()), rel.shape)[0]], float(rel.max()))
+        srel = np.abs(eng.cell_strength(np.ascontiguousarray(c.reshape(-1))).reshape(k, nb) - bstrength) / bstrength
+        # (where the reference's top two are closer than float32 resolution the device sees TWO maxima -- n_max = 2 -- and utils.py:111-116
+        # leaves both out of the mean: the strength moves by ~(max - mean) / N ~ 1e-3.  Same knife edge as the arg-max: not compared, counted)
+        knife = bgap < GAP
+        tally["strength_knife"] = tally.get("strength_knife", 0) + int((knife & ~bad).sum())
+        srel[knife | bad] = 0.0
+        tally["worst_strength"] = max(tally["worst_strength"], float(srel.max()))
+        assert srel.max() <= 1e-4, (label, rws[np.unravel_index(int(srel.argmax()), srel.shape)[0]], float(srel.max()))
+        # the device's selection (grid_best_bin_kernel, acquisition.py:180-189: the first bin holding the largest maximum)
+        g = best[rws[:, 0], rws[:, 1] - 1]
+        other = g["bin"] != bin_idx
+        if other.any():
+            top2 = np.sort(bmax[other], axis=1)[:, -2:]
+            assert np.all((top2[:, 1] - top2[:, 0]) / top2[:, 1] < GAP), (label, rws[other][:3], g["bin"][other][:3], bin_idx[other][:3])
+            tally["bin_knife"] += int(other.sum())
+        ok = ~other & ~(bad | knife)[np.arange(k), bin_idx]
+        assert np.array_equal(g["argmax"][ok], peak_index[ok]), (label, rws[ok][g["argmax"][ok] != peak_index[ok]][:3])
+        assert np.all(np.abs(g["strength"][ok] - strength[ok]) <= 1e-4 * strength[ok]), label
+    print(f"[{label}] {tally['rows']} (unit, satellite) rows = {tally['cells']} cells and {tally['rows']} best-bin records against the oracle (pool of "
+          f"{procs} processes: {t_pool:.0f} s; comparison {time.time() - t0 - t_pool:.0f} s): arg-max / best bin bit-exact except {tally['argmax_knife']} cells / "
+          f"{tally['bin_knife']} rows where the reference's own top two are < {GAP:g} apart ({tally.get('strength_knife', 0)} more such cells left out of the strength comparison); worst peak difference {tally['worst_peak']:.1e}, worst strength "
+          f"difference {tally['worst_strength']:.1e} (bar 1e-4)")
     return tally
 
 
@@ -193,7 +201,7 @@ def test_cfg5_launch_shape_against_the_oracle(engine_factory):
                 for s, sv, d, argmax, peak, strength, gap, n_max in part:
                     g = got[s, sv - 1, int(round((d + 10000.0) / 100.0))]
                     n_done += 1
-                    if int(g["argmax"]) != argmax:
+                    if int(g["argmax"]) != argmax or gap < GAP:
                         assert gap < GAP, (s, sv, d, int(g["argmax"]), argmax, gap)
                         knife += 1
                         continue

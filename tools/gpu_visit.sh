@@ -83,6 +83,9 @@ l=json.loads(sys.stdin.read()); print({k:l[k] for k in ('value','ms_per_step','a
       # r06: parity at the benchmarked shapes (multi-stream banks on their natural paths, flat grids at bench.py's launch sizes) + N = 2 splits
       timeout ${SHAPES_TIMEOUT:-1500} python -m pytest tests/test_gpu_track_survey.py tests/test_gpu_grid_shapes.py tests/test_gpu_bench_n2.py -x -q -m gpu -s -rxXs -k "bench_shaped or launch_shape or two_ranks" > $O/pytest_shapes.log 2>&1
       echo "pytest rc=$?" >> $O/pytest_shapes.log; grep -v "^$" $O/pytest_shapes.log | cut -c1-1500 | grep "^\[\|passed\|failed\|rc=\|UNEXPL\|knife\|Error\|assert\|^    \|^E " | tail -60 ;;
+    r06grids)
+      timeout ${SHAPES_TIMEOUT:-1200} python -m pytest tests/test_gpu_grid_shapes.py tests/test_gpu_bench_n2.py -x -q -m gpu -s -rxXs -k "launch_shape or two_ranks" > $O/pytest_grids.log 2>&1
+      echo "pytest rc=$?" >> $O/pytest_grids.log; grep -v "^$" $O/pytest_grids.log | cut -c1-1500 | grep "^\[\|passed\|failed\|rc=\|UNEXPL\|knife\|Error\|assert\|^    \|^E " | tail -60 ;;
     locktests)
       timeout 900 python -m pytest tests/test_gpu_track_survey.py -x -q -m gpu -s -k "locked_regime" > $O/pytest_lock.log 2>&1
       echo "pytest rc=$?" >> $O/pytest_lock.log; grep -v "^$" $O/pytest_lock.log | cut -c1-600 | tail -40 ;;
