@@ -942,7 +942,7 @@ def run_grid(eng, comm, args, rng, workload: str, steps: int, warmup: int) -> di
                                   (", best bin per (stream-ms, satellite) on the device + one ncclAllGather" if workload == "cfg4" else "")},
         "samples_per_step": B * T * n, "elapsed": elapsed, "fs": fs, "streams_total": 64 if workload == "cfg4" else B * comm.world,
         "total_samples_override": 64 * T * n * steps if workload == "cfg4" else None,
-        "dominant": {"kernel": "grid_fold_kernel<2, false> + grid_cells_wave_shared_kernel<2, 8>", "ms": k_ms, "flops": flops,
+        "dominant": {"kernel": "grid_cells_wave_fused_kernel<2, false>", "ms": k_ms, "flops": flops,
                      "bytes": (8 * n + 32 * 32 * len(bins)) * n_units},
         "extra": extra, "_sample": sample, "_table": table if recv is not None else None,
     }

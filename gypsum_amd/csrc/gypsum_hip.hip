@@ -124,6 +124,8 @@ struct gyp_ctx {
     float symbol_tau = 1e-4f;     // gyp_debug_set("symbol_tau"): |Re peak| / |peak| below which the pseudosymbol is decided in float64 (test hook: 10 = always)
     bool no_shared_fwd = false;   // gyp_debug_set("no_shared_fwd"): A/B switch: flat grids transform every cell's rows themselves again
     int cells_cu_reserve = 0;     // gyp_debug_set("cells_cu_reserve", n): CUs the correlation-cell launches leave free (see launch_cells)
+    int last_grid_path = 0;       // gyp_debug_get("last_grid_path"): which cells kernel the last gyp_correlate_grid* call took (1 fused, 2 shared forward, 3 one wavefront per cell, 4 workgroup per cell)
+    bool no_grid_fused = false;   // gyp_debug_set("no_grid_fused"): A/B switch: flat grids go through grid_fold_kernel + folded rows in HBM (r05) instead of the fused kernel
     bool no_grid_parts = false;   // gyp_debug_set("no_grid_parts"): A/B switch: flat-grid work items take whole units (no branch runs + merge)
     std::string err;
     // stream format
@@ -808,6 +810,25 @@ int gyp_correlate_grid_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams,
     switch (ctx->k) {
 #define X(K)                                                                                                                  \
     case K: {                                                                                                                 \
+        /* r06: enough units to fill the chip's 2048 wavefront slots twice over, at most 32 satellites, at most 8 samples per chip: the     \
+           fold is fused into the cells kernel, one wavefront per (stream, bin) unit loops every satellite (no folded rows in HBM) */      \
+        if (K <= 8 && n_blk == 1 && n_sats >= 4 && n_sats <= 32 && n_units >= (int64_t)ctx->n_cus * 16 && !ctx->no_pipe &&                 \
+            !ctx->no_shared_fwd && !ctx->no_grid_fused) {                                                                             \
+            const size_t lds = 2 * kTablesBytes + 8 * kXchWaveBytes + 8 * 32 * sizeof(SatStat);                                        \
+            const int wgrid = std::max(1, std::min((int)((n_units + 7) / 8), ctx->n_cus));                                             \
+            if (coh) {                                                                                                                \
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(grid_cells_wave_fused_kernel<(K <= 8 ? K : 8), true>),  \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
+                hipLaunchKernelGGL((grid_cells_wave_fused_kernel<(K <= 8 ? K : 8), true>), dim3(wgrid), dim3(512), lds, ctx->stream, p); \
+            } else {                                                                                                                  \
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(grid_cells_wave_fused_kernel<(K <= 8 ? K : 8), false>), \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
+                hipLaunchKernelGGL((grid_cells_wave_fused_kernel<(K <= 8 ? K : 8), false>), dim3(wgrid), dim3(512), lds, ctx->stream, p); \
+            }                                                                                                                         \
+            HIP_TRY(ctx, hipGetLastError());                                                                                          \
+            ctx->last_grid_path = 1;                                                                                                  \
+            return GYP_OK;                                                                                                            \
+        }                                                                                                                             \
         if (K > 8) { /* wide rates: coalesced wipe-off into z, then the K-sample boxcar out of LDS tiles */                 \
             const size_t zbytes = (size_t)n_units * n_blk * (K * kChips) * sizeof(cf);                                         \
             int rcz;                                                                                                           \
@@ -867,6 +888,7 @@ int gyp_correlate_grid_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams,
                 hipLaunchKernelGGL(grid_merge_parts_kernel, dim3((n_cells + 255) / 256), dim3(256), 0, ctx->stream, p, n_cells); \
                 HIP_TRY(ctx, hipGetLastError());                                                                              \
             }                                                                                                                 \
+            ctx->last_grid_path = 2;                                                                                          \
             return GYP_OK;                                                                                                    \
         }                                                                                                                     \
         if (n_blk == 1 && K % 2 == 0 && !ctx->no_pipe) { /* one wavefront per cell, 256 VGPRs, next row prefetched */              \
@@ -876,6 +898,7 @@ int gyp_correlate_grid_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
             hipLaunchKernelGGL(grid_cells_wave_pipe_kernel<(K % 2 == 0 ? K : 16)>, dim3(wgrid), dim3(512), lds, ctx->stream, p);     \
             HIP_TRY(ctx, hipGetLastError());                                                                                  \
+            ctx->last_grid_path = 3;                                                                                          \
             return GYP_OK;                                                                                                    \
         }                                                                                                                     \
         if (n_blk == 1 && K <= 8) { /* one wavefront per cell, no barriers */                                                \
@@ -885,8 +908,10 @@ int gyp_correlate_grid_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
             hipLaunchKernelGGL(grid_cells_wave_kernel<K>, dim3(wgrid), dim3(512), lds, ctx->stream, p);                        \
             HIP_TRY(ctx, hipGetLastError());                                                                                  \
+            ctx->last_grid_path = 3;                                                                                          \
             return GYP_OK;                                                                                                    \
         }                                                                                                                     \
+        ctx->last_grid_path = 4;                                                                                              \
         return coh ? launch_k(ctx, grid_cells_kernel<K, true>, K, grid, p, lds_bytes<K>())                                    \
                    : launch_k(ctx, grid_cells_kernel<K, false>, K, grid, p, lds_bytes<K>());                                  \
     }
@@ -1896,7 +1921,7 @@ const DebugKnob kDebugKnobs[] = {
     {"no_pipe", 0, 1, true}, {"no_shared_fwd", 0, 1, true}, {"no_acq_split", 0, 1, true}, {"no_spec", 0, 1, true},
     {"spec_debug", 0, 1, true}, {"acq_lanes", 1, gyp_ctx::kMaxAcqLanes, true}, {"track_chunk_ms", 0, 1e6, true},
     {"symbol_tau", 0, 100, false}, {"dll_prov_bias", -1e6, 1e6, false}, {"spec_fail_at", -1, 2147483647.0, true},
-    {"spec_redo", 0, 1, true}, {"exact_prefetch", 0, 1, true}, {"prof_wave", 0, 7, true}, {"no_grid_parts", 0, 1, true}, {"cells_cu_reserve", 0, 128, true},
+    {"spec_redo", 0, 1, true}, {"exact_prefetch", 0, 1, true}, {"prof_wave", 0, 7, true}, {"no_grid_parts", 0, 1, true}, {"no_grid_fused", 0, 1, true}, {"cells_cu_reserve", 0, 128, true},
 };
 }  // namespace
 static int debug_apply(gyp_ctx* ctx, const char* name, double v, bool set, double* out) {
@@ -1906,6 +1931,8 @@ static int debug_apply(gyp_ctx* ctx, const char* name, double v, bool set, doubl
     GYP_KNOB_BOOL("no_pipe", no_pipe)
     GYP_KNOB_BOOL("no_shared_fwd", no_shared_fwd)
     GYP_KNOB_BOOL("no_grid_parts", no_grid_parts)
+    GYP_KNOB_BOOL("no_grid_fused", no_grid_fused)
+    if (is("last_grid_path")) { if (set) return GYP_E_BAD_ARG; *out = (double)ctx->last_grid_path; return GYP_OK; }
     GYP_KNOB_NUM("cells_cu_reserve", cells_cu_reserve, int)
     GYP_KNOB_BOOL("no_acq_split", no_acq_split)
     GYP_KNOB_BOOL("no_spec", no_spec)

@@ -411,6 +411,102 @@ __global__ __launch_bounds__(512, 2) void grid_cells_wave_shared_kernel(GridPara
     }
 }
 
+// r06 -- the fold FUSED into the cells kernel, all satellites of a unit on ONE wavefront (rates up to 8 samples per chip, single-block
+// grids: one non-coherent millisecond, or any coherent block count).  grid_fold_kernel + grid_cells_wave_shared_kernel move every folded
+// row through HBM five times (written once, read by four 8-satellite groups: configs 2 / 4 moved 22 x their algorithmic bytes, VERDICT
+// r05) and run a forward transform per (unit, branch, GROUP).  Here a wavefront takes a (stream, bin) unit, and per polyphase branch
+//   wipes + pre-sums the unit's samples into ITS OWN transpose tile (stage_general<K, 1>: the samples come from L1 / L2 -- the bins of a
+//   stream are neighbouring wavefronts -- and cost ~2 % of the 1 + n_sats transforms they feed), reads the row back in transform order,
+//   runs ONE forward transform, and loops the satellites: replica product (next replica requested first), inverse, statistics.
+// (1 + 32) transforms per 32 cells instead of 36, no fold kernel, no folded rows: HBM sees the samples once and the 32-byte records.
+template <int K, bool COHERENT>
+__global__ __launch_bounds__(512, 2) void grid_cells_wave_fused_kernel(GridParams p) {
+    constexpr int G = 32;
+    constexpr int N = K * kChips;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cf* tw1024 = reinterpret_cast<cf*>(smem_raw);
+    cf* tw2048 = tw1024 + 1024;
+    cf* tiles = tw2048 + 1024;
+    for (int i = threadIdx.x; i < 2048; i += 512) tw1024[i] = p.tw_tables[i];
+    __syncthreads();
+    const int tid = launder(threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, l = lane & 31, h = lane >> 5;
+    cf* row = tiles + wave * kXchWave;                            // the staged row aliases the transpose tile (1088 >= 1024 complex)
+    float* tile_half = reinterpret_cast<float*>(row) + h * kXchTile;
+    SatStat* stats = reinterpret_cast<SatStat*>(tiles + 8 * kXchWave) + wave * G;
+    const LdsTables t{tw1024, tw2048};
+    const int n_units = p.n_streams * p.n_bins;
+    for (int v = blockIdx.x * 8 + wave; v < n_units; v += gridDim.x * 8) {
+        // bins vary fastest: the eight wavefronts of a workgroup (and the workgroups of an XCD's contiguous slice) wipe the same samples
+        const int unit_i = (n_units & 7) ? v : xcd_contiguous(v >> 3, n_units >> 3) * 8 + (v & 7);
+        const int bin = unit_i % p.n_bins, stream = unit_i / p.n_bins;
+        const double f = p.doppler[bin];
+        const double du = f * p.inv_fs;
+        const CarrierSteps cs = carrier_steps<K>(du);
+        const double u0_step = f * ((double)N * p.inv_fs);        // carrier cycles per block (utils.py:92-96)
+        const cf* src = p.iq + (int64_t)stream * p.stream_stride;
+        if (lane < G) { SatStat z; z.v = -1.0f; z.key = 0x7fffffff; z.cnt = 0; z.pad = 0; z.sum = 0.0; stats[lane] = z; }
+#pragma unroll 1
+        for (int r = 0; r < K; ++r) {
+            cf prn[32];
+            auto request_replica = [&](int g) {
+                const int sat_index = __builtin_amdgcn_readfirstlane(p.sat_ids[g]) - 1;
+                const cf* rep = replica_of(p.replica_table, sat_index) + launder(lane);
+#pragma unroll
+                for (int i = 0; i < 32; ++i) prn[i] = rep[64 * i];
+            };
+            {
+                cf* y_rows[1] = {row};
+                stage_general<K, 1>(src, COHERENT ? p.n_ms : 1, r, 0.0, u0_step, du, cs, y_rows, lane);
+                if (lane == 0) row[kChips] = make_float2(0.f, 0.f);
+            }
+            wave_lds_fence();
+            cf x[32];
+            {
+                const cf* yw = row + launder(l);
+#pragma unroll
+                for (int j = 0; j < 32; ++j) x[j] = yw[32 * j];
+            }
+            request_replica(0);
+            wave_lds_fence();                                     // every lane has its row values before the transposes overwrite the tile
+            __builtin_amdgcn_sched_barrier(0);
+            wave_fft_fwd(x, tile_half, t, l, h);
+#pragma unroll 1
+            for (int g = 0; g < p.n_sats; ++g) {
+                cf y[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) y[i] = cmul(x[i], prn[i]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 1 < p.n_sats) request_replica(g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                cf c[16];
+                wave_fft_inv(y, c, tile_half, t, l, h);
+                float mag[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) mag[j] = __builtin_amdgcn_sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
+                const WaveProfile wp = wave_profile(
+                    mag, nullptr, tid, [&](int j) { return mag[j]; },
+                    [&](int L, int j) { return K * ((L & 31) + 512 * (L >> 5)) + r + 32 * K * j; });
+                if (lane == 0) {   // utils.py:111-116: max, first arg-max, sum, count of the max -- folded in branch order like every grid kernel
+                    SatStat a = stats[g];
+                    a.sum += wp.sum;
+                    if (wp.vmax > a.v) { a.v = wp.vmax; a.key = wp.key; a.cnt = wp.cnt; }
+                    else if (wp.vmax == a.v) { a.cnt += wp.cnt; a.key = wp.key < a.key ? wp.key : a.key; }
+                    stats[g] = a;
+                }
+            }
+            wave_lds_fence();                                     // the last inverse's tile reads are done before the next branch is staged
+        }
+        if (lane < p.n_sats) {
+            const SatStat a = stats[lane];
+            gyp_cell o;
+            o.peak = a.v; o.argmax = a.key; o.sum = a.sum; o.n_max = a.cnt; o.reserved = 0; o.tap_re = 0.f; o.tap_im = 0.f;
+            p.out[(stream * p.n_sats + lane) * p.n_bins + bin] = o;
+        }
+    }
+}
+
 // The partial statistics of a cell's branch runs, folded in branch order exactly as the running statistics fold branches inside one
 // item (utils.py:111-116: max, first arg-max, sum, count of the max).  One thread per cell.
 __global__ void grid_merge_parts_kernel(GridParams p, int n_cells) {

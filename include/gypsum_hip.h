@@ -506,6 +506,10 @@ int gyp_ingest_times(const gyp_ingest* ing, int64_t first_ms, int32_t n_ms, doub
  *   "no_shared_fwd" 0/1 (0)     flat grids transform every cell's rows themselves
  *   "no_grid_parts" 0/1 (0)     flat-grid work items take whole (unit, satellite group)s even where that leaves the last round of a
  *                               launch partly empty (default: a unit's polyphase branches are cut into runs, merged afterwards)
+ *   "no_grid_fused" 0/1 (0)     flat grids that fill the chip (<= 8 samples per chip, single block) fold into rows in HBM first (r05's
+ *                               grid_fold_kernel + grid_cells_wave_shared_kernel) instead of one fused kernel per (stream, bin) unit
+ *   "last_grid_path" (read only, gyp_debug_get)  the cells kernel the last gyp_correlate_grid* call took: 1 fused, 2 shared forward
+ *                               transforms out of folded rows, 3 one wavefront per cell, 4 one workgroup per cell
  *   "no_acq_split" 0/1 (0)      a multi-stream scan runs on the caller's stream alone
  *   "acq_lanes" 1..4 (2)        parts a multi-stream scan is split into
  *   "cells_cu_reserve" 0..128 (0)  CUs the correlation-cell launches of this context leave free (a receiver's scan context beside its

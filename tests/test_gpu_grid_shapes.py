@@ -58,6 +58,7 @@ def _noncoherent_grid(eng, B, T, seed, rng_seed):
     n_units = B * T
     out_dev = eng.alloc(n_units * 32 * len(bins) * CELL.itemsize)
     eng.correlate_grid_dev(iq.ptr.value, n_units, n, 1, ALL_IDS, bins, GYP_NON_COHERENT, out_dev.ptr.value)
+    assert eng.debug_get("last_grid_path") == 1        # r06: a launch of this size takes the fused kernel (no folded rows in HBM)
     best_dev = eng.alloc(n_units * 32 * BEST_BIN.itemsize)
     eng.grid_best_bins_dev(out_dev.ptr.value, n_units * 32, len(bins), best_dev.ptr.value)
     cells = out_dev.download(CELL, n_units * 32 * len(bins)).reshape(n_units, 32, len(bins))
@@ -217,3 +218,61 @@ def test_cfg5_launch_shape_against_the_oracle(engine_factory):
     assert worst_peak <= 1e-4 and worst_strength <= 1e-4
     hits = sum(int(abs(int(got[s, sv - 1, b]["argmax"]) - cp) <= 1) for s, sv, b, cp in planted)
     assert hits >= 0.8 * len(planted), (hits, len(planted))
+
+
+@pytest.mark.parametrize("fs,n_ms,integration", [(2_046_000, 1, GYP_NON_COHERENT), (8_184_000, 1, GYP_NON_COHERENT), (2_046_000, 3, GYP_COHERENT),
+                                                 (4_092_000, 1, GYP_NON_COHERENT), (1_023_000, 2, GYP_COHERENT)])
+def test_fused_grid_kernel_against_folded_rows_and_oracle(engine_factory, fs, n_ms, integration):
+    """r06's grid_cells_wave_fused_kernel (the fold inside the cells kernel, every satellite of a (stream, bin) unit on one wavefront)
+    against r05's grid_fold_kernel + grid_cells_wave_shared_kernel on the same launch (`no_grid_fused`), and against the oracle on sampled
+    cells.  The two stage a row with different summation orders (a direct K-sample sum here, a sliding window there), so magnitudes agree
+    to float32 rounding, not bit for bit; an arg-max may differ only between lags whose magnitudes agree to that rounding."""
+    import bench
+    from oracle import gypsum_oracle as orc
+
+    n = fs // 1000
+    eng = engine_factory(fs, n)
+    B = 216                                                   # x 20 bins = 4320 units: past the fused path's threshold (16 per CU)
+    scene = bench.make_scene(np.random.default_rng(77 + n), B, 6, fs, 20.0 / n)
+    iq = eng.alloc(B * n_ms * n * 8)
+    eng.synth_iq(iq, B, n_ms * n, n_ms, scene, 6 * 20.0 / n, 4242)
+    bins = np.arange(-5000, 5000, 500, dtype=np.float64)
+    out_dev = eng.alloc(B * 32 * len(bins) * CELL.itemsize)
+
+    def run():
+        eng.correlate_grid_dev(iq.ptr.value, B, n_ms * n, n_ms, ALL_IDS, bins, integration, out_dev.ptr.value)
+        return out_dev.download(CELL, B * 32 * len(bins)).reshape(B, 32, len(bins)), int(eng.debug_get("last_grid_path"))
+
+    fused, path = run()
+    assert path == 1
+    eng.debug_set("no_grid_fused", 1)
+    try:
+        rows, path = run()
+    finally:
+        eng.debug_set("no_grid_fused", 0)
+    assert path == 2
+    np.testing.assert_allclose(fused["peak"], rows["peak"], rtol=3e-6)
+    np.testing.assert_allclose(fused["sum"], rows["sum"], rtol=3e-6)
+    other = fused["argmax"] != rows["argmax"]
+    assert other.mean() < 1e-4, other.sum()
+    assert np.array_equal(fused["n_max"][~other], rows["n_max"][~other]) or (fused["n_max"] != rows["n_max"]).mean() < 1e-4
+    # sampled cells against the reference arithmetic: the planted satellites of three streams at every bin
+    host = iq.download(np.complex64, B * n_ms * n).reshape(B, n_ms * n)
+    chips = orc.generate_ca_codes()
+    kind = orc.COHERENT if integration == GYP_COHERENT else orc.NON_COHERENT
+    checked = 0
+    for b in (0, B // 2, B - 1):
+        for sat in scene[b][:3]:
+            sv = int(sat["sat_id"])
+            for bi in range(0, len(bins), 3):
+                ref = np.abs(orc.integrate_correlation(kind, host[b], fs, n, float(bins[bi]), orc.prn_as_complex(chips[sv - 1], n)))
+                top2 = np.partition(ref, -2)[-2:]
+                if (top2[1] - top2[0]) / top2[1] < GAP:
+                    continue
+                g = fused[b, sv - 1, bi]
+                assert int(g["argmax"]) == int(np.argmax(ref)), (b, sv, bi)
+                assert float(g["peak"]) == pytest.approx(ref.max(), rel=1e-4)
+                assert float(eng.cell_strength(np.array([g]))[0]) == pytest.approx(orc.peak_strength(ref), rel=1e-4)
+                checked += 1
+    assert checked >= 50
+    iq.free(); out_dev.free()

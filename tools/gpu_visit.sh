@@ -86,6 +86,17 @@ l=json.loads(sys.stdin.read()); print({k:l[k] for k in ('value','ms_per_step','a
     r06grids)
       timeout ${SHAPES_TIMEOUT:-1200} python -m pytest tests/test_gpu_grid_shapes.py tests/test_gpu_bench_n2.py -x -q -m gpu -s -rxXs -k "launch_shape or two_ranks" > $O/pytest_grids.log 2>&1
       echo "pytest rc=$?" >> $O/pytest_grids.log; grep -v "^$" $O/pytest_grids.log | cut -c1-1500 | grep "^\[\|passed\|failed\|rc=\|UNEXPL\|knife\|Error\|assert\|^    \|^E " | tail -60 ;;
+    gridfused)
+      timeout 900 python -m pytest tests/test_gpu_grid_shapes.py tests/test_gpu_parity.py -x -q -m gpu -s -k "fused or launch_shape or grid or config5" > $O/pytest_gridfused.log 2>&1
+      echo "pytest rc=$?" >> $O/pytest_gridfused.log; grep -v "^$" $O/pytest_gridfused.log | cut -c1-900 | grep "^\[\|^\.\[\|passed\|failed\|rc=\|Error\|assert\|^E " | tail -30
+      for v in 0 1; do
+        echo "== GYP_NO_GRID_FUSED=$v"
+        for W in cfg2 cfg4; do
+          GYP_NO_GRID_FUSED=$v timeout 300 python bench.py --workload $W --no-cpu-baseline --no-telemetry --steps 6 --warmup 2 --verbose 2>/dev/null | python -c "
+import json,sys
+l=json.loads(sys.stdin.read()); print('$W', {k:l[k] for k in ('value','ms_per_step')}, l['roofline']['kernel_ms_per_launch'], l['roofline']['valu_frac'], l.get('visible_sats_found_stream0_ms0'))"
+        done
+      done ;;
     locktests)
       timeout 900 python -m pytest tests/test_gpu_track_survey.py -x -q -m gpu -s -k "locked_regime" > $O/pytest_lock.log 2>&1
       echo "pytest rc=$?" >> $O/pytest_lock.log; grep -v "^$" $O/pytest_lock.log | cut -c1-600 | tail -40 ;;
