@@ -30,7 +30,7 @@ def test_the_oracle_locks_in_a_lock_regime_scene_and_reports_margins():
     seed, path, inits, traj = survey_worker.run_scene((2_046_000, 900, 0, 5000, None, "lock"))     # a*N = 15.8, sigma^2 N = 1.2, two satellites
     os.unlink(path)
     rows = traj[0]
-    assert rows.shape[1] == 11 and np.all(rows[:, 10] > 0)      # (last column: |prompt peak|, the 1e-4 bar of the surveys)
+    assert rows.shape[1] == 12 and np.all(rows[:, 10] > 0)      # (last column: |prompt peak|, the 1e-4 bar of the surveys)
     locked = rows[:, 3] != 0
     assert locked[:240].sum() == 0 and locked.sum() > 300          # nothing before the 250-ms window has filled, then lock
     assert np.all(np.isinf(rows[:240, 7])) and np.all(np.isfinite(rows[260:, 7])) and np.all(rows[260:, 7] >= 0)
@@ -80,7 +80,7 @@ def test_sync_horizon_accepts_a_mismatch_only_with_the_oracles_margin():
     t = _tally()
     assert ts._sync_horizon(g1, r1, "x", t) == 700 and t["knife_edge"] == 1 and t["unexplained"] == 0
     # the same mismatch with a comfortable margin is a defect
-    r1[700, 7] = 1e-3
+    r1[700, 7] = 3e-6          # (r06: the band is 1e-6; 3e-6 was accepted under r05's 1e-5)
     t = _tally()
     assert ts._sync_horizon(g1, r1, "x", t) == 700 and t["unexplained"] == 1
     # a peak-offset mismatch: accepted only if the reference's two largest magnitudes are within 2e-6
@@ -111,6 +111,15 @@ def test_sync_horizon_accepts_a_mismatch_only_with_the_oracles_margin():
     t = _tally()
     ts._sync_horizon(g4, r4, "x", t)
     assert t["unexplained"] == 1
+    # r06: ... and only if the float64 oracle's own twin of the channel (3e-7 rad off) has separated by then -- an oracle-only criterion
+    g4["doppler_hz"] = 1e-3
+    r4b = np.hstack([r4, np.zeros((n, 1)), np.full((n, 1), np.inf)])      # columns 10 (|peak|) and 11 (fragile_from): the twin never differs
+    t = _tally()
+    ts._sync_horizon(g4, r4b, "x", t)
+    assert t["unexplained"] == 1 and t["unlocked_divergence"] == 0
+    r4b[:, 11] = 2500                                                       # the twin differs 700 ms after the device did: same instability
+    t = _tally()
+    assert ts._sync_horizon(g4, r4b, "x", t) == 1800 and t["unlocked_divergence"] == 1
     # a pseudosymbol whose peak has a zero real part in an unlocked channel: the float32 floor, counted elsewhere, does not end the comparison
     g5, r5 = g.copy(), r.copy()
     r5[:, 3] = 0
