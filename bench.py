@@ -1135,7 +1135,7 @@ def compact_line(d: dict) -> dict:
         elif isinstance(r, dict) and "error" in r:
             legs[name] = {"error": r["error"][:80]}
     for name, key in (("s8184", "single_stream"), ("s8184_lock", "single_stream_locked"), ("s2046", "single_stream_2046"),
-                      ("s2046_lock", "single_stream_2046_locked"), ("s16368", "single_stream_16368"), ("s16368_lock", "single_stream_16368_locked")):
+                      ("s2046_aN41", "single_stream_2046_aN41"), ("s2046_lock", "single_stream_2046_locked"), ("s16368", "single_stream_16368"), ("s16368_lock", "single_stream_16368_locked")):
         single(name, key)
     if isinstance(d.get("single_stream_snr"), list):
         legs["snr_x"] = {str(p_["aN"]): p_["x_realtime"] for p_ in d["single_stream_snr"]}
@@ -1321,6 +1321,11 @@ def main() -> None:
         # profiles/r05_experiments.txt item 9).  r01-r04 ran them behind the headline.
         run_legs((("single_stream", lambda: {**run_single_stream(eng, eng2), "method": SINGLE_STREAM_METHOD}),
                   ("single_stream_2046", lambda: run_single_stream(eng, eng2, fs=2_046_000)),
+                  # the same rate on the headline's amplitude rule (a N = 41, sigma = 6 a: peak^2 / energy ~ 18-24, a fifth of the milliseconds
+                  # would fail a kappa = 18.6 confidence test) in 5-s blocks: with blocks longer than the reference's 6-s watchdog period its
+                  # own rule drops all twelve channels of such a scene (circularity < 0.2) and a dropped channel costs nothing
+                  ("single_stream_2046_aN41", lambda: run_single_stream(eng, eng2, steps=6, warmup=2, fs=2_046_000, amplitude=41.0 / 2046,
+                                                                        sigma=6 * 41.0 / 2046, T=5000)),
                   # the reference's third recording format (radio_input.py:111, 16x): same scene rule as tools/rate_probe.py (a N = 41, sigma = 6 a)
                   ("single_stream_16368", lambda: run_single_stream(eng, eng2, steps=5, warmup=2, fs=16_368_000, amplitude=41.0 / 16368,
                                                                     sigma=6 * 41.0 / 16368)),

@@ -58,7 +58,7 @@ RECORD_SIZES = {"gyp_bit_event": BIT_EVENT.itemsize, "gyp_bits_state": BITS_STAT
                 "gyp_chan_in": CHAN_IN.itemsize, "gyp_chan_out": CHAN_OUT.itemsize, "gyp_best_bin": BEST_BIN.itemsize,
                 "gyp_params": PARAMS.itemsize, "gyp_track_rec": TRACK_REC.itemsize}
 # include/gypsum_hip.h GYP_VERSION these mirrors were written against: load() refuses any other library
-GYP_VERSION = 202
+GYP_VERSION = 203
 
 EXPORTS = (
     "gyp_version gyp_create gyp_destroy gyp_last_error gyp_device_name gyp_set_stream gyp_sync gyp_wait_for gyp_timer_start "
@@ -66,7 +66,7 @@ EXPORTS = (
     "gyp_memcpy_h2d gyp_memcpy_d2h gyp_memcpy_d2h_async gyp_cell_strength gyp_correlate_cells_dev gyp_correlate_cells gyp_correlate_grid_dev "
     "gyp_correlate_grid gyp_acquire_dev gyp_params_default gyp_set_params gyp_get_params gyp_search_level_dev gyp_search_level "
     "gyp_acquire gyp_track_step_dev gyp_track_step gyp_bank_create gyp_bank_destroy gyp_bank_size gyp_bank_set_channel gyp_bank_drop_channel "
-    "gyp_track_block_dev gyp_track_block gyp_bank_get_state gyp_bank_keep_profiles gyp_bank_read_profiles gyp_synth_iq_dev gyp_synth_nav_bit gyp_bank_reset_dev gyp_debug_track_profile gyp_debug_fft_bench gyp_debug_spec_read gyp_debug_dll_read gyp_debug_track_timing gyp_debug_set gyp_debug_get gyp_debug_spec_redo_read gyp_debug_spec_layout gyp_device_locality "
+    "gyp_track_block_dev gyp_track_block gyp_bank_get_state gyp_bank_keep_profiles gyp_bank_read_profiles gyp_synth_iq_dev gyp_synth_nav_bit gyp_bank_reset_dev gyp_debug_track_profile gyp_debug_fft_bench gyp_debug_spec_read gyp_debug_dll_read gyp_debug_track_timing gyp_debug_set gyp_debug_get gyp_debug_spec_redo_read gyp_debug_spec_layout gyp_debug_spec_layout_for gyp_device_locality "
     "gyp_grid_best_bins_dev gyp_comm_unique_id gyp_comm_init gyp_comm_destroy gyp_comm_info gyp_allgather_dev gyp_host_alloc gyp_host_free gyp_widen_iq_dev "
     "gyp_bits_create gyp_bits_destroy gyp_bits_reset gyp_bits_push gyp_bits_push_block gyp_bits_drain gyp_bits_get_state "
     "gyp_ingest_open gyp_ingest_close gyp_ingest_total_ms gyp_ingest_set_scale gyp_ingest_seek gyp_ingest_next_host gyp_ingest_next_dev gyp_ingest_times"
@@ -148,6 +148,7 @@ def load() -> C.CDLL:
         "gyp_debug_track_timing": (C.c_int, [vp, C.c_int, vp]),
         "gyp_debug_spec_redo_read": (C.c_int, [vp, vp]),
         "gyp_debug_spec_layout": (C.c_int, [C.c_int32, vp]),
+        "gyp_debug_spec_layout_for": (C.c_int, [C.c_int32, C.c_int32, vp]),
         "gyp_device_locality": (C.c_int, [vp, C.POINTER(i32), C.c_char_p, i32]),
         "gyp_debug_set": (C.c_int, [vp, C.c_char_p, dbl]),
         "gyp_debug_get": (C.c_int, [vp, C.c_char_p, C.POINTER(dbl)]),

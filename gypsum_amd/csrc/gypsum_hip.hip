@@ -143,6 +143,7 @@ struct gyp_ctx {
     void* comm = nullptr;
     int comm_rank = 0, comm_world = 1;
     gyp_params params;
+    int spec_sub_ms = 0;         // gyp_debug_set("spec_sub_ms"): target length of a speculative block's sub-blocks (a failed verification costs one); 0 = by rate (spec_sub_ms_for)
     bool spec_redo = true;       // gyp_debug_set("spec_redo"): 0 = A/B switch back to re-running a failed speculation on the throughput kernel
     int prof_wave = 0;           // gyp_debug_set("prof_wave"): which wavefront of workgroup 0 stamps gyp_debug_track_profile's counters
     int exact_prefetch = 0;      // gyp_debug_set("exact_prefetch"): A/B switch of dll_exact_wave_kernel's software prefetch depth
@@ -1389,7 +1390,11 @@ static int track_block_throughput(gyp_bank* bank, TrackBlockParams p, const int3
 // Sub-blocks of a speculative block: the last sub-block's verification trails the tracking, and a failed verification costs a
 // sub-block (more, shorter ones for long blocks); each round re-reads the channel state and the tables (~20 us).
 static constexpr int kMaxSub = 20;
-static int spec_sub_blocks(int n_ms) { return n_ms >= 2048 ? std::min(kMaxSub, std::max(4, n_ms / 500)) : (n_ms >= 256 ? 4 : 1); }
+static int spec_sub_ms_for(const gyp_ctx* ctx) { return ctx->spec_sub_ms >= 100 ? ctx->spec_sub_ms : (ctx->k == 2 ? 167 : 500); }
+static int spec_sub_blocks(int n_ms, int sub_ms = 500) {   // sub_ms: target sub-block length (gyp_debug_set "spec_sub_ms"; 500 by default)
+    const int cap = sub_ms == 500 ? kMaxSub : kMaxSubBlocks - 2;   // (a layout ends with two more, shrinking, sub-blocks: SubLayout holds 32)
+    return n_ms >= 2048 ? std::min(cap, std::max(4, n_ms / sub_ms)) : (n_ms >= 256 ? 4 : 1);
+}
 // ... and their lengths: equal ones, except that a block of sub-blocks of >= 160 ms ends with three shrinking ones (0.56, 0.34 and
 // 0.20 of the usual length) in place of its last one (SubLayout: only the last sub-block's verification is not hidden behind tracking;
 // each piece is ~0.6 of the one before because round R waits for the verification of round R - 2, which takes about half as long
@@ -1472,7 +1477,13 @@ static int spec_prepare(gyp_bank* bank, TrackBlockParams& p, size_t n_rec) {
     // gyp_params::spec_confidence_kappa is quoted for 8184 lags: the chance that some noise lag beats a peak of kappa x the sample
     // energy is (number of lags) x exp(-kappa), so a rate with fewer lags reaches the same risk at a lower threshold (2.046 Msps:
     // 20 -> 18.6, which moves ~5 % of its milliseconds from the in-kernel transform path to the fast path; 16.368 Msps: 20.7)
-    p.spec_kappa = (float)std::max(0.0, ctx->params.spec_confidence_kappa + (ctx->params.spec_confidence_kappa > 0.0 ? std::log((double)ctx->n / 8184.0) : 0.0));
+    // r06, 2.046 Msps only: a further -5 (20 -> 13.6) together with sub-blocks of ~167 ms instead of ~500 (spec_sub_ms_for).  At two
+    // samples per chip a millisecond that fails the test runs its transforms on TWO of the workgroup's eight wavefronts (~15 us against
+    // 2.9 on the fast path), and a verification that fails costs its channel one short sub-block: measured on five scenes / seeds at
+    // a N = 18..41, sigma = 6 a (tools/kappa_sweep.py, profiles/r06_experiments.txt item 2): 180-205 x -> 217-245 x real time, SURVEY d2's
+    // cfg2 scene 316 -> 320 x.  8.184 / 16.368 Msps: no difference within the noise of the measurement, left alone.
+    const double kappa_rate = std::log((double)ctx->n / 8184.0) + (ctx->k == 2 ? -5.0 : 0.0);
+    p.spec_kappa = (float)std::max(0.0, ctx->params.spec_confidence_kappa + (ctx->params.spec_confidence_kappa > 0.0 ? kappa_rate : 0.0));
     if (ctx->spec_debug) {
         if (bank->dbg_cap < n_rec * 20) {
             if (bank->d_dbg) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(bank->d_dbg)); }
@@ -1502,7 +1513,7 @@ static int track_block_speculative_rerun(gyp_bank* bank, TrackBlockParams p) {
     gyp_ctx* ctx = bank->ctx;
     const size_t n_rec = (size_t)bank->n_chan * p.n_ms;
     int rc;
-    const SubLayout lay = spec_layout(p.n_ms, spec_sub_blocks(p.n_ms));
+    const SubLayout lay = spec_layout(p.n_ms, spec_sub_blocks(p.n_ms, spec_sub_ms_for(ctx)));
     const int n_sub = lay.n;
     if ((rc = ensure_spec_buffers(bank, n_sub, 1))) return rc;
     if ((rc = ensure_dll_buffers(bank, n_rec))) return rc;
@@ -1551,7 +1562,7 @@ static int track_block_speculative_rerun(gyp_bank* bank, TrackBlockParams p) {
 // synchronises with the host.
 static int track_block_speculative(gyp_bank* bank, TrackBlockParams p) {
     gyp_ctx* ctx = bank->ctx;
-    const SubLayout lay = spec_layout(p.n_ms, spec_sub_blocks(p.n_ms));
+    const SubLayout lay = spec_layout(p.n_ms, spec_sub_blocks(p.n_ms, spec_sub_ms_for(ctx)));
     const int n_sub_used = lay.n;
     // The rounds couple the tracking launches to the verify launches two rounds back, so the verify kernels must keep up beside the
     // tracking -- on the CUs the channels leave free, one workgroup per CU (launch_track_verify).  That holds for a receiver's bank
@@ -1828,9 +1839,10 @@ int gyp_debug_spec_read(gyp_bank* bank, float* out, int32_t n_floats, int32_t* b
     return GYP_OK;
 }
 
-int gyp_debug_spec_layout(int32_t n_ms, int32_t* starts_out) {
-    if (n_ms <= 0 || !starts_out) return GYP_E_BAD_ARG;
-    const SubLayout l = spec_layout(n_ms, spec_sub_blocks(n_ms));
+int gyp_debug_spec_layout(int32_t n_ms, int32_t* starts_out) { return gyp_debug_spec_layout_for(n_ms, 500, starts_out); }
+int gyp_debug_spec_layout_for(int32_t n_ms, int32_t sub_ms, int32_t* starts_out) {
+    if (n_ms <= 0 || sub_ms < 100 || sub_ms > 2000 || !starts_out) return GYP_E_BAD_ARG;
+    const SubLayout l = spec_layout(n_ms, spec_sub_blocks(n_ms, sub_ms));
     for (int i = 0; i <= l.n; ++i) starts_out[i] = l.start[i];
     return l.n;
 }
@@ -1921,7 +1933,7 @@ const DebugKnob kDebugKnobs[] = {
     {"no_pipe", 0, 1, true}, {"no_shared_fwd", 0, 1, true}, {"no_acq_split", 0, 1, true}, {"no_spec", 0, 1, true},
     {"spec_debug", 0, 1, true}, {"acq_lanes", 1, gyp_ctx::kMaxAcqLanes, true}, {"track_chunk_ms", 0, 1e6, true},
     {"symbol_tau", 0, 100, false}, {"dll_prov_bias", -1e6, 1e6, false}, {"spec_fail_at", -1, 2147483647.0, true},
-    {"spec_redo", 0, 1, true}, {"exact_prefetch", 0, 1, true}, {"prof_wave", 0, 7, true}, {"no_grid_parts", 0, 1, true}, {"no_grid_fused", 0, 1, true}, {"cells_cu_reserve", 0, 128, true},
+    {"spec_redo", 0, 1, true}, {"spec_sub_ms", 0, 2000, true}, {"exact_prefetch", 0, 1, true}, {"prof_wave", 0, 7, true}, {"no_grid_parts", 0, 1, true}, {"no_grid_fused", 0, 1, true}, {"cells_cu_reserve", 0, 128, true},
 };
 }  // namespace
 static int debug_apply(gyp_ctx* ctx, const char* name, double v, bool set, double* out) {
@@ -1938,6 +1950,7 @@ static int debug_apply(gyp_ctx* ctx, const char* name, double v, bool set, doubl
     GYP_KNOB_BOOL("no_spec", no_spec)
     GYP_KNOB_BOOL("spec_debug", spec_debug)
     GYP_KNOB_BOOL("spec_redo", spec_redo)
+    GYP_KNOB_NUM("spec_sub_ms", spec_sub_ms, int)
     GYP_KNOB_NUM("acq_lanes", acq_lanes, int)
     GYP_KNOB_NUM("track_chunk_ms", track_chunk_ms, int)
     GYP_KNOB_NUM("symbol_tau", symbol_tau, float)

@@ -28,11 +28,13 @@
 extern "C" {
 #endif
 
-/* 202: gyp_memcpy_d2h_async added (per-ms records leave the device on a copy stream while the next block is tracked).
+/* 203: gyp_debug_spec_layout_for added (sub-block length by rate: ~167 ms at 2.046 Msps, r06); new gyp_debug_set names (no_grid_fused,
+ *      spec_sub_ms) and the read-only "last_grid_path".
+ * 202: gyp_memcpy_d2h_async added (per-ms records leave the device on a copy stream while the next block is tracked).
  * 201: gyp_debug_set / gyp_debug_get / gyp_debug_spec_redo_read / gyp_debug_spec_layout added (the library no longer reads GYP_* environment switches).
  * 200: gyp_chan_out carries the float64 early/late pair (80 bytes), gyp_track_rec::path_info, gyp_debug_track_profile writes
  * 16 values, gyp_params grew; a binding written against another value must not load the library (gypsum_amd/_lib.py checks). */
-#define GYP_VERSION 202 /* 0.2.2 */
+#define GYP_VERSION 203 /* 0.2.3 */
 
 enum {
     GYP_OK = 0,
@@ -101,7 +103,9 @@ typedef struct gyp_params {
      * (~1e-7 relative), and so do peak_re/peak_im/error/doppler_hz/carrier_phase downstream.  Two lags whose |c|^2 the
      * float32 transform cannot order (within 4e-6 relative) count as agreement with the window's choice.
      * The value is quoted for 8184 lags (8.184 Msps): the chance that a noise lag beats a peak of kappa x energy is (lags) x exp(-kappa),
-     * so the library applies kappa + ln(N / 8184) at N samples per millisecond (18.6 at 2.046 Msps, 20.7 at 16.368); 0 stays 0. */
+     * so the library applies kappa + ln(N / 8184) at N samples per millisecond (20.7 at 16.368 Msps); 0 stays 0.  At 2.046 Msps it
+     * applies a further -5 (20 -> 13.6, with sub-blocks of ~167 ms): there a millisecond off the fast path costs five fast ones and a
+     * failed verification one short sub-block (r06, measured: 190 x -> 217-245 x real time at a N = 41, sigma = 6 a). */
     double spec_confidence_kappa;      /* 20 */
     /* acquisition.py:200-219: the reference keeps a cache of integrated profiles keyed by (data, Doppler, PRN) but has its
      * lookup switched off (`if False and key in ...`, "to rule it out as a confounding factor"), so it correlates a bin
@@ -510,6 +514,8 @@ int gyp_ingest_times(const gyp_ingest* ing, int64_t first_ms, int32_t n_ms, doub
  *                               grid_fold_kernel + grid_cells_wave_shared_kernel) instead of one fused kernel per (stream, bin) unit
  *   "last_grid_path" (read only, gyp_debug_get)  the cells kernel the last gyp_correlate_grid* call took: 1 fused, 2 shared forward
  *                               transforms out of folded rows, 3 one wavefront per cell, 4 one workgroup per cell
+ *   "spec_sub_ms" 0, 100..2000 (0)  target length of the sub-blocks of a speculative tracking block (a failed verification costs its
+ *                               channel one); 0: by rate -- 167 ms at 2.046 Msps, 500 ms otherwise
  *   "no_acq_split" 0/1 (0)      a multi-stream scan runs on the caller's stream alone
  *   "acq_lanes" 1..4 (2)        parts a multi-stream scan is split into
  *   "cells_cu_reserve" 0..128 (0)  CUs the correlation-cell launches of this context leave free (a receiver's scan context beside its
@@ -559,6 +565,9 @@ int gyp_debug_spec_redo_read(gyp_bank* bank, int32_t* out4);
  * with shrinking sub-blocks because only the LAST sub-block's verification is not hidden behind tracking.
  * starts_out must hold 33 values.  Returns n, or GYP_E_BAD_ARG (negative). */
 int gyp_debug_spec_layout(int32_t n_ms, int32_t* starts_out);
+/* The same for a target sub-block length of sub_ms (100..2000): what a context at 2.046 Msps uses (167) against 500 elsewhere -- at two
+ * samples per chip a millisecond is cheap and a failed verification should cost few of them ("spec_sub_ms" of gyp_debug_set overrides). */
+int gyp_debug_spec_layout_for(int32_t n_ms, int32_t sub_ms, int32_t* starts_out);
 /* Debug: time `iters` forward+inverse wavefront transform pairs per wavefront, `wgs` workgroups of `waves_per_wg`
  * wavefronts (LDS-resident data, no global traffic): the floor the correlator kernels are measured against. */
 int gyp_debug_fft_bench(gyp_ctx* ctx, int waves_per_wg, int wgs, int iters, float* ms_out);

@@ -249,3 +249,12 @@ def test_speculative_blocks_are_cut_into_sub_blocks_that_cover_them_and_shrink_a
             assert tail[0] <= 0.6 * body[0] + 1 and tail[1] <= 0.65 * tail[0] + 1, (n_ms, lens)
             assert tail[0] >= 0.5 * body[0] and tail[1] >= 0.5 * tail[0], (n_ms, lens)   # no step steeper than a half
             assert lens[-1] <= 0.3 * body[0] + 32, (n_ms, lens)
+    # r06: the ~167-ms sub-blocks of a 2.046 Msps context (a failed verification costs one): still a partition of at most 32 pieces
+    assert lib.gyp_debug_spec_layout_for(5000, 50, _lib.ptr(out)) == _lib.GYP_E_BAD_ARG
+    for n_ms in (300, 2048, 5000, 6109, 10000, 60000):
+        n = lib.gyp_debug_spec_layout_for(n_ms, 167, _lib.ptr(out))
+        assert 1 <= n <= 32, (n_ms, n)
+        starts = out[: n + 1].astype(int)
+        assert starts[0] == 0 and starts[n] == n_ms and (np.diff(starts) > 0).all(), (n_ms, starts)
+        if n_ms == 5000:
+            assert n >= 29 and np.diff(starts).max() <= 185, (n, np.diff(starts))
