@@ -507,8 +507,10 @@ __global__ __launch_bounds__(512, 2) void grid_cells_wave_fused_kernel(GridParam
     }
 }
 
-// The partial statistics of a cell's branch runs, folded in branch order exactly as the running statistics fold branches inside one
-// item (utils.py:111-116: max, first arg-max, sum, count of the max).  One thread per cell.
+// The partial statistics of a cell's branch runs, folded in branch order as the running statistics fold branches inside one item
+// (utils.py:111-116): max, first arg-max and count of the max come out bit for bit as from whole-unit items; the float64 sum is
+// re-associated -- (s_0 + ..) + (s_k + ..) instead of one running sum -- so gyp_cell::sum, and the strength formed from it, agree to
+// rounding (1e-15), not to the bit, and may differ with the number of runs the host picked.  One thread per cell.
 __global__ void grid_merge_parts_kernel(GridParams p, int n_cells) {
     const int cell = blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= n_cells) return;

@@ -81,6 +81,20 @@ def test_rccl_communicator_comes_up_in_either_import_order(order):
     assert f"{order} comm ok" in r.stdout and "'uses_rccl': 1" in r.stdout, r.stdout[-2000:]
 
 
+def test_dist_record_gather_goes_through_the_librarys_collective():
+    """gypsum_amd.dist.sharded_grid_search / RankComm.allgather_records with a real engine: the gather is gyp_allgather_dev (ncclAllGather
+    on a one-rank RCCL communicator) -- the ONE collective call path of the package since r06 (the torch all_gather_into_tensor
+    variant the gloo test used to exercise is gone) -- and the gathered table equals the unsharded call's bytes."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    repo = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(repo / "tools" / "dist_records_probe.py")], cwd=str(repo), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "dist records ok" in r.stdout, r.stdout[-2000:]
+
+
 def test_bench_line_through_rccl_on_one_rank():
     """bench.py with the distributed plumbing forced on (gloo rendezvous of one rank + a real RCCL communicator): the step's
     all-gather is ncclAllGather issued by the library, and the line says so."""
