@@ -15,6 +15,7 @@ os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
 os.environ.setdefault("OMP_NUM_THREADS", "1")
 os.environ.setdefault("MKL_NUM_THREADS", "1")
 
+import math
 import sys
 import tempfile
 from pathlib import Path
@@ -39,11 +40,8 @@ def scene_inits(scene, rng):
 def run_scene(args):
     """args = (fs, n_ms, n_sats, seed, keep_iq_dir[, regime]).  Returns (seed, iq_path, inits, traj) with traj[ch] an int64/float64
     array of per-ms rows (pseudosymbol, code_phase_after, peak_offset, locked, doppler_after, lost_flag, nudged, lock_margin,
-    |Re peak| / |peak|, argmax_margin, |peak|, fragile_from).  `fragile_from` (lock regime only, else inf; the same value in every row of a
-    channel): the first row at which a SECOND float64 oracle tracker of the same channel, started with its carrier phase 3e-7 rad off --
-    the size of the device's float32 peak rounding -- produces a different integer (pseudosymbol, code phase, peak offset, lock flag)
-    than the first: from there on the reference's own trajectory is not determined to better than float32 rounding (an unlocked Costas
-    loop amplifies perturbations), which is an oracle-only criterion for the surveys' "unlocked loop separated" excuse."""
+    |Re peak| / |peak|, argmax_margin, |peak|, fragile_from).  `fragile_from`: NaN = not computed (the surveys compute it on demand,
+    `fragile_from` below, for the rare channel whose mismatch asks for the "unlocked loop separated" excuse)."""
     fs, n_ms, n_sats, seed, iq_dir = args[:5]
     regime = args[5] if len(args) > 5 else "pull-in"
     from gypsum_amd import synth
@@ -69,7 +67,7 @@ def run_scene(args):
     for sv, dop, phi, cp in inits:
         trk = orc.Tracker(orc.TrackingState(dop, phi, cp), orc.prn_as_complex(chips[sv - 1], n), fs, n)
         rows = np.zeros((len(times), 12), dtype=np.float64)
-        rows[:, 11] = np.inf
+        rows[:, 11] = np.nan
         trk.record_margins = regime == "lock"
         for j, (st, en) in enumerate(times):
             ms = 9 + j
@@ -80,24 +78,37 @@ def run_scene(args):
                 break
             rows[j, :11] = (r.pseudosymbol, r.code_phase_after, r.peak_offset, float(r.locked), r.doppler_after, 0.0, float(r.nudged),
                        r.lock_margin, abs(r.peak.real) / max(abs(r.peak), 1e-300), r.argmax_margin, abs(r.peak))
-        if regime == "lock":
-            twin = orc.Tracker(orc.TrackingState(dop, float(np.angle(np.exp(1j * (phi + 3e-7)))), cp), orc.prn_as_complex(chips[sv - 1], n), fs, n)
-            for j, (st, en) in enumerate(times):
-                if rows[j, 5] != 0:
-                    break
-                try:
-                    q = twin.process_samples(iq[(9 + j) * n:(10 + j) * n], st, en)
-                except orc.LostSatelliteLock:
-                    rows[:, 11] = j
-                    break
-                if (q.pseudosymbol, q.code_phase_after, q.peak_offset, float(q.locked)) != tuple(rows[j, :4]):
-                    rows[:, 11] = j
-                    break
         traj.append(rows)
     base = iq_dir or ("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir())
     path = os.path.join(base, f"gyp_survey_{os.getpid()}_{seed}.npy")
     np.save(path, iq)
     return seed, path, inits, traj
+
+
+def fragile_from(iq_from_ms9, fs, init, rows) -> float:
+    """The first row at which a SECOND float64 oracle tracker of the channel `init` = (sat_id, doppler, carrier_phase, code_phase), started
+    with its carrier phase 3e-7 rad off -- the size of the device's float32 peak rounding -- produces a different integer (pseudosymbol,
+    code phase, peak offset, lock flag) than the first one did (`rows`, run_scene's trajectory): from there on the reference's own
+    trajectory is not determined to better than float32 rounding (an unlocked Costas loop amplifies perturbations).  inf: never within
+    the rows.  An ORACLE-ONLY witness for the surveys' "unlocked loop separated" excuse."""
+    from oracle import gypsum_oracle as orc
+
+    n = fs // 1000
+    sv, dop, phi, cp = init
+    chips = orc.generate_ca_codes()
+    twin = orc.Tracker(orc.TrackingState(dop, float(np.angle(np.exp(1j * (phi + 3e-7)))), cp), orc.prn_as_complex(chips[sv - 1], n), fs, n)
+    flat = np.asarray(iq_from_ms9).reshape(-1)
+    for j in range(len(rows)):
+        if rows[j, 5] != 0:
+            break
+        st, en = orc.chunk_times((9 + j) * n, n, fs)
+        try:
+            q = twin.process_samples(flat[j * n:(j + 1) * n], st, en)
+        except orc.LostSatelliteLock:
+            return float(j)
+        if (q.pseudosymbol, q.code_phase_after, q.peak_offset, float(q.locked)) != tuple(rows[j, :4]):
+            return float(j)
+    return math.inf
 
 
 def run_acq_scene(args):

@@ -8,6 +8,7 @@ process on the GPU.  ~1.05 million channel-milliseconds at 8.184 Msps go through
 """
 from __future__ import annotations
 
+import math
 import multiprocessing as mp
 import os
 import time
@@ -60,7 +61,7 @@ FRAGILE_SLACK_MS = 1500   # an "unlocked loop separated" event is accepted only 
                           # produced a different integer no later than this many ms after the device did (survey_worker.run_scene)
 
 
-def _sync_horizon(g, r, where, tally):
+def _sync_horizon(g, r, where, tally, twin=None):
     """Lock regime: how many leading milliseconds of a channel are held to "every integer equal".
 
     Two things can legitimately end that, and both are properties of the REFERENCE's arithmetic, not of this device:
@@ -79,7 +80,8 @@ def _sync_horizon(g, r, where, tally):
       estimates already measurably apart (> 1e-5 Hz) on the millisecond before AND -- r06, an oracle-only criterion (the
       Doppler difference is itself a GPU-vs-oracle quantity, a device bug that drifts an unlocked loop would satisfy it) -- the float64
       oracle's own twin of the channel, started 3e-7 rad off in carrier phase, having lost integer agreement with it by then
-      (`fragile_from`, column 11 of the worker's rows, within FRAGILE_SLACK_MS).
+      (`survey_worker.fragile_from`, computed on demand through `twin` -- or taken from column 11 of the rows if a caller filled it --
+      within FRAGILE_SLACK_MS).
     A pseudosymbol whose peak has |Re| < 2e-4 |peak| in a channel that is not locked is the float32 floor documented in r03 (counted,
     does not end the comparison).  Anything else is `unexplained` and fails the test."""
     sym = g["pseudosymbol"] != r[:, 0].astype(np.int64)
@@ -94,21 +96,33 @@ def _sync_horizon(g, r, where, tally):
     what = f"{where} ms {9 + j}: lock gpu {int(g['locked'][j])} oracle {int(lk[j])} (oracle margin {r[j, 7]:.2e}), peak offset gpu " \
            f"{int(g['peak_offset'][j])} oracle {int(r[j, 2])} (oracle's top-two gap {r[j, 9]:.2e}), pseudosymbol gpu " \
            f"{int(g['pseudosymbol'][j])} oracle {int(r[j, 0])}, code phase gpu {int(g['code_phase'][j])} oracle {int(r[j, 1])}, Doppler " \
-           f"difference the ms before {ddop:.2e} Hz" + (f", the oracle's own 3e-7-rad twin differs from ms {9 + int(r[0, 11])}" if r.shape[1] > 11 and np.isfinite(r[0, 11]) else
-                                                        (", the oracle's own 3e-7-rad twin never differs" if r.shape[1] > 11 else ""))
+           f"difference the ms before {ddop:.2e} Hz"
     if (g["locked"].astype(bool) != lk)[j] and r[j, 7] < KNIFE_EDGE:
         tally["knife_edge"] += 1
         tally["events"].append("knife-edge lock verdict: " + what)
     elif g["peak_offset"][j] != int(r[j, 2]) and r[j, 9] < ARGMAX_EDGE:
         tally["knife_edge_argmax"] += 1
         tally["events"].append("knife-edge arg-max: " + what)
-    elif j + 9 >= 1000 and not lk[max(0, j - 250):j + 1].any() and ddop > 1e-5 and (r.shape[1] <= 11 or r[0, 11] <= j + FRAGILE_SLACK_MS):
+    elif j + 9 >= 1000 and not lk[max(0, j - 250):j + 1].any() and ddop > 1e-5 and _fragile(r, twin) <= j + FRAGILE_SLACK_MS:
         tally["unlocked_divergence"] += 1
         tally["events"].append("unlocked loop separated: " + what)
     else:
         tally["unexplained"] += 1
         tally["events"].append("UNEXPLAINED: " + what)
+    if r.shape[1] > 11 and not np.isnan(r[0, 11]):
+        tally["events"][-1] += (f"; the oracle's own 3e-7-rad twin differs from ms {9 + int(r[0, 11])}" if np.isfinite(r[0, 11]) else
+                                "; the oracle's own 3e-7-rad twin never differs")
     return j
+
+
+def _fragile(r, twin):
+    """fragile_from of the channel (survey_worker.fragile_from): column 11 if filled, else computed now through `twin` and stored there;
+    rows without the column (r05-format trajectories, the host tests) do not ask for the witness."""
+    if r.shape[1] <= 11:
+        return -math.inf
+    if np.isnan(r[0, 11]):
+        r[:, 11] = twin() if twin is not None else math.inf
+    return r[0, 11]
 
 
 def _compare(eng, seed, path, inits, traj, n_ms, tally, label, FS=FS, N=N):
@@ -120,17 +134,17 @@ def _compare(eng, seed, path, inits, traj, n_ms, tally, label, FS=FS, N=N):
     bank = eng.create_bank(init_rec)
     rec = bank.track_block(iq[9 * N:], 1, n_ms - 9, t0)
     bank.close()
-    _tally_scene(rec, seed, traj, tally, label, tally.get("regime"))
+    _tally_scene(rec, seed, traj, tally, label, tally.get("regime"), twin=lambda i: survey_worker.fragile_from(iq[9 * N:], FS, inits[i], traj[i]))
 
 
-def _tally_scene(rec, seed, traj, tally, label, regime):
+def _tally_scene(rec, seed, traj, tally, label, regime, twin=None):
     """One scene's channels (`rec[i]` = the device's records of channel i from ms 9 on) against the oracle's trajectories."""
     for i, rows in enumerate(traj):
         alive = rows[:, 5] == 0
         k = int(alive.sum())
         k_all = k
         if regime == "lock":
-            k = _sync_horizon(rec[i, :k], rows[:k], f"{label} seed {seed} ch {i}", tally)
+            k = _sync_horizon(rec[i, :k], rows[:k], f"{label} seed {seed} ch {i}", tally, twin=(lambda i=i: twin(i)) if twin else None) if k else 0
             tally["n_after_event"] += k_all - k
         g = rec[i, :k]
         r = rows[:k]
@@ -432,7 +446,8 @@ def _multi_stream_survey(eng, specs, n_ms, label, FS=FS, N=N):
     at = 0
     for seed, _, _ in specs:
         inits, traj = got[seed]
-        _tally_scene(rec[at:at + len(inits)], seed, traj, tally, f"{label} stream {stream_of[seed]}", regime_of[seed])
+        _tally_scene(rec[at:at + len(inits)], seed, traj, tally, f"{label} stream {stream_of[seed]}", regime_of[seed],
+                     twin=lambda i, seed=seed, inits=inits, traj=traj: survey_worker.fragile_from(iq[stream_of[seed]], FS, inits[i], traj[i]))
         at += len(inits)
     print(f"[{label}] ONE bank of {len(init_rec)} channels over {len(specs)} streams x {T} ms at {FS / 1e6:.3f} Msps (seed offset {SEED_OFFSET}; "
           f"oracle pool {procs} processes, {time.time() - t_start:.0f} s in all, gyp_track_block {t_gpu:.2f} s incl. the upload): {tally['n']} channel-ms compared, "

@@ -113,7 +113,11 @@ def test_sync_horizon_accepts_a_mismatch_only_with_the_oracles_margin():
     assert t["unexplained"] == 1
     # r06: ... and only if the float64 oracle's own twin of the channel (3e-7 rad off) has separated by then -- an oracle-only criterion
     g4["doppler_hz"] = 1e-3
-    r4b = np.hstack([r4, np.zeros((n, 1)), np.full((n, 1), np.inf)])      # columns 10 (|peak|) and 11 (fragile_from): the twin never differs
+    r4b = np.hstack([r4, np.zeros((n, 1)), np.full((n, 1), np.nan)])      # columns 10 (|peak|) and 11 (fragile_from, NaN = ask the twin)
+    t = _tally()
+    asked = []
+    ts._sync_horizon(g4, r4b, "x", t, twin=lambda: asked.append(1) or float("inf"))    # the twin never differs: computed on demand, once
+    assert t["unexplained"] == 1 and t["unlocked_divergence"] == 0 and asked == [1] and np.isinf(r4b[0, 11])
     t = _tally()
     ts._sync_horizon(g4, r4b, "x", t)
     assert t["unexplained"] == 1 and t["unlocked_divergence"] == 0
