@@ -208,29 +208,34 @@ def cpu_baseline_cfg3(fs: int, n: int, sample: dict = None) -> dict:
     chips = orc.generate_ca_codes()
     parity = None
     if sample is not None:
-        iq, sats = sample["iq"], [int(v) for v in sample["sat_ids"][:3]]
+        iq, sats = sample["iq"], [int(v) for v in sample["sat_ids"][:len(sample["rec"])]]
+        acq_sats = [int(v) for v in sample["sat_ids"][:8]]
     else:
         scene = synth.random_scene(fs, 130, 12, 4242, max_code_phase=2046)
         iq, sats = synth.render(scene), [s.sat_id for s in scene.sats[:3]]
+        acq_sats = sats
     t_acq, results = [], {}
-    for sv in sats:
+    for sv in acq_sats:
         t0 = time.perf_counter()
         results[sv] = orc.acquire_satellite(sv, iq[:10 * n], fs, n, orc.prn_as_complex(chips[sv - 1], n))
         t_acq.append(time.perf_counter() - t0)
     t_trk = []
-    n_trk_ms = 120
+    n_trk_ms = 400 if sample is not None else 120
     bad = []
     worst_mag = 0.0
+    if sample is not None:
+        for sv in acq_sats:      # the device's acquisition records of the same samples (bit-exact Doppler bin / code phase, strength and carrier phase 1e-4)
+            a, g = results[sv], sample["acq"][sv - 1]
+            if int(g["doppler_hz"]) != int(a.doppler_shift) or int(g["code_phase"]) != int(a.prn_phase_shift) or \
+                    abs(float(g["strength"]) - a.correlation_strength) > 1e-4 * a.correlation_strength or \
+                    abs(math.remainder(float(g["carrier_phase"]) - a.carrier_wave_phase_shift, math.tau)) > 1e-4:
+                bad.append(f"acq sv{sv}")
     for c, sv in enumerate(sats):
         a = results[sv]
         if sample is not None:
             # teacher-forced start: the oracle's tracker begins where the device's did (its own acquisition record, compared below)
             g = sample["acq"][sv - 1]
             init = (float(g["doppler_hz"]), float(g["carrier_phase"]), int(g["code_phase"]))
-            if int(g["doppler_hz"]) != int(a.doppler_shift) or int(g["code_phase"]) != int(a.prn_phase_shift) or \
-                    abs(float(g["strength"]) - a.correlation_strength) > 1e-4 * a.correlation_strength or \
-                    abs(math.remainder(float(g["carrier_phase"]) - a.carrier_wave_phase_shift, math.tau)) > 1e-4:
-                bad.append(f"acq sv{sv}")
         else:
             init = (a.doppler_shift, a.carrier_wave_phase_shift, a.prn_phase_shift)
         trk = orc.Tracker(orc.TrackingState(*init), orc.prn_as_complex(chips[sv - 1], n), fs, n)
@@ -250,10 +255,11 @@ def cpu_baseline_cfg3(fs: int, n: int, sample: dict = None) -> dict:
                     bad.append(f"trk sv{sv} ms{ms}")
                     break
     if sample is not None:
-        parity = {"ok": not bad, "acq_sats": len(sats), "track_channel_ms": len(sats) * n_trk_ms, "worst_prompt_mag_rel": float(f"{worst_mag:.2e}"),
+        parity = {"ok": not bad, "acq_sats": len(acq_sats), "track_channel_ms": len(sats) * n_trk_ms, "worst_prompt_mag_rel": float(f"{worst_mag:.2e}"),
                   **({"first_bad": bad[:3]} if bad else {})}
     acq_s, trk_s = statistics.median(t_acq), statistics.median(t_trk)
     ov = reference_bookkeeping_overheads(n)
+    n_sampled = f"{len(acq_sats)} sats / {len(sats)} ch x {n_trk_ms} ms"
     n_calls = 231                                          # ~230 Doppler bins over the ten levels + the coherent pass, per satellite
     acq_ref, trk_ref = acq_s + ov["acquisition_call_overhead_s"] * n_calls, trk_s + ov["tracker_ms_overhead_s"]
     t_10s = 32 * acq_s + 10_000 * 12 * trk_s               # 10 s of one stream: one 32-sat scan + 10 000 ms x 12 channels
@@ -266,15 +272,15 @@ def cpu_baseline_cfg3(fs: int, n: int, sample: dict = None) -> dict:
         # (tools/calibrate_port.py -> profiles/r05_port_calibration.json): value / port_over_reference reads as a reference figure
         "port_over_reference": cal,
         "acq_s_per_sat": round(acq_s, 4), "track_ms_per_channel_ms": round(trk_s * 1e3, 4),
-        "sample_short": f"32 sats x {acq_s:.3f} s + 12 ch x 1e4 ms x {trk_s * 1e3:.3f} ms; 3 sats / 120 ms of "
-                        f"{'stream 0 of the benchmarked input' if sample is not None else 'a synthetic scene'}, median of 3",
+        "sample_short": f"32 sats x {acq_s:.3f} s + 12 ch x 1e4 ms x {trk_s * 1e3:.3f} ms; {n_sampled} of "
+                        f"{'the benchmarked stream 0' if sample is not None else 'a synthetic scene'}, medians",
         # the oracle's outputs on that sample against the device's records of the same samples: Doppler bin, code phase (bit-exact), strength,
-        # carrier phase (1e-4) of the three acquisitions; pseudosymbol, int(self.phase), prompt arg-max, lock flag (bit-exact) and prompt |.|
-        # (1e-4) of 3 x 120 tracked milliseconds
+        # carrier phase (1e-4) of the eight acquisitions; pseudosymbol, int(self.phase), prompt arg-max, lock flag (bit-exact) and prompt |.|
+        # (1e-4) of 6 x 400 tracked milliseconds
         "parity_sampled_ok": (parity or {}).get("ok"), "parity_sample": parity,
         "value_with_reference_bookkeeping": round(10.0 * fs / t_10s_ref / 1e6, 5),
-        "sample": f"numpy oracle (reference algorithm, float64 pocketfft), median of 3: full 10-level acquisition "
-                  f"{acq_s:.3f} s/sat, tracker {trk_s * 1e3:.3f} ms/channel-ms over 120 ms, at {fs / 1e6:.3f} Msps, scaled to "
+        "sample": f"numpy oracle (reference algorithm, float64 pocketfft), medians over {n_sampled}: full 10-level acquisition "
+                  f"{acq_s:.3f} s/sat, tracker {trk_s * 1e3:.3f} ms/channel-ms, at {fs / 1e6:.3f} Msps, scaled to "
                   f"32 sats / 10 s + 12 channels.  The oracle leaves out the reference's per-ms np.array(deque) "
                   f"({ov['tracker_ms_overhead_s'] * 1e6:.0f} us, tracker.py:356) and per-correlation hash/tobytes "
                   f"({ov['acquisition_call_overhead_s'] * 1e6:.0f} us x ~{n_calls} calls/sat, acquisition.py:203), measured here "
@@ -440,11 +446,11 @@ class Cfg3Setup:
                 self.eng.host_free(h)
             self.rec_host = None
 
-    def parity_sample(self, rec: np.ndarray, n_ms: int = 130) -> dict:
+    def parity_sample(self, rec: np.ndarray, n_ms: int = 400, n_chan: int = 6) -> dict:
         """What cpu_baseline_cfg3 times the oracle on and checks it against: the first `n_ms` of stream 0 as the device holds them, the
-        device's acquisition records of that stream and its tracking records (from the bank's reset state) of the first three channels."""
+        device's acquisition records of that stream and its tracking records (from the bank's reset state) of the first `n_chan` channels."""
         return {"iq": self.iq.download(np.complex64, min(n_ms, self.T) * self.n), "sat_ids": self.scene[0]["sat_id"].copy(),
-                "acq": self.acq_stream0, "rec": [rec[0, c, :n_ms].copy() for c in range(3)]}
+                "acq": self.acq_stream0, "rec": [rec[0, c, :n_ms].copy() for c in range(min(n_chan, self.C))]}
 
     def symbol_agreement(self, rec: np.ndarray, max_streams: int = 8) -> float:
         T = self.T
