@@ -37,6 +37,9 @@ def show(d):
     # the last scan starts at the last acq_plan_kernel that follows an acq_finish_kernel (or the first one)
     starts = [i for i, r in enumerate(rows) if "acq_plan_kernel" in r["Kernel_Name"] and (i == 0 or "acq_finish" in rows[i - 1]["Kernel_Name"]
                                                                                              or "synth" in rows[i - 1]["Kernel_Name"])]
+    if not starts:   # r04 on: a scan's search states are initialised on the device -- it starts with one acq_init_kernel per part (two parts)
+        inits = [i for i, r in enumerate(rows) if "acq_init_kernel" in r["Kernel_Name"]]
+        starts = [inits[-2] if len(inits) >= 2 else inits[-1]]
     rows = rows[starts[-1]:]
     t0 = int(rows[0]["Start_Timestamp"])
     prev_end = t0
