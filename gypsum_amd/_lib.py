@@ -67,7 +67,7 @@ EXPORTS = (
     "gyp_correlate_grid gyp_acquire_dev gyp_params_default gyp_set_params gyp_get_params gyp_search_level_dev gyp_search_level "
     "gyp_acquire gyp_track_step_dev gyp_track_step gyp_bank_create gyp_bank_destroy gyp_bank_size gyp_bank_set_channel gyp_bank_drop_channel "
     "gyp_track_block_dev gyp_track_block gyp_bank_get_state gyp_bank_keep_profiles gyp_bank_read_profiles gyp_synth_iq_dev gyp_synth_nav_bit gyp_bank_reset_dev gyp_debug_track_profile gyp_debug_fft_bench gyp_debug_spec_read gyp_debug_dll_read gyp_debug_track_timing gyp_debug_set gyp_debug_get gyp_debug_spec_redo_read gyp_debug_spec_layout gyp_debug_spec_layout_for gyp_device_locality "
-    "gyp_grid_best_bins_dev gyp_comm_unique_id gyp_comm_init gyp_comm_destroy gyp_comm_info gyp_allgather_dev gyp_host_alloc gyp_host_free gyp_widen_iq_dev "
+    "gyp_grid_best_bins_dev gyp_grid_best_bins_refined_dev gyp_comm_unique_id gyp_comm_init gyp_comm_destroy gyp_comm_info gyp_allgather_dev gyp_host_alloc gyp_host_free gyp_widen_iq_dev "
     "gyp_bits_create gyp_bits_destroy gyp_bits_reset gyp_bits_push gyp_bits_push_block gyp_bits_drain gyp_bits_get_state "
     "gyp_ingest_open gyp_ingest_close gyp_ingest_total_ms gyp_ingest_set_scale gyp_ingest_seek gyp_ingest_next_host gyp_ingest_next_dev gyp_ingest_times"
 ).split()
@@ -153,6 +153,7 @@ def load() -> C.CDLL:
         "gyp_debug_set": (C.c_int, [vp, C.c_char_p, dbl]),
         "gyp_debug_get": (C.c_int, [vp, C.c_char_p, C.POINTER(dbl)]),
         "gyp_grid_best_bins_dev": (C.c_int, [vp, vp, i32, i32, vp]),
+        "gyp_grid_best_bins_refined_dev": (C.c_int, [vp, vp, i32, i64, i32, vp, i32, vp, i32, i32, vp, vp]),
         "gyp_comm_unique_id": (C.c_int, [vp]),
         "gyp_comm_init": (C.c_int, [vp, i32, i32, vp]),
         "gyp_comm_destroy": (C.c_int, [vp]),

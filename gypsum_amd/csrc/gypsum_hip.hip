@@ -124,6 +124,7 @@ struct gyp_ctx {
     float symbol_tau = 1e-4f;     // gyp_debug_set("symbol_tau"): |Re peak| / |peak| below which the pseudosymbol is decided in float64 (test hook: 10 = always)
     bool no_shared_fwd = false;   // gyp_debug_set("no_shared_fwd"): A/B switch: flat grids transform every cell's rows themselves again
     int cells_cu_reserve = 0;     // gyp_debug_set("cells_cu_reserve", n): CUs the correlation-cell launches leave free (see launch_cells)
+    int last_grid_refined_rows = 0;   // gyp_debug_get("last_grid_refined_rows"): rows the last gyp_grid_best_bins_refined_dev call decided in float64
     int last_grid_path = 0;       // gyp_debug_get("last_grid_path"): which cells kernel the last gyp_correlate_grid* call took (1 fused, 2 shared forward, 3 one wavefront per cell, 4 workgroup per cell)
     bool no_grid_fused = false;   // gyp_debug_set("no_grid_fused"): A/B switch: flat grids go through grid_fold_kernel + folded rows in HBM (r05) instead of the fused kernel
     bool no_grid_parts = false;   // gyp_debug_set("no_grid_parts"): A/B switch: flat-grid work items take whole units (no branch runs + merge)
@@ -948,6 +949,57 @@ int gyp_grid_best_bins_dev(gyp_ctx* ctx, const gyp_cell* cells_dev, int32_t n_ro
     if (!cells_dev || !out_dev || n_rows < 0 || n_bins <= 0) return fail(ctx, GYP_E_BAD_ARG, "gyp_grid_best_bins_dev: bad argument");
     if (n_rows == 0) return GYP_OK;
     hipLaunchKernelGGL(grid_best_bin_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, ctx->stream, cells_dev, n_rows, n_bins, ctx->n, out_dev);
+    HIP_TRY(ctx, hipGetLastError());
+    return GYP_OK;
+}
+
+int gyp_grid_best_bins_refined_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_t stream_stride_samples, int32_t n_ms,
+                                   const int32_t* sat_ids_host, int32_t n_sats, const double* doppler_hz_host, int32_t n_bins, int32_t integration,
+                                   const gyp_cell* cells_dev, gyp_best_bin* out_dev) {
+    if (!ctx) return GYP_E_BAD_ARG;
+    if (!ctx->k) return fail(ctx, GYP_E_NO_FORMAT, "gyp_set_stream_format has not been called");
+    if (!iq_dev || !sat_ids_host || !doppler_hz_host || !cells_dev || !out_dev || n_streams <= 0 || n_ms <= 0 || n_sats <= 0 || n_bins <= 0 ||
+        (integration != GYP_COHERENT && integration != GYP_NON_COHERENT))
+        return fail(ctx, GYP_E_BAD_ARG, "gyp_grid_best_bins_refined_dev: bad argument");
+    for (int i = 0; i < n_sats; ++i)
+        if (sat_ids_host[i] < 1 || sat_ids_host[i] > 32) return fail(ctx, GYP_E_BAD_ARG, "satellite id out of range");
+    const int64_t n_rows = (int64_t)n_streams * n_sats, n_cells = n_rows * n_bins;
+    if (n_cells > 2147483647LL / 2) return fail(ctx, GYP_E_BAD_ARG, "gyp_grid_best_bins_refined_dev: grid too large");
+    int rc;
+    // scratch: the ids and bins (slots 1 / 4 as in gyp_correlate_grid_dev), the work list + counters + pending rows, the per-ms sums
+    if ((rc = ensure_scratch(ctx, 1, (size_t)n_sats * sizeof(int32_t) + 64))) return rc;
+    if ((rc = ensure_scratch(ctx, 4, (size_t)n_bins * sizeof(double) + 64))) return rc;
+    if ((rc = ensure_scratch(ctx, 8, (size_t)(n_cells + 2 * n_rows + 4) * sizeof(int32_t)))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[1], sat_ids_host, (size_t)n_sats * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[4], doppler_hz_host, (size_t)n_bins * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    GridRefineParams p;
+    p.iq = reinterpret_cast<const cf*>(iq_dev);
+    p.stream_stride = stream_stride_samples;
+    p.n_ms = n_ms; p.n_per_ms = ctx->n; p.k = ctx->k; p.n_sats = n_sats; p.n_bins = n_bins; p.n_rows = (int32_t)n_rows;
+    p.coherent = integration == GYP_COHERENT ? 1 : 0;
+    p.sat_ids = (const int32_t*)ctx->scratch[1];
+    p.doppler = (const double*)ctx->scratch[4];
+    p.cells = cells_dev; p.out = out_dev; p.chips = ctx->d_chips; p.inv_fs = 1.0 / (double)ctx->fs;
+    p.n_cand = (int32_t*)ctx->scratch[8];
+    p.pend_rows = p.n_cand + 4;
+    p.pend_first = p.pend_rows + n_rows;
+    p.cand = p.pend_first + n_rows;
+    HIP_TRY(ctx, hipMemsetAsync(p.n_cand, 0, 4 * sizeof(int32_t), ctx->stream));
+    p.partial = nullptr;
+    hipLaunchKernelGGL(grid_best_bin_select_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    // how many candidates there are decides the size of the per-millisecond sums: one small read-back (the host arrays above are
+    // temporaries of the caller anyway: the entry point synchronises like gyp_correlate_grid_dev)
+    int32_t counts[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(counts, p.n_cand, sizeof(counts), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->last_grid_refined_rows = counts[1];
+    if (counts[0] == 0) return GYP_OK;
+    if ((rc = ensure_scratch(ctx, 9, (size_t)counts[0] * n_ms * 2 * sizeof(double)))) return rc;
+    p.partial = (double*)ctx->scratch[9];
+    hipLaunchKernelGGL(grid_refine_kernel, dim3((unsigned)std::min(counts[0], 65535), (unsigned)n_ms), dim3(256), 0, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(grid_best_bin_decide_kernel, dim3((unsigned)std::min((counts[1] + 63) / 64, 1024)), dim3(64), 0, ctx->stream, p);
     HIP_TRY(ctx, hipGetLastError());
     return GYP_OK;
 }
@@ -1944,6 +1996,7 @@ static int debug_apply(gyp_ctx* ctx, const char* name, double v, bool set, doubl
     GYP_KNOB_BOOL("no_shared_fwd", no_shared_fwd)
     GYP_KNOB_BOOL("no_grid_parts", no_grid_parts)
     GYP_KNOB_BOOL("no_grid_fused", no_grid_fused)
+    if (is("last_grid_refined_rows")) { if (set) return GYP_E_BAD_ARG; *out = (double)ctx->last_grid_refined_rows; return GYP_OK; }
     if (is("last_grid_path")) { if (set) return GYP_E_BAD_ARG; *out = (double)ctx->last_grid_path; return GYP_OK; }
     GYP_KNOB_NUM("cells_cu_reserve", cells_cu_reserve, int)
     GYP_KNOB_BOOL("no_acq_split", no_acq_split)

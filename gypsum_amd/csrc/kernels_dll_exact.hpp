@@ -597,4 +597,124 @@ __global__ void grid_best_bin_kernel(const gyp_cell* __restrict__ cells, int n_r
     out[row] = o;
 }
 
+// ---- the same selection with a float64 tie-break (r06) -------------------------------------------------------------------------
+// "Which bin holds the largest maximum" (acquisition.py:180-182) cannot always be decided from float32 cells: two bins of a row can
+// agree to ~1e-6 -- two bins at equal distance from the true Doppler do by construction -- and float32 magnitudes carry 3e-7.  As in
+// the 10-level search (acq_refine_kernel), every bin whose peak is within kGridTieBand of the row's maximum is re-evaluated in float64,
+// straight from the samples in the time domain, at its own arg-max lag:
+//     c_ms = sum_n x[ms, n] * exp(-2 pi i f t(ms, n)) * code[(n - lag) mod N]       V = sum_ms |c_ms|  (non-coherent)  or  |sum_ms c_ms|
+// -- the profile value the float64 reference compares -- and the first bin with the largest V wins.  Rows with one candidate (all but
+// ~1 %) are written by the first kernel and cost nothing more.
+constexpr float kGridTieBand = 2e-5f;
+struct GridRefineParams {
+    const cf* iq;
+    int64_t stream_stride;
+    int32_t n_ms, n_per_ms, k, n_sats, n_bins, n_rows, coherent;
+    const int32_t* sat_ids;        // [n_sats]
+    const double* doppler;         // [n_bins]
+    const gyp_cell* cells;         // [n_rows][n_bins], n_rows = n_streams x n_sats
+    gyp_best_bin* out;             // [n_rows]
+    const uint8_t* chips;          // [32][1023]
+    double inv_fs;
+    int32_t* cand;                 // work list: row * n_bins + bin of every candidate of every row with more than one
+    int32_t* n_cand;               // [0] length of cand, [1] rows with more than one candidate
+    int32_t* pend_rows;            // those rows ...
+    int32_t* pend_first;           // ... and where each one's candidates start in `cand` (contiguous, ascending bin)
+    double* partial;               // [cand][n_ms][2]: c_ms (re, im)
+};
+__global__ void grid_best_bin_select_kernel(GridRefineParams p) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= p.n_rows) return;
+    const gyp_cell* c = p.cells + (int64_t)row * p.n_bins;
+    int best = 0;
+    float pk = c[0].peak;
+    for (int b = 1; b < p.n_bins; ++b)
+        if (c[b].peak > pk) { pk = c[b].peak; best = b; }
+    const float floor_ = pk * (1.0f - kGridTieBand);
+    int n = 0;
+    for (int b = 0; b < p.n_bins; ++b) n += !(c[b].peak < floor_) ? 1 : 0;
+    const gyp_cell w = c[best];
+    gyp_best_bin o;
+    o.bin = best; o.argmax = w.argmax; o.peak = w.peak; o.reserved = n > 1 ? 1 : 0;     // reserved: 1 = decided by the float64 tie-break below
+    const double pd = (double)w.peak;
+    o.strength = pd / ((w.sum - (double)w.n_max * pd) / (double)(p.n_per_ms - w.n_max));
+    p.out[row] = o;
+    if (n > 1) {
+        const int at = atomicAdd(p.n_cand, n);
+        const int slot = atomicAdd(p.n_cand + 1, 1);
+        p.pend_rows[slot] = row; p.pend_first[slot] = at;
+        int k = 0;
+        for (int b = 0; b < p.n_bins; ++b)
+            if (!(c[b].peak < floor_)) p.cand[at + k++] = row * p.n_bins + b;
+    }
+}
+// grid (candidate slots, n_ms), 256 threads: c_ms of one candidate cell and millisecond (the arithmetic of acq_refine_kernel)
+__global__ __launch_bounds__(256) void grid_refine_kernel(GridRefineParams p) {
+    __shared__ double red_re[4], red_im[4];
+    const int n_cand = p.n_cand[0], ms = blockIdx.y;
+    for (int c = blockIdx.x; c < n_cand; c += gridDim.x) {
+        const int ci = p.cand[c], row = ci / p.n_bins, bin = ci - row * p.n_bins;
+        const int stream = row / p.n_sats, sat = p.sat_ids[row % p.n_sats];
+        const int n = p.n_per_ms, lag = p.cells[ci].argmax;
+        const uint8_t* code = p.chips + (sat - 1) * kChips;
+        const cf* block = p.iq + (int64_t)stream * p.stream_stride + (int64_t)ms * n;
+        const double f = p.doppler[bin], du = f * p.inv_fs;
+        double s_step, c_step;
+        sincospi(2.0 * (du * 256.0 - rint(du * 256.0)), &s_step, &c_step);     // exp(-2*pi*i*du*256) = (c, -s)
+        const double u = f * (((double)((int64_t)ms * n) + (double)threadIdx.x) * p.inv_fs);
+        double sn, cs;
+        sincospi(2.0 * (u - rint(u)), &sn, &cs);
+        double car_re = cs, car_im = -sn, acc_re = 0.0, acc_im = 0.0;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            int cidx = i - lag;
+            cidx = cidx < 0 ? cidx + n : cidx;
+            const double sgn = code[cidx / p.k] ? 1.0 : -1.0;
+            const cf x = block[i];
+            acc_re += sgn * ((double)x.x * car_re - (double)x.y * car_im);
+            acc_im += sgn * ((double)x.x * car_im + (double)x.y * car_re);
+            const double nr = car_re * c_step + car_im * s_step;             // car *= (c_step - i*s_step)
+            car_im = car_im * c_step - car_re * s_step;
+            car_re = nr;
+        }
+        acc_re = wave_sum(acc_re);
+        acc_im = wave_sum(acc_im);
+        if ((threadIdx.x & 63) == 0) { red_re[threadIdx.x >> 6] = acc_re; red_im[threadIdx.x >> 6] = acc_im; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double* o = p.partial + ((int64_t)c * p.n_ms + ms) * 2;
+            o[0] = (red_re[0] + red_re[1]) + (red_re[2] + red_re[3]);
+            o[1] = (red_im[0] + red_im[1]) + (red_im[2] + red_im[3]);
+        }
+        __syncthreads();
+    }
+}
+// one thread per pending row: its candidates sit contiguously in `cand` from pend_first on (ascending bin); the first bin with the largest float64 value wins
+__global__ void grid_best_bin_decide_kernel(GridRefineParams p) {
+    const int n_pend = p.n_cand[1], n_cand = p.n_cand[0];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pend; i += gridDim.x * blockDim.x) {
+        const int row = p.pend_rows[i], first = p.pend_first[i];
+        int best_bin = -1;
+        double best_v = -1.0;
+        for (int c = first; c < n_cand && p.cand[c] / p.n_bins == row; ++c) {
+            const double* q = p.partial + (int64_t)c * p.n_ms * 2;
+            double v;
+            if (p.coherent) {
+                double re = 0.0, im = 0.0;
+                for (int ms = 0; ms < p.n_ms; ++ms) { re += q[2 * ms]; im += q[2 * ms + 1]; }
+                v = sqrt(re * re + im * im);
+            } else {
+                v = 0.0;
+                for (int ms = 0; ms < p.n_ms; ++ms) v += sqrt(q[2 * ms] * q[2 * ms] + q[2 * ms + 1] * q[2 * ms + 1]);   // millisecond order, as utils.py:100-106 integrates
+            }
+            if (v > best_v) { best_v = v; best_bin = p.cand[c] - row * p.n_bins; }
+        }
+        const gyp_cell w = p.cells[(int64_t)row * p.n_bins + best_bin];
+        gyp_best_bin o;
+        o.bin = best_bin; o.argmax = w.argmax; o.peak = w.peak; o.reserved = 1;
+        const double pd = (double)w.peak;
+        o.strength = pd / ((w.sum - (double)w.n_max * pd) / (double)(p.n_per_ms - w.n_max));
+        p.out[row] = o;
+    }
+}
+
 }  // namespace gyp

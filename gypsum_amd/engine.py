@@ -258,6 +258,16 @@ class GypsumEngine:
         """acquisition.py:180-189 per (stream, satellite) row of a flat grid's records, on the device (BEST_BIN records)."""
         self._check(self.lib.gyp_grid_best_bins_dev(self.ctx, C.c_void_p(cells_ptr), int(n_rows), int(n_bins), C.c_void_p(out_ptr)))
 
+    def grid_best_bins_refined_dev(self, iq_ptr: int, n_streams: int, stream_stride: int, n_ms: int, sat_ids: Sequence[int],
+                                   doppler_hz: Sequence[float], integration: int, cells_ptr: int, out_ptr: int) -> int:
+        """The same selection with the float64 tie-break between near-equal bins (gyp_grid_best_bins_refined_dev): the grid as
+        correlate_grid_dev took it + the records it wrote.  Returns the number of rows decided in float64."""
+        ids = np.ascontiguousarray(sat_ids, dtype=np.int32)
+        bins = np.ascontiguousarray(doppler_hz, dtype=np.float64)
+        self._check(self.lib.gyp_grid_best_bins_refined_dev(self.ctx, C.c_void_p(iq_ptr), n_streams, stream_stride, n_ms, ptr(ids), len(ids),
+                                                             ptr(bins), len(bins), integration, C.c_void_p(cells_ptr), C.c_void_p(out_ptr)))
+        return int(self.debug_get("last_grid_refined_rows"))
+
     def cell_strength(self, cells: np.ndarray) -> np.ndarray:
         """utils.py:111-116 on the reduced record, float64."""
         pk = cells["peak"].astype(np.float64)

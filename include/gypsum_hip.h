@@ -28,8 +28,9 @@
 extern "C" {
 #endif
 
-/* 203: gyp_debug_spec_layout_for added (sub-block length by rate: ~167 ms at 2.046 Msps, r06); new gyp_debug_set names (no_grid_fused,
- *      spec_sub_ms) and the read-only "last_grid_path".
+/* 203: gyp_debug_spec_layout_for added (sub-block length by rate: ~167 ms at 2.046 Msps, r06), gyp_grid_best_bins_refined_dev added (float64
+ *      tie-break of the flat grids' best-bin selection); new gyp_debug_set names (no_grid_fused, spec_sub_ms) and the read-only
+ *      "last_grid_path" / "last_grid_refined_rows".
  * 202: gyp_memcpy_d2h_async added (per-ms records leave the device on a copy stream while the next block is tracked).
  * 201: gyp_debug_set / gyp_debug_get / gyp_debug_spec_redo_read / gyp_debug_spec_layout added (the library no longer reads GYP_* environment switches).
  * 200: gyp_chan_out carries the float64 early/late pair (80 bytes), gyp_track_rec::path_info, gyp_debug_track_profile writes
@@ -209,6 +210,14 @@ typedef struct gyp_best_bin {
     double strength;     /* correlation_strength of that bin's profile */
 } gyp_best_bin;
 int gyp_grid_best_bins_dev(gyp_ctx* ctx, const gyp_cell* cells_dev, int32_t n_rows, int32_t n_bins, gyp_best_bin* out_dev);
+/* The same selection with a float64 tie-break (ABI 203): float32 cells cannot always say which of two bins holds the larger maximum (two
+ * bins at equal distance from the true Doppler agree to ~1e-6 by construction).  Every bin of a row whose peak is within 2e-5 of the row's
+ * maximum is re-evaluated in float64 from the samples, in the time domain, at its own arg-max lag -- the value acquisition.py:180-182
+ * compares -- and the first bin holding the largest wins; gyp_best_bin::reserved = 1 in the rows decided that way (about 1 %).  Takes the
+ * grid exactly as gyp_correlate_grid_dev took it (same iq / ids / bins / integration) plus the records it wrote.  Synchronises the stream. */
+int gyp_grid_best_bins_refined_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams, int64_t stream_stride_samples, int32_t n_ms,
+                                   const int32_t* sat_ids_host, int32_t n_sats, const double* doppler_hz_host, int32_t n_bins,
+                                   int32_t integration, const gyp_cell* cells_dev, gyp_best_bin* out_dev);
 
 /* ---------------------------------------------------------------- acquisition ------------------------- */
 /* acquisition.py:35-41 SatelliteAcquisitionAttemptResult */

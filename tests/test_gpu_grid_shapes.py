@@ -46,7 +46,7 @@ def _pool_size(n_jobs: int) -> int:
     return max(1, min(64, (os.cpu_count() or 2) - 2, n_jobs))
 
 
-def _noncoherent_grid(eng, B, T, seed, rng_seed):
+def _noncoherent_grid(eng, B, T, seed, rng_seed, refined=False):
     """bench.run_grid's launch: B streams x T ms at 2.046 Msps, every (stream, ms) a unit of stride N, 32 satellites x range(-5000, 5000, 500)."""
     import bench
 
@@ -60,7 +60,11 @@ def _noncoherent_grid(eng, B, T, seed, rng_seed):
     eng.correlate_grid_dev(iq.ptr.value, n_units, n, 1, ALL_IDS, bins, GYP_NON_COHERENT, out_dev.ptr.value)
     assert eng.debug_get("last_grid_path") == 1        # r06: a launch of this size takes the fused kernel (no folded rows in HBM)
     best_dev = eng.alloc(n_units * 32 * BEST_BIN.itemsize)
-    eng.grid_best_bins_dev(out_dev.ptr.value, n_units * 32, len(bins), best_dev.ptr.value)
+    if refined:      # the float64 tie-break between near-equal bins (gyp_grid_best_bins_refined_dev)
+        n_ref = eng.grid_best_bins_refined_dev(iq.ptr.value, n_units, n, 1, ALL_IDS, bins, GYP_NON_COHERENT, out_dev.ptr.value, best_dev.ptr.value)
+        print(f"[refined best bins] {n_ref} of {n_units * 32} rows had more than one bin within 2e-5 of the row maximum and were decided in float64")
+    else:
+        eng.grid_best_bins_dev(out_dev.ptr.value, n_units * 32, len(bins), best_dev.ptr.value)
     cells = out_dev.download(CELL, n_units * 32 * len(bins)).reshape(n_units, 32, len(bins))
     best = best_dev.download(BEST_BIN, n_units * 32).reshape(n_units, 32)
     host_iq = iq.download(np.complex64, n_units * n).reshape(n_units, n)
@@ -154,11 +158,12 @@ def test_cfg4_launch_shape_every_best_bin_record_against_the_oracle(engine_facto
     fs, n = 2_046_000, 2046
     eng = engine_factory(fs, n)
     B, T = 64, 64
-    scene, bins, cells, best, host_iq = _noncoherent_grid(eng, B, T, 99, 5)
+    scene, bins, cells, best, host_iq = _noncoherent_grid(eng, B, T, 99, 5, refined=True)
     rows = [(u, sv) for u in range(B * T) for sv in ALL_IDS]
-    t = _check_rows(eng, cells, best, host_iq, rows, "cfg4 launch shape (64 streams x 64 ms, every record)")
+    t = _check_rows(eng, cells, best, host_iq, rows, "cfg4 launch shape (64 streams x 64 ms, every record, float64 tie-break between bins)")
     assert t["rows"] == B * T * 32
-    assert t["argmax_knife"] <= 8 and t["bin_knife"] <= 4, t       # expected ~1 per 1e6 cells / 3e5 rows from the gap statistics; printed above
+    assert t["argmax_knife"] <= 8, t       # arg-max WITHIN a cell: expected ~1 per 1e6 cells from the gap statistics; printed above
+    assert t["bin_knife"] == 0, t          # the best BIN of all 131 072 rows as the reference picks it: near-equal bins are decided in float64
 
 
 def test_cfg5_launch_shape_against_the_oracle(engine_factory):
@@ -276,3 +281,46 @@ def test_fused_grid_kernel_against_folded_rows_and_oracle(engine_factory, fs, n_
                 checked += 1
     assert checked >= 50
     iq.free(); out_dev.free()
+
+
+def test_refined_best_bin_decides_bins_float32_cannot(engine_factory):
+    """Two Doppler bins at equal distance from the true Doppler hold the same maximum by construction: 512 noise-free one-satellite units at
+    -250 Hz +- up to 5e-4 Hz put the -500 Hz and the 0 Hz bin within ~1e-7 of each other -- below float32 resolution -- and the reference picks
+    by its float64 values (acquisition.py:180-182).  gyp_grid_best_bins_refined_dev re-evaluates such bins in float64 from the samples and must
+    agree with the oracle in EVERY unit; the float32 selection (gyp_grid_best_bins_dev) is reported beside it."""
+    from oracle import gypsum_oracle as orc
+
+    fs, n = 2_046_000, 2046
+    eng = engine_factory(fs, n)
+    rng = np.random.default_rng(606)
+    U = 512
+    chips = orc.generate_ca_codes()
+    sv = 7
+    prn = orc.prn_as_complex(chips[sv - 1], n).real
+    t = np.arange(n) / fs
+    iq = np.empty((U, n), dtype=np.complex64)
+    for u in range(U):
+        d = -250.0 + rng.uniform(-5e-4, 5e-4)
+        iq[u] = (0.02 * np.roll(prn, int(rng.integers(0, n))) * np.exp(1j * (2 * np.pi * d * t + rng.uniform(0, 2 * np.pi)))).astype(np.complex64)
+    bins = np.arange(-5000, 5000, 500, dtype=np.float64)
+    dev = eng.alloc(iq.nbytes).upload(iq)
+    sats = [sv, 3, 11, 19]
+    out_dev = eng.alloc(U * len(sats) * len(bins) * CELL.itemsize)
+    eng.correlate_grid_dev(dev.ptr.value, U, n, 1, sats, bins, GYP_NON_COHERENT, out_dev.ptr.value)
+    b32, b64 = eng.alloc(U * len(sats) * BEST_BIN.itemsize), eng.alloc(U * len(sats) * BEST_BIN.itemsize)
+    eng.grid_best_bins_dev(out_dev.ptr.value, U * len(sats), len(bins), b32.ptr.value)
+    n_ref = eng.grid_best_bins_refined_dev(dev.ptr.value, U, n, 1, sats, bins, GYP_NON_COHERENT, out_dev.ptr.value, b64.ptr.value)
+    f32 = b32.download(BEST_BIN, U * len(sats)).reshape(U, len(sats))
+    f64 = b64.download(BEST_BIN, U * len(sats)).reshape(U, len(sats))
+    want = np.array([orc.best_doppler_bin(0.0, 5000.0, iq[u], fs, n, orc.prn_as_complex(chips[sv - 1], n)) for u in range(U)], dtype=object)
+    want_bin = np.array([w.bins.index(w.doppler_hz) for w in want])
+    assert set(want_bin) == {9, 10}                                  # -500 Hz or 0 Hz, as the float64 values fall
+    wrong32 = int(np.sum(f32[:, 0]["bin"] != want_bin))
+    assert np.array_equal(f64[:, 0]["bin"], want_bin), np.flatnonzero(f64[:, 0]["bin"] != want_bin)
+    assert np.array_equal(f64[:, 0]["argmax"], np.array([w.peak_index for w in want]))
+    assert np.all(f64[:, 0]["reserved"] == 1) and n_ref >= U        # every planted row went through the tie-break
+    print(f"[refined best bins] {U} units with two bins within ~1e-7: float64 tie-break agrees with the oracle in all of them; the float32 "
+          f"selection differs in {wrong32}")
+    assert wrong32 > 0                                               # the case is real: float32 alone cannot decide these rows
+    for b in (dev, out_dev, b32, b64):
+        b.free()
