@@ -323,24 +323,6 @@ def cpu_baseline_cfg3_all_cores(fs: int, n: int) -> dict:
     }
 
 
-def cpu_baseline_cfg2(fs: int, n: int) -> dict:
-    from gypsum_amd import synth
-    from oracle import gypsum_oracle as orc
-
-    chips = orc.generate_ca_codes()
-    iq, _, _ = synth.kat_grid_scene()
-    n_sat, runs = 6, []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        for sv in range(1, n_sat + 1):
-            orc.best_doppler_bin(0.0, 5000.0, iq, fs, n, orc.prn_as_complex(chips[sv - 1], n))
-        runs.append((time.perf_counter() - t0) * 32 / n_sat)
-    t_ms = statistics.median(runs)
-    return {"value": round(n / t_ms / 1e6, 5), "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "x_realtime": round(1e-3 / t_ms, 6),
-            "sample": f"numpy oracle, median of 3: {n_sat} sats x 20 Doppler bins x 1 ms, scaled to 32 sats; host has {os.cpu_count()} cores"}
-
-
 def cpu_sample_grid(sample: dict) -> dict:
     """The flat-grid legs' CPU figure and parity flag: the oracle timed on unit 0 of the leg's OWN input (`sample` from run_grid /
     run_cfg5: the samples as the device holds them, the device's cell records of that unit) for the scene's visible satellites, and its
@@ -1375,8 +1357,9 @@ def main() -> None:
                 result["cpu_baseline_all_cores"] = cpu_baseline_cfg3_all_cores(8_184_000, 8184)
             except Exception as e:
                 result["cpu_baseline_all_cores"] = {"error": repr(e)}
-        elif args.workload in ("cfg2", "cfg4"):
-            result["cpu_baseline"] = cpu_baseline_cfg2(2_046_000, 2046)
+        elif result.get("_sample") is not None:
+            # the flat-grid workloads: the oracle timed on unit 0 of THIS run's input and compared with the device's cells of it
+            result["cpu_baseline"] = cpu_sample_grid(result["_sample"])
 
     result.pop("_su", None)
     if args.dump_table and rank == 0 and result.get("_table") is not None:
