@@ -97,6 +97,21 @@ import json,sys
 l=json.loads(sys.stdin.read()); print('$W', {k:l[k] for k in ('value','ms_per_step')}, l['roofline']['kernel_ms_per_launch'], l['roofline']['valu_frac'], l.get('visible_sats_found_stream0_ms0'))"
         done
       done ;;
+    r06surveys)
+      # fresh seeds through what r06 touched or newly covers: multi-stream banks on their natural paths, the 2.046 Msps speculative tracker's new
+      # threshold / sub-block defaults in both regimes, and the other rates for the tightened 1e-6 bands
+      export GYP_SURVEY_SEED=${R06_SEED_BASE:-0}
+      : > $O/surveys.txt
+      run() { echo "== $*" >> $O/surveys.txt; timeout 900 "$@" 2>&1 | grep -v "^$" | cut -c1-1600 | grep "^\[\|^    \|^{" | tail -12 >> $O/surveys.txt; tail -2 $O/surveys.txt | cut -c1-700; }
+      run python tools/bank_survey.py 6 8184000 40 12 1809 6100000
+      run python tools/bank_survey.py 6 2046000 26 10 1209 6200000
+      run python tools/bank_survey.py 6 8184000 14 10 2009 6300000
+      run python tools/big_survey.py 500 - 2046000 6400000
+      run python tools/big_survey.py 400 - 2046000 6500000 lock 8
+      run python tools/big_survey.py 300 - 8184000 6600000 lock 6
+      run python tools/big_survey.py 300 GYP_NO_SPEC 8184000 6700000 lock 6
+      run python tools/big_survey.py 120 - 16368000 6800000 lock 3
+      run python tools/big_survey.py 300 - 8184000 6900000 ;;
     locktests)
       timeout 900 python -m pytest tests/test_gpu_track_survey.py -x -q -m gpu -s -k "locked_regime" > $O/pytest_lock.log 2>&1
       echo "pytest rc=$?" >> $O/pytest_lock.log; grep -v "^$" $O/pytest_lock.log | cut -c1-600 | tail -40 ;;
