@@ -851,29 +851,30 @@ int gyp_correlate_grid_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams,
         }                                                                                                                     \
         /* satellites per wavefront: more of them share a forward transform (1 + gs transforms per gs cells) but make fewer,   \
            longer work items -- on a chip the grid does not fill (config 5 on one GPU, anything strong-scaled) the rounds decide */ \
-        int gs_best = 1; double cost_best = 0;                                                                                \
-        for (int gs = 1; gs <= 8; gs *= 2) {                                                                                  \
-            const double items = (double)n_units * ((n_sats + gs - 1) / gs), slots = ctx->n_cus * 8.0;                         \
-            const double cost = (gs == 1 ? 2.0 : 1.0 + gs) * std::ceil(items / slots);                                         \
-            if (gs == 1 || cost < cost_best) { gs_best = gs; cost_best = cost; }                                               \
-        }                                                                                                                     \
+        /* r06: group size and branch runs are chosen TOGETHER -- cost = (1 + gs) transforms x (K / parts) branches per item x rounds of   \
+           the chip's 2048 wavefront slots -- with up to 32 satellites per wavefront and runs down to one branch (r05: gs <= 8, at most   \
+           16 runs, chosen one after the other: config 5 ran 19 rounds x 4 branches x 9 = 684 transform times, now 19 x 1 x 33 = 627) */  \
+        int gs_best = 1, parts_best = 1; double cost_best = 0;                                                                        \
+        {                                                                                                                             \
+            const double slots = ctx->n_cus * 8.0;                                                                                    \
+            cost_best = 2.0 * K * std::ceil((double)n_units * n_sats / slots);   /* one wavefront per cell: fwd + inv per branch */     \
+            for (int gs = 2; gs <= 32; gs *= 2) {                                                                                     \
+                if (gs / 2 >= n_sats) break;                                                                                          \
+                const double groups = (double)n_units * ((n_sats + gs - 1) / gs);                                                     \
+                for (int pp = 1; pp <= K; ++pp) {                                                                                     \
+                    if (K % pp || (pp > 1 && ctx->no_grid_parts)) continue;                                                            \
+                    const double t = (1.0 + gs) * (K / pp) * std::ceil(groups * pp / slots) + (pp > 1 ? 0.25 * (1.0 + gs) : 0.0); /* (+: a merge launch) */ \
+                    if (t < cost_best * (pp > 1 ? 0.97 : 1.0)) { cost_best = t; gs_best = gs; parts_best = pp; }                        \
+                }                                                                                                                     \
+            }                                                                                                                         \
+        }                                                                                                                             \
         if (n_blk == 1 && gs_best > 1 && !ctx->no_pipe && !ctx->no_shared_fwd) { /* one wavefront per (unit, gs satellites) */ \
-            const size_t lds = 2 * kTablesBytes + 8 * kXchWaveBytes + 8 * 8 * sizeof(SatStat);                                 \
+            const size_t lds = 2 * kTablesBytes + 8 * kXchWaveBytes + 8 * 32 * sizeof(SatStat);                                \
             int n_groups = n_units * ((n_sats + gs_best - 1) / gs_best);                                                       \
-            /* a chip the items do not fill runs a last round that is partly empty (config 5 on one GPU: 3200 items of 48 branches on  \
-               2048 wavefront slots, the second round 44 % empty): cut the K branches of a unit into `parts` runs -- the forward      \
-               transforms stay shared -- so that the rounds are shorter and the last one costs less; partial statistics are merged   \
-               by grid_merge_parts_kernel.  Rounds x branches per item, smallest wins, ties to fewer parts */                        \
-            int parts = 1;                                                                                                    \
-            if (!ctx->no_grid_parts) {                                                                                        \
-                const double slots = ctx->n_cus * 8.0;                                                                         \
-                double best = std::ceil(n_groups / slots) * K;                                                                  \
-                for (int pp = 2; pp <= K && pp <= 16; ++pp) {                                                                  \
-                    if (K % pp) continue;                                                                                      \
-                    const double t = std::ceil((double)n_groups * pp / slots) * (K / pp) + 0.25; /* (+: a merge launch) */       \
-                    if (t < best * 0.97) { best = t; parts = pp; }                                                             \
-                }                                                                                                             \
-            }                                                                                                                 \
+            /* a chip the items do not fill runs a last round that is partly empty (config 5 on one GPU): a unit's K branches are cut     \
+               into `parts` runs -- the forward transforms stay shared -- so that the rounds are shorter and the last one costs less;     \
+               partial statistics are merged by grid_merge_parts_kernel */                                                             \
+            const int parts = parts_best;                                                                                             \
             p.parts = parts;                                                                                                  \
             if (parts > 1) {                                                                                                  \
                 int rcp;                                                                                                      \
@@ -882,9 +883,9 @@ int gyp_correlate_grid_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams,
                 n_groups *= parts;                                                                                            \
             }                                                                                                                 \
             const int wgrid = std::max(1, std::min((n_groups + 7) / 8, ctx->n_cus));                                           \
-            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(grid_cells_wave_shared_kernel<K, 8>),              \
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(grid_cells_wave_shared_kernel<K, 32>),              \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
-            hipLaunchKernelGGL((grid_cells_wave_shared_kernel<K, 8>), dim3(wgrid), dim3(512), lds, ctx->stream, p, gs_best);  \
+            hipLaunchKernelGGL((grid_cells_wave_shared_kernel<K, 32>), dim3(wgrid), dim3(512), lds, ctx->stream, p, gs_best);  \
             HIP_TRY(ctx, hipGetLastError());                                                                                  \
             if (parts > 1) {                                                                                                  \
                 hipLaunchKernelGGL(grid_merge_parts_kernel, dim3((n_cells + 255) / 256), dim3(256), 0, ctx->stream, p, n_cells); \
