@@ -708,6 +708,7 @@ __global__ void grid_best_bin_decide_kernel(GridRefineParams p) {
             }
             if (v > best_v) { best_v = v; best_bin = p.cand[c] - row * p.n_bins; }
         }
+        if (best_bin < 0) continue;    // (every candidate's value NaN -- samples that are not numbers: the float32 selection of the first kernel stands)
         const gyp_cell w = p.cells[(int64_t)row * p.n_bins + best_bin];
         gyp_best_bin o;
         o.bin = best_bin; o.argmax = w.argmax; o.peak = w.peak; o.reserved = 1;
