@@ -303,11 +303,26 @@ __device__ __forceinline__ double2 cmul64(double2 a, double2 b) {
 struct CarrierSteps {
     cf rot1;      // exp(-2*pi*i*du): one sample
     cf rot_wrap;  // exp(+2*pi*i*du*N): samples that wrapped to the start of the block
+    float amp;    // what a chip's anchor carrier is scaled by (carrier_amp below): 1 +- 2.5e-7
 };
+// The float32 one-sample rotation has a modulus of 1 - eps, |eps| <= 3e-8 -- fixed for a given Doppler -- so the carrier recurrence
+// over a chip's K samples decays (or grows) like (1 - eps)^i and the wiped chip carries a gain of 1 - eps (K - 1) / 2 on average: up to
+// 2.5e-7 at 16 samples per chip, the same in every chip and every millisecond for as long as the Doppler sits in the same float32
+// cell.  A systematic gain on the prompt peak is a systematic change of the Costas loop's gain, and an UNLOCKED loop amplifies it: r06
+// traced a lock verdict that left the reference's with an oracle margin of 3e-5 (100 x the float32 floor of locked loops) to exactly
+// this -- the Doppler estimate of a 16.368 Msps channel drifting from the oracle's by 1e-6 Hz over its first second
+// (profiles/r06_experiments.txt item 6).  The anchors are therefore scaled by 1 + eps (K - 1) / 2, eps evaluated in float64 from the
+// float32 components actually used: the mean gain error falls from <= 2.5e-7 to ~2e-8 for two multiplications per chip.
+template <int K>
+__device__ __forceinline__ float carrier_amp(cf rot1) {
+    const double e = 1.0 - ((double)rot1.x * (double)rot1.x + (double)rot1.y * (double)rot1.y);   // 1 - |rot1|^2 = 2 eps to first order
+    return (float)(1.0 + 0.25 * (double)(K - 1) * e);
+}
 template <int K>
 __device__ __forceinline__ CarrierSteps carrier_steps(double du) {
     CarrierSteps cs;
     cs.rot1 = carrier_from_cycles_fast(du);
+    cs.amp = carrier_amp<K>(cs.rot1);
     const cf w = carrier_from_cycles_fast(du * (double)(K * kChips));
     cs.rot_wrap = make_float2(w.x, -w.y);
     return cs;
@@ -357,6 +372,7 @@ __device__ __forceinline__ void stage_ms(const cf* __restrict__ block, double u0
             const int m = tid + (c0 + u) * T;
             if (m < kChips) {
                 cf car = carrier_from_cycles_fast(u0 + du * (double)(K * m));
+                car.x *= cs.amp; car.y *= cs.amp;
 #pragma unroll
                 for (int i = 0; i < K; ++i) {
                     w[u][i] = cmul(w[u][i], car);
@@ -485,8 +501,10 @@ __device__ __forceinline__ void stage_emit_own(OwnSamples<K, T>& s, double u0, d
                                                cf* (&y_rows)[K], cf* __restrict__ halo, int tid, Wiped&& wiped) {
     cf anchor[OwnSamples<K, T>::CH];
 #pragma unroll
-    for (int c = 0; c < OwnSamples<K, T>::CH; ++c)
+    for (int c = 0; c < OwnSamples<K, T>::CH; ++c) {
         anchor[c] = carrier_from_cycles_fast(u0 + du * (double)(K * (tid + c * T)));
+        anchor[c].x *= cs.amp; anchor[c].y *= cs.amp;       // (carrier_amp: the recurrence's mean gain over the chip's K samples -> 1)
+    }
     stage_emit_own_anchored<K, T>(s, anchor, cs, y_rows, halo, tid, wiped);
 }
 template <int K, int T>
@@ -535,6 +553,7 @@ __device__ __forceinline__ void stage_general(const cf* __restrict__ stream, int
             for (int b = 0; b < n_blocks; ++b) {
                 const cf* block = stream + (int64_t)b * N;
                 cf car = carrier_from_cycles_fast(u0_first + u0_step * (double)b + du * (double)idx0);
+                car.x *= cs.amp; car.y *= cs.amp;
                 cf first[W > 1 ? W - 1 : 1];
                 cf win = make_float2(0.f, 0.f);
                 int idx = idx0;

@@ -156,7 +156,7 @@ struct RedScratch {
     int32_t defer, pad3;   // 1: the last millisecond's error has not joined se / see and its ring entries are not stored yet
     double t0_next;        // start time of the next millisecond's chunk, fetched by an idle wavefront during the loop updates
     LoopConst kc;
-    struct CostasCand { double nf, nphi; cf rot1; cf step; double pad; } cc[3];   // step: the carrier over 4096 samples (second chip of a thread)
+    struct CostasCand { double nf, nphi; cf rot1; cf step; double pad; } cc[3];   // step: the carrier over 4096 samples (second chip of a thread); pad: CarrierSteps::amp (carrier_amp)
     int cand_sel, rec_sel, pad2[2];
     // speculative tracker under the round protocol (SpecCtl, kernels_track_block.hpp): what this channel does in this launch
     int32_t ctl_sub, ctl_restore, ctl_nforce, ctl_pad;

@@ -336,6 +336,7 @@ __device__ __forceinline__ CarrierSteps tracking_steps(double du) {
         CarrierSteps cs;
         cs.rot1 = make_float2((float)rot.x, (float)rot.y);
         cs.rot_wrap = make_float2(1.f, 0.f);
+        cs.amp = carrier_amp<K>(cs.rot1);
         return cs;
     } else {
         return carrier_steps<K>(du);
@@ -485,6 +486,7 @@ __device__ __forceinline__ void costas_candidate(double inv_fs, RedScratch* red,
         const cf rot1 = make_float2((float)rot.x, (float)rot.y);
         red->cc[slot].rot1 = rot1;
         red->cc[slot].step = step;
+        red->cc[slot].pad = (double)carrier_amp<K>(rot1);     // CarrierSteps::amp of this candidate
     }
 }
 // Everything else of costas_update -- histories, lock verdict, watchdog, the record's fields -- arranged so that ONLY the
@@ -621,6 +623,7 @@ __device__ __forceinline__ void spec_lock_verdict(const LoopParams& lp, double i
                         const cf rot1 = make_float2((float)rot.x, (float)rot.y);
                         red->cc[2].rot1 = rot1;
                         red->cc[2].step = step;
+                        red->cc[2].pad = (double)carrier_amp<K>(rot1);
                     }
                 }
             }
@@ -977,6 +980,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
                                                                         // the same records however it is cut into launches
         sm.red->cc[0].nf = st->doppler; sm.red->cc[0].nphi = st->carrier_phase;
         sm.red->cc[0].rot1 = sm.red->steps.rot1;
+        sm.red->cc[0].pad = (double)carrier_amp<K>(sm.red->steps.rot1);
         sm.red->cc[0].step = carrier_from_cycles_fast(st->doppler * p.inv_fs * (double)(K * kSpecThreads));
         sm.red->cand_sel = 0; sm.red->rec_sel = 0;
         sm.red->defer = 0;
@@ -1067,7 +1071,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
         cf half_step = make_float2(1.f, 0.f);
         if constexpr (SPEC) {
             const auto cand = sm.red->cc[sm.red->cand_sel];
-            f = cand.nf; phi = cand.nphi; cs.rot1 = cand.rot1; cs.rot_wrap = make_float2(1.f, 0.f);
+            f = cand.nf; phi = cand.nphi; cs.rot1 = cand.rot1; cs.rot_wrap = make_float2(1.f, 0.f); cs.amp = (float)cand.pad;
             half_step = cand.step;
         } else {
             f = sm.red->dstate[0]; phi = sm.red->dstate[1]; cs = sm.red->steps;
@@ -1094,6 +1098,7 @@ __global__ __launch_bounds__(MODE ? kSpecThreads : Geom<K>::kThreads, MODE ? 2 :
                 static_assert(OwnSamples<K, kSpecThreads>::CH == 2, "second chip = first + K * 512 samples");
                 cf anchor[2];
                 anchor[0] = carrier_from_cycles_fast(u0 + du * (double)(K * tid));
+                anchor[0].x *= cs.amp; anchor[0].y *= cs.amp;   // (carrier_amp, corr_core.hpp: the recurrence's mean gain over a chip -> 1)
                 anchor[1] = cmul(anchor[0], half_step);
                 float e_in;
                 if constexpr (SPLIT) {

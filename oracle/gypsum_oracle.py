@@ -403,6 +403,12 @@ class Tracker:
         self.accumulator = 0                                             # tracker.py:223
         self._last_circularity_check = 0.0                               # tracker.py:222
         self.record_margins = False       # test infrastructure: fill TrackStepRecord.lock_margin (costs a second pass over the window)
+        # test infrastructure: relative size of a per-millisecond perturbation of the prompt peak before it feeds the loops and the lock
+        # detector (0: none, the reference's arithmetic).  3e-7 models a correlator whose peaks carry float32 rounding: the peak is
+        # rounded to complex64 and its components moved by up to `peak_noise` x |peak| (a fixed pseudo-random sequence).  A "twin" run
+        # this way says whether the REFERENCE's own integers at some millisecond survive float32-sized perturbations of every peak.
+        self.peak_noise = 0.0
+        self._noise_rng = None
 
     def process_samples(self, samples: np.ndarray, start_time: float, end_time: float) -> TrackStepRecord:
         s = self.s
@@ -433,6 +439,11 @@ class Tracker:
             amargin = float((top2[1] - top2[0]) / top2[1]) if top2[1] > 0 else 0.0
         strength = float(peak_strength(mag))
         peak = complex(c[k])
+        if self.peak_noise:
+            if self._noise_rng is None:
+                self._noise_rng = np.random.default_rng(0x70EA)
+            d = self._noise_rng.uniform(-1.0, 1.0, 2) * self.peak_noise * abs(peak)
+            peak = complex(np.complex64(peak)) + complex(d[0], d[1])
         symbol = int(np.sign(peak.real))
         if symbol == 0:
             raise KeyError(0)                                            # tracker.py:93-96 from_val

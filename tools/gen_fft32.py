@@ -42,8 +42,43 @@ class Emitter:
         return t
 
 
-def gen(sign: int, in_slot, out_slot):
-    """Returns (Emitter, outputs) for X[k] = sum_n x[n] exp(sign * 2 pi i n k / 32)."""
+def _f32(v: float) -> float:
+    import numpy as np
+    return float(np.float32(v))
+
+
+def _ulp_up(v: float) -> float:
+    import numpy as np
+    return float(np.nextafter(np.float32(v), np.float32(np.inf), dtype=np.float32))
+
+
+# The float32 twiddles the codelets are emitted with (r06).  Rounding cos and sin of 2 pi k / 32 to the nearest float32 each gives
+# |w| < 1 for EVERY one of the seven constants (-2.9e-8, -2.9e-8, -7.5e-9, -1.7e-8, ...): a codelet then has a mean gain of 1 - 2.3e-8
+# over its bins, a 1024-point transform 1 - 4.7e-8 and a forward + inverse pair 1 - 1e-7 -- measured on the device as a systematic
+# -1.0 .. -1.6e-7 on every correlation peak (tools/gain_bias_probe.py).  A systematic gain on the prompt peak is a systematic change of
+# the Costas loop's gain, which an unlocked loop amplifies (profiles/r06_experiments.txt item 6).  Moving two of the
+# seven constants by one unit in the last place -- sin(2 pi 2 / 32) and sin(2 pi 4 / 32), and with them cos(2 pi 6 / 32) -- brings the
+# codelet's mean gain error to 1e-11 (largest single bin 1.3e-8), at twiddle-angle errors (<= 4.2e-8 rad) of the size rounding to nearest
+# leaves anyway (an exhaustive search over the +-1-ulp neighbours of the four independent pairs; `--check` re-derives the figure).
+def quantised_twiddle(idx: int):
+    """(cos, sin) of 2 pi idx / 32 as the float32 pair the codelets use, 0 < idx < 16, idx != 8."""
+    def first_octant(k):          # k = 1..7
+        c, s = _f32(math.cos(2.0 * math.pi * k / 32)), _f32(math.sin(2.0 * math.pi * k / 32))
+        if k > 4:
+            s2, c2 = first_octant(8 - k)
+            return c2, s2
+        if k in (2, 4):
+            s = _ulp_up(s)
+        return c, s
+    if idx < 8:
+        return first_octant(idx)
+    c, s = first_octant(idx - 8)  # + pi / 2:  cos -> -sin, sin -> cos
+    return -s, c
+
+
+def gen(sign: int, in_slot, out_slot, exact: bool = True):
+    """Returns (Emitter, outputs) for X[k] = sum_n x[n] exp(sign * 2 pi i n k / 32).  exact: float64 twiddles (for --check against
+    numpy.fft); otherwise the float32 pairs of quantised_twiddle, as emitted."""
     e = Emitter()
     v = [(f"x[{in_slot[bitrev5(i)]}].x", f"x[{in_slot[bitrev5(i)]}].y") for i in range(32)]   # v[i] = time sample bitrev5(i)
     for s in range(5):
@@ -65,6 +100,9 @@ def gen(sign: int, in_slot, out_slot):
                 else:
                     ang = sign * 2.0 * math.pi * num / den
                     c, sn = math.cos(ang), math.sin(ang)
+                    if not exact:
+                        c, sn = quantised_twiddle(num * (32 // den))
+                        sn *= sign
                     # out1 = a + (c + i sn)(br + i bi) = (ar + br c - bi sn) + i (ai + bi c + br sn)
                     r1 = e.op("fma", bi, -sn, ar)
                     r1 = e.op("fma", br, c, r1)
@@ -178,10 +216,10 @@ VARIANTS = [
 ]
 
 
-def build():
+def build(exact: bool = False):
     out = []
     for name, sign, ins, outs_, comment in VARIANTS:
-        e, outs = gen(sign, [ins(n) for n in range(32)], [outs_(k) for k in range(32)])
+        e, outs = gen(sign, [ins(n) for n in range(32)], [outs_(k) for k in range(32)], exact=exact)
         out.append((name, sign, ins, outs_, comment, e, outs))
     return out
 
@@ -189,7 +227,23 @@ def build():
 def check():
     import numpy as np
     rng = np.random.default_rng(1)
-    for name, sign, ins, outs_, comment, e, outs in build():
+    # the emitted (float32-twiddle) codelets: still the transform to float32 rounding, and their MEAN gain over matched tones is 1 to 1e-9
+    for name, sign, ins, outs_, comment, e, outs in build(exact=False):
+        gains = []
+        worst = 0.0
+        for k in range(32):
+            t = np.exp(-sign * 2j * np.pi * k * np.arange(32) / 32)           # the tone bin k answers to
+            x = np.zeros(32, dtype=complex)
+            for n in range(32):
+                x[ins(n)] = t[n]
+            got = evaluate(e, outs, x)
+            gains.append(abs(got[outs_(k)]) / 32.0 - 1.0)
+            ref = np.zeros(32, dtype=complex)
+            ref[outs_(k)] = 32.0
+            worst = max(worst, float(np.abs(got - ref).max()))
+        assert worst < 3e-6 and abs(float(np.mean(gains))) < 1e-9 and max(abs(g) for g in gains) < 2e-8, (name, worst, np.mean(gains))
+        print(f"{name} as emitted (float32 twiddles): mean gain error over matched tones {np.mean(gains):+.1e}, largest bin {max(gains, key=abs):+.1e}, leakage {worst:.1e}")
+    for name, sign, ins, outs_, comment, e, outs in build(exact=True):
         t = rng.standard_normal(32) + 1j * rng.standard_normal(32)          # t[n]: time samples
         x = np.zeros(32, dtype=complex)
         for n in range(32):
