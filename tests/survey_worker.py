@@ -86,29 +86,39 @@ def run_scene(args):
 
 
 def fragile_from(iq_from_ms9, fs, init, rows) -> float:
-    """The first row at which a SECOND float64 oracle tracker of the channel `init` = (sat_id, doppler, carrier_phase, code_phase), started
-    with its carrier phase 3e-7 rad off -- the size of the device's float32 peak rounding -- produces a different integer (pseudosymbol,
-    code phase, peak offset, lock flag) than the first one did (`rows`, run_scene's trajectory): from there on the reference's own
-    trajectory is not determined to better than float32 rounding (an unlocked Costas loop amplifies perturbations).  inf: never within
-    the rows.  An ORACLE-ONLY witness for the surveys' "unlocked loop separated" excuse."""
+    """The first row at which one of FOUR float64 oracle twins of the channel `init` = (sat_id, doppler, carrier_phase, code_phase) produces
+    a different integer (pseudosymbol, code phase, peak offset, lock flag) than the oracle itself did (`rows`, run_scene's trajectory):
+    one twin started with its carrier phase 3e-7 rad off, three whose every prompt peak carries a float32-sized perturbation before it
+    feeds the loops (oracle.Tracker.peak_noise = 3e-7, three pseudo-random sequences) -- what a correlator with float32 peaks IS.  From
+    that row on the reference's own integers are not determined to better than float32 rounding (an unlocked Costas loop amplifies
+    perturbations; a pseudosymbol is the sign of a real part that can pass through zero).  inf: no twin differs within the rows.  An
+    ORACLE-ONLY witness for the surveys' "unlocked loop separated" excuse."""
     from oracle import gypsum_oracle as orc
 
     n = fs // 1000
     sv, dop, phi, cp = init
     chips = orc.generate_ca_codes()
-    twin = orc.Tracker(orc.TrackingState(dop, float(np.angle(np.exp(1j * (phi + 3e-7)))), cp), orc.prn_as_complex(chips[sv - 1], n), fs, n)
+    prn = orc.prn_as_complex(chips[sv - 1], n)
     flat = np.asarray(iq_from_ms9).reshape(-1)
-    for j in range(len(rows)):
-        if rows[j, 5] != 0:
-            break
-        st, en = orc.chunk_times((9 + j) * n, n, fs)
-        try:
-            q = twin.process_samples(flat[j * n:(j + 1) * n], st, en)
-        except orc.LostSatelliteLock:
-            return float(j)
-        if (q.pseudosymbol, q.code_phase_after, q.peak_offset, float(q.locked)) != tuple(rows[j, :4]):
-            return float(j)
-    return math.inf
+    first = math.inf
+    for kind, arg in (("phase", 3e-7), ("noise", 1), ("noise", 2), ("noise", 3)):
+        twin = orc.Tracker(orc.TrackingState(dop, float(np.angle(np.exp(1j * (phi + (arg if kind == "phase" else 0.0))))), cp), prn, fs, n)
+        if kind == "noise":
+            twin.peak_noise = 3e-7
+            twin._noise_rng = np.random.default_rng(arg)
+        for j in range(len(rows)):
+            if rows[j, 5] != 0 or j >= first:
+                break
+            st, en = orc.chunk_times((9 + j) * n, n, fs)
+            try:
+                q = twin.process_samples(flat[j * n:(j + 1) * n], st, en)
+            except (orc.LostSatelliteLock, KeyError):
+                first = float(j)
+                break
+            if (q.pseudosymbol, q.code_phase_after, q.peak_offset, float(q.locked)) != tuple(rows[j, :4]):
+                first = float(j)
+                break
+    return first
 
 
 def run_acq_scene(args):

@@ -79,7 +79,8 @@ def _sync_horizon(g, r, where, tally, twin=None):
       integer differs).  Accepted only after >= 1000 ms, with the oracle unlocked throughout the preceding 250 ms, the two Doppler
       estimates already measurably apart (> 1e-5 Hz) on the millisecond before AND -- r06, an oracle-only criterion (the
       Doppler difference is itself a GPU-vs-oracle quantity, a device bug that drifts an unlocked loop would satisfy it) -- the float64
-      oracle's own twin of the channel, started 3e-7 rad off in carrier phase, having lost integer agreement with it by then
+      oracle's own twins of the channel (one started 3e-7 rad off in carrier phase, three with float32-sized perturbations of every prompt
+      peak) having lost integer agreement with it by then
       (`survey_worker.fragile_from`, computed on demand through `twin` -- or taken from column 11 of the rows if a caller filled it --
       within FRAGILE_SLACK_MS).
     A pseudosymbol whose peak has |Re| < 2e-4 |peak| in a channel that is not locked is the float32 floor documented in r03 (counted,
@@ -110,8 +111,8 @@ def _sync_horizon(g, r, where, tally, twin=None):
         tally["unexplained"] += 1
         tally["events"].append("UNEXPLAINED: " + what)
     if r.shape[1] > 11 and not np.isnan(r[0, 11]):
-        tally["events"][-1] += (f"; the oracle's own 3e-7-rad twin differs from ms {9 + int(r[0, 11])}" if np.isfinite(r[0, 11]) else
-                                "; the oracle's own 3e-7-rad twin never differs")
+        tally["events"][-1] += (f"; the oracle's own float32-perturbed twins differ from ms {9 + int(r[0, 11])}" if np.isfinite(r[0, 11]) else
+                                "; none of the oracle's own float32-perturbed twins ever differs")
     return j
 
 
