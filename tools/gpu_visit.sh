@@ -103,29 +103,29 @@ l=json.loads(sys.stdin.read()); print('$W', {k:l[k] for k in ('value','ms_per_st
       export GYP_SURVEY_SEED=${R06_SEED_BASE:-0}
       : > $O/surveys.txt
       run() { echo "== $*" >> $O/surveys.txt; timeout 900 "$@" 2>&1 | grep -v "^$" | cut -c1-1600 | grep "^\[\|^    \|^{" | tail -12 >> $O/surveys.txt; tail -2 $O/surveys.txt | cut -c1-700; }
-      run python tools/bank_survey.py 6 8184000 40 12 1809 6100000
-      run python tools/bank_survey.py 6 2046000 26 10 1209 6200000
-      run python tools/bank_survey.py 6 8184000 14 10 2009 6300000
-      run python tools/big_survey.py 500 - 2046000 6400000
-      run python tools/big_survey.py 400 - 2046000 6500000 lock 8
-      run python tools/big_survey.py 300 - 8184000 6600000 lock 6
-      run python tools/big_survey.py 300 GYP_NO_SPEC 8184000 6700000 lock 6
-      run python tools/big_survey.py 120 - 16368000 6800000 lock 3
-      run python tools/big_survey.py 300 - 8184000 6900000 ;;
+      run python tools/bank_survey.py 6 8184000 40 12 1809 $(( 6100000 + ${R06_SEED_SHIFT:-0} ))
+      run python tools/bank_survey.py 6 2046000 26 10 1209 $(( 6200000 + ${R06_SEED_SHIFT:-0} ))
+      run python tools/bank_survey.py 6 8184000 14 10 2009 $(( 6300000 + ${R06_SEED_SHIFT:-0} ))
+      run python tools/big_survey.py 500 - 2046000 $(( 6400000 + ${R06_SEED_SHIFT:-0} ))
+      run python tools/big_survey.py 400 - 2046000 $(( 6500000 + ${R06_SEED_SHIFT:-0} )) lock 8
+      run python tools/big_survey.py 300 - 8184000 $(( 6600000 + ${R06_SEED_SHIFT:-0} )) lock 6
+      run python tools/big_survey.py 300 GYP_NO_SPEC 8184000 $(( 6700000 + ${R06_SEED_SHIFT:-0} )) lock 6
+      run python tools/big_survey.py 120 - 16368000 $(( 6800000 + ${R06_SEED_SHIFT:-0} )) lock 3
+      run python tools/big_survey.py 300 - 8184000 $(( 6900000 + ${R06_SEED_SHIFT:-0} )) ;;
     r06surveys2)
       # second set: the throughput kernel on single-stream banks (pull-in), the other supported rates, more multi-stream banks
       export GYP_SURVEY_SEED=${R06_SEED_BASE:-0}
       : > $O/surveys2.txt
       run() { echo "== $*" >> $O/surveys2.txt; timeout 900 "$@" 2>&1 | grep -v "^$" | cut -c1-1600 | grep "^\[\|^    \|^{" | tail -12 >> $O/surveys2.txt; tail -2 $O/surveys2.txt | cut -c1-700; }
-      run python tools/big_survey.py 300 GYP_NO_SPEC 8184000 7100000
-      run python tools/big_survey.py 400 GYP_NO_SPEC 2046000 7200000
-      run python tools/big_survey.py 300 GYP_NO_SPEC 2046000 7300000 lock 6
-      run python tools/big_survey.py 150 - 4092000 7400000
-      run python tools/big_survey.py 100 - 10230000 7500000
-      run python tools/big_survey.py 100 - 12276000 7600000
-      run python tools/bank_survey.py 4 8184000 41 12 1809 7700000
-      run python tools/bank_survey.py 8 2046000 26 10 2209 7800000
-      run python tools/big_survey.py 120 GYP_NO_SPEC 16368000 7900000 lock 3 ;;
+      run python tools/big_survey.py 300 GYP_NO_SPEC 8184000 $(( 7100000 + ${R06_SEED_SHIFT:-0} ))
+      run python tools/big_survey.py 400 GYP_NO_SPEC 2046000 $(( 7200000 + ${R06_SEED_SHIFT:-0} ))
+      run python tools/big_survey.py 300 GYP_NO_SPEC 2046000 $(( 7300000 + ${R06_SEED_SHIFT:-0} )) lock 6
+      run python tools/big_survey.py 150 - 4092000 $(( 7400000 + ${R06_SEED_SHIFT:-0} ))
+      run python tools/big_survey.py 100 - 10230000 $(( 7500000 + ${R06_SEED_SHIFT:-0} ))
+      run python tools/big_survey.py 100 - 12276000 $(( 7600000 + ${R06_SEED_SHIFT:-0} ))
+      run python tools/bank_survey.py 4 8184000 41 12 1809 $(( 7700000 + ${R06_SEED_SHIFT:-0} ))
+      run python tools/bank_survey.py 8 2046000 26 10 2209 $(( 7800000 + ${R06_SEED_SHIFT:-0} ))
+      run python tools/big_survey.py 120 GYP_NO_SPEC 16368000 $(( 7900000 + ${R06_SEED_SHIFT:-0} )) lock 3 ;;
     locktests)
       timeout 900 python -m pytest tests/test_gpu_track_survey.py -x -q -m gpu -s -k "locked_regime" > $O/pytest_lock.log 2>&1
       echo "pytest rc=$?" >> $O/pytest_lock.log; grep -v "^$" $O/pytest_lock.log | cut -c1-600 | tail -40 ;;
