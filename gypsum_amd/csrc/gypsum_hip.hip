@@ -728,6 +728,7 @@ static int correlate_cells_listed(gyp_ctx* ctx, const float* iq_dev, int64_t str
     p.tw_tables = ctx->d_tw;
     p.inv_fs = 1.0 / (double)ctx->fs;
     p.prof = ctx->d_prof;
+    p.prof_wave = std::min(ctx->prof_wave, 7);
     p.order = order_dev;
     p.n_active = n_active_dev;
     return launch_cells(ctx, p, integration);

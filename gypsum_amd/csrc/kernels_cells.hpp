@@ -19,7 +19,8 @@ struct CellsParams {
     const cf* replica_table;
     const cf* tw_tables;
     double inv_fs;
-    long long* prof;   // optional: per-phase cycle counters of workgroup 0 of the pipelined kernel (debug)
+    long long* prof;   // optional: per-phase cycle counters of workgroup 0 of the pipelined kernel (debug) ...
+    int32_t prof_wave; // ... as seen by lane 0 of this wavefront (gyp_debug_set "prof_wave")
     // optional work list (the acquisition driver): order[0 .. *n_active) = the cells to evaluate, ascending.  Padding and
     // cached cells fall at regular positions of the [state][28] layout; walked with a fixed stride they land on the same
     // workgroups every time (half of them idle through levels 2 and 3), the compacted list spreads what is left evenly.
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(Geom<K>::kThreads, 2) void corr_cells_pipe_kernel(C
     for (int i = threadIdx.x; i < 2048; i += Geom<K>::kThreads) sm.tw1024[i] = p.tw_tables[i];
     __syncthreads();
     const LdsTables tables{sm.tw1024, sm.tw2048};
-    const bool prof = PROF && p.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+    const bool prof = PROF && p.prof != nullptr && blockIdx.x == 0 && (int)threadIdx.x == 64 * p.prof_wave;
     long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define GYP_TICK(var) const long long var = PROF ? (long long)__builtin_readcyclecounter() : 0
     const int n_work = cells_work(p);

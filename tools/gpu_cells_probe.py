@@ -34,6 +34,9 @@ def main():
                 k += 1
     d_cells = eng.alloc(cells.nbytes).upload(cells)
     d_out = eng.alloc(len(cells) * CELL.itemsize)
+    for a in sys.argv:
+        if a.startswith("--wave="):
+            eng.debug_set("prof_wave", int(a[7:]))     # whose stamps: wavefront 0 is the oldest of its SIMD's two, wavefront 4 the other
     if "--noprof" not in sys.argv:
         eng._check(eng.lib.gyp_debug_track_profile(eng.ctx, 1, None))
     for _ in range(3):
