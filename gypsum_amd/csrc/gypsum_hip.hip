@@ -126,6 +126,7 @@ struct gyp_ctx {
     int cells_cu_reserve = 0;     // gyp_debug_set("cells_cu_reserve", n): CUs the correlation-cell launches leave free (see launch_cells)
     int last_grid_refined_rows = 0;   // gyp_debug_get("last_grid_refined_rows"): rows the last gyp_grid_best_bins_refined_dev call decided in float64
     int last_grid_path = 0;       // gyp_debug_get("last_grid_path"): which cells kernel the last gyp_correlate_grid* call took (1 fused, 2 shared forward, 3 one wavefront per cell, 4 workgroup per cell)
+    int grid_fused_waves = 12;    // gyp_debug_set("grid_fused_waves"): 12 (default) or 8 wavefronts per workgroup of the fused flat-grid kernel (A/B)
     bool no_grid_fused = false;   // gyp_debug_set("no_grid_fused"): A/B switch: flat grids go through grid_fold_kernel + folded rows in HBM (r05) instead of the fused kernel
     bool no_grid_parts = false;   // gyp_debug_set("no_grid_parts"): A/B switch: flat-grid work items take whole units (no branch runs + merge)
     std::string err;
@@ -817,17 +818,20 @@ int gyp_correlate_grid_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams,
            fold is fused into the cells kernel, one wavefront per (stream, bin) unit loops every satellite (no folded rows in HBM) */      \
         if (K <= 8 && n_blk == 1 && n_sats >= 4 && n_sats <= 32 && n_units >= (int64_t)ctx->n_cus * 16 && !ctx->no_pipe &&                 \
             !ctx->no_shared_fwd && !ctx->no_grid_fused) {                                                                             \
-            const size_t lds = 2 * kTablesBytes + 8 * kXchWaveBytes + 8 * 32 * sizeof(SatStat);                                        \
-            const int wgrid = std::max(1, std::min((int)((n_units + 7) / 8), ctx->n_cus));                                             \
-            if (coh) {                                                                                                                \
-                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(grid_cells_wave_fused_kernel<(K <= 8 ? K : 8), true>),  \
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
-                hipLaunchKernelGGL((grid_cells_wave_fused_kernel<(K <= 8 ? K : 8), true>), dim3(wgrid), dim3(512), lds, ctx->stream, p); \
-            } else {                                                                                                                  \
-                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(grid_cells_wave_fused_kernel<(K <= 8 ? K : 8), false>), \
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
-                hipLaunchKernelGGL((grid_cells_wave_fused_kernel<(K <= 8 ? K : 8), false>), dim3(wgrid), dim3(512), lds, ctx->stream, p); \
-            }                                                                                                                         \
+            const int fw = ctx->grid_fused_waves == 8 ? 8 : 12;                                                                     \
+            const size_t lds = 2 * kTablesBytes + (size_t)fw * kXchWaveBytes + (size_t)fw * 32 * sizeof(SatStat);                       \
+            const int wgrid = std::max(1, std::min((int)((n_units + fw - 1) / fw), ctx->n_cus));                                       \
+            auto launch_fused = [&](auto kernel) -> int {                                                                             \
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                hipLaunchKernelGGL(kernel, dim3(wgrid), dim3(64 * fw), lds, ctx->stream, p);                                           \
+                return GYP_OK;                                                                                                        \
+            };                                                                                                                        \
+            int rcf;                                                                                                                  \
+            if (fw == 12) rcf = coh ? launch_fused(grid_cells_wave_fused_kernel<(K <= 8 ? K : 8), true, 12>)                            \
+                                    : launch_fused(grid_cells_wave_fused_kernel<(K <= 8 ? K : 8), false, 12>);                          \
+            else rcf = coh ? launch_fused(grid_cells_wave_fused_kernel<(K <= 8 ? K : 8), true, 8>)                                      \
+                           : launch_fused(grid_cells_wave_fused_kernel<(K <= 8 ? K : 8), false, 8>);                                    \
+            if (rcf) return rcf;                                                                                                      \
             HIP_TRY(ctx, hipGetLastError());                                                                                          \
             ctx->last_grid_path = 1;                                                                                                  \
             return GYP_OK;                                                                                                            \
@@ -857,7 +861,7 @@ int gyp_correlate_grid_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams,
            16 runs, chosen one after the other: config 5 ran 19 rounds x 4 branches x 9 = 684 transform times, now 19 x 1 x 33 = 627) */  \
         int gs_best = 1, parts_best = 1; double cost_best = 0;                                                                        \
         {                                                                                                                             \
-            const double slots = ctx->n_cus * 8.0;                                                                                    \
+            const double slots = ctx->n_cus * (ctx->grid_fused_waves == 8 ? 8.0 : 12.0);                                              \
             cost_best = 2.0 * K * std::ceil((double)n_units * n_sats / slots);   /* one wavefront per cell: fwd + inv per branch */     \
             for (int gs = 2; gs <= 32; gs *= 2) {                                                                                     \
                 if (gs / 2 >= n_sats) break;                                                                                          \
@@ -870,7 +874,8 @@ int gyp_correlate_grid_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams,
             }                                                                                                                         \
         }                                                                                                                             \
         if (n_blk == 1 && gs_best > 1 && !ctx->no_pipe && !ctx->no_shared_fwd) { /* one wavefront per (unit, gs satellites) */ \
-            const size_t lds = 2 * kTablesBytes + 8 * kXchWaveBytes + 8 * 32 * sizeof(SatStat);                                \
+            const int sw = ctx->grid_fused_waves == 8 ? 8 : 12;   /* wavefronts per workgroup ("grid_fused_waves") */               \
+            const size_t lds = 2 * kTablesBytes + (size_t)sw * kXchWaveBytes + (size_t)sw * 32 * sizeof(SatStat);                     \
             int n_groups = n_units * ((n_sats + gs_best - 1) / gs_best);                                                       \
             /* a chip the items do not fill runs a last round that is partly empty (config 5 on one GPU): a unit's K branches are cut     \
                into `parts` runs -- the forward transforms stay shared -- so that the rounds are shorter and the last one costs less;     \
@@ -883,10 +888,16 @@ int gyp_correlate_grid_dev(gyp_ctx* ctx, const float* iq_dev, int32_t n_streams,
                 p.partial = (GridPartial*)ctx->scratch[10];                                                                     \
                 n_groups *= parts;                                                                                            \
             }                                                                                                                 \
-            const int wgrid = std::max(1, std::min((n_groups + 7) / 8, ctx->n_cus));                                           \
-            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(grid_cells_wave_shared_kernel<K, 32>),              \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
-            hipLaunchKernelGGL((grid_cells_wave_shared_kernel<K, 32>), dim3(wgrid), dim3(512), lds, ctx->stream, p, gs_best);  \
+            const int wgrid = std::max(1, std::min((n_groups + sw - 1) / sw, ctx->n_cus));                                     \
+            if (sw == 12) {                                                                                                   \
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(grid_cells_wave_shared_kernel<K, 32, 12>),      \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
+                hipLaunchKernelGGL((grid_cells_wave_shared_kernel<K, 32, 12>), dim3(wgrid), dim3(768), lds, ctx->stream, p, gs_best); \
+            } else {                                                                                                          \
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(grid_cells_wave_shared_kernel<K, 32, 8>),       \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
+                hipLaunchKernelGGL((grid_cells_wave_shared_kernel<K, 32, 8>), dim3(wgrid), dim3(512), lds, ctx->stream, p, gs_best); \
+            }                                                                                                                 \
             HIP_TRY(ctx, hipGetLastError());                                                                                  \
             if (parts > 1) {                                                                                                  \
                 hipLaunchKernelGGL(grid_merge_parts_kernel, dim3((n_cells + 255) / 256), dim3(256), 0, ctx->stream, p, n_cells); \
@@ -1987,7 +1998,7 @@ const DebugKnob kDebugKnobs[] = {
     {"no_pipe", 0, 1, true}, {"no_shared_fwd", 0, 1, true}, {"no_acq_split", 0, 1, true}, {"no_spec", 0, 1, true},
     {"spec_debug", 0, 1, true}, {"acq_lanes", 1, gyp_ctx::kMaxAcqLanes, true}, {"track_chunk_ms", 0, 1e6, true},
     {"symbol_tau", 0, 100, false}, {"dll_prov_bias", -1e6, 1e6, false}, {"spec_fail_at", -1, 2147483647.0, true},
-    {"spec_redo", 0, 1, true}, {"spec_sub_ms", 0, 2000, true}, {"exact_prefetch", 0, 1, true}, {"prof_wave", 0, 7, true}, {"no_grid_parts", 0, 1, true}, {"no_grid_fused", 0, 1, true}, {"cells_cu_reserve", 0, 128, true},
+    {"spec_redo", 0, 1, true}, {"spec_sub_ms", 0, 2000, true}, {"exact_prefetch", 0, 1, true}, {"prof_wave", 0, 7, true}, {"no_grid_parts", 0, 1, true}, {"no_grid_fused", 0, 1, true}, {"grid_fused_waves", 8, 12, true}, {"cells_cu_reserve", 0, 128, true},
 };
 }  // namespace
 static int debug_apply(gyp_ctx* ctx, const char* name, double v, bool set, double* out) {
@@ -1998,6 +2009,7 @@ static int debug_apply(gyp_ctx* ctx, const char* name, double v, bool set, doubl
     GYP_KNOB_BOOL("no_shared_fwd", no_shared_fwd)
     GYP_KNOB_BOOL("no_grid_parts", no_grid_parts)
     GYP_KNOB_BOOL("no_grid_fused", no_grid_fused)
+    GYP_KNOB_NUM("grid_fused_waves", grid_fused_waves, int)
     if (is("last_grid_refined_rows")) { if (set) return GYP_E_BAD_ARG; *out = (double)ctx->last_grid_refined_rows; return GYP_OK; }
     if (is("last_grid_path")) { if (set) return GYP_E_BAD_ARG; *out = (double)ctx->last_grid_path; return GYP_OK; }
     GYP_KNOB_NUM("cells_cu_reserve", cells_cu_reserve, int)

@@ -323,27 +323,30 @@ __global__ __launch_bounds__(512, 2) void grid_cells_wave_pipe_kernel(GridParams
 // statistics: (1 + G) transforms per G cells instead of 2 G.  Running statistics per satellite live in a few bytes of LDS
 // (lane 0 merges them after every branch), so the satellite loop is a real loop: one inverse transform's worth of code.
 struct SatStat { float v; int key; int cnt; int pad; double sum; };
-template <int K, int G>
-__global__ __launch_bounds__(512, 2) void grid_cells_wave_shared_kernel(GridParams p, int gs) {   // gs <= G satellites per wavefront (the host picks it by how full the chip gets)
+// WAVES: as for grid_cells_wave_fused_kernel below -- 12 (three wavefronts per SIMD, the replica multiplied in from L1 / L2 in batches) or 8 (two per
+// SIMD, the next replica prefetched into registers).
+template <int K, int G, int WAVES = 8>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void grid_cells_wave_shared_kernel(GridParams p, int gs) {
+    constexpr bool kPrefetch = WAVES == 8;   // gs <= G satellites per wavefront (the host picks it by how full the chip gets)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cf* tw1024 = reinterpret_cast<cf*>(smem_raw);
     cf* tw2048 = tw1024 + 1024;
     cf* tiles = tw2048 + 1024;
-    for (int i = threadIdx.x; i < 2048; i += 512) tw1024[i] = p.tw_tables[i];
+    for (int i = threadIdx.x; i < 2048; i += 64 * WAVES) tw1024[i] = p.tw_tables[i];
     __syncthreads();
     const int tid = launder(threadIdx.x);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, l = lane & 31, h = lane >> 5;
     float* tile_half = reinterpret_cast<float*>(tiles + wave * kXchWave) + h * kXchTile;
-    SatStat* stats = reinterpret_cast<SatStat*>(tiles + 8 * kXchWave) + wave * G;
+    SatStat* stats = reinterpret_cast<SatStat*>(tiles + WAVES * kXchWave) + wave * G;
     const LdsTables t{tw1024, tw2048};
     const int n_sg = (p.n_sats + gs - 1) / gs;
     const int parts = p.parts > 1 ? p.parts : 1;                 // runs of K / parts polyphase branches (the host picks a divisor of K)
     const int n_groups = p.n_streams * p.n_bins * n_sg * parts;
-    for (int v = blockIdx.x * 8 + wave; v < n_groups; v += gridDim.x * 8) {
+    for (int v = blockIdx.x * WAVES + wave; v < n_groups; v += gridDim.x * WAVES) {
         // satellite groups vary fastest, then the branch runs: the groups that read the SAME rows of a unit are neighbouring wavefronts of
         // one workgroup (the rows come out of L1 / L2 for all but the first), and a unit's items run back to back inside one XCD's slice
-        const int item = (n_groups & 7) ? v : xcd_contiguous(v >> 3, n_groups >> 3) * 8 + (v & 7);
+        const int item = (WAVES != 8 || (n_groups & 7)) ? v : xcd_contiguous(v >> 3, n_groups >> 3) * 8 + (v & 7);
         const int sg = item % n_sg, part = (item / n_sg) % parts, unit_i = item / (n_sg * parts);
         const int bin = unit_i % p.n_bins, stream = unit_i / p.n_bins;
         const int g_n = min(gs, p.n_sats - sg * gs);
@@ -360,12 +363,13 @@ __global__ __launch_bounds__(512, 2) void grid_cells_wave_shared_kernel(GridPara
             }
             // the replica spectrum of the NEXT satellite is requested before the current one's inverse transform (64 registers: the
             // 256-register budget has room for it), the first one's before the forward transform: no load latency between transforms
-            cf prn[32];
+            cf prn[kPrefetch ? 32 : 1];
             auto request_replica = [&](int g) {
+                if constexpr (!kPrefetch) return;
                 const int sat_index = __builtin_amdgcn_readfirstlane(p.sat_ids[sg * gs + g]) - 1;
                 const cf* row = replica_of(p.replica_table, sat_index) + launder(lane);
 #pragma unroll
-                for (int i = 0; i < 32; ++i) prn[i] = row[64 * i];
+                for (int i = 0; i < (kPrefetch ? 32 : 1); ++i) prn[i] = row[64 * i];
             };
             request_replica(0);
             __builtin_amdgcn_sched_barrier(0);
@@ -373,11 +377,26 @@ __global__ __launch_bounds__(512, 2) void grid_cells_wave_shared_kernel(GridPara
 #pragma unroll 1
             for (int g = 0; g < g_n; ++g) {
                 cf y[32];
+                if constexpr (kPrefetch) {
 #pragma unroll
-                for (int i = 0; i < 32; ++i) y[i] = cmul(x[i], prn[i]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (g + 1 < g_n) request_replica(g + 1);
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int i = 0; i < 32; ++i) y[i] = cmul(x[i], prn[i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g + 1 < g_n) request_replica(g + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    const int sat_index = __builtin_amdgcn_readfirstlane(p.sat_ids[sg * gs + g]) - 1;
+                    const cf* rep_sat = replica_of(p.replica_table, sat_index);
+#pragma unroll
+                    for (int b = 0; b < 32; b += kTwBatch) {
+                        cf q[kTwBatch];
+                        const cf* rowp = rep_sat + 64 * b + launder(lane);
+#pragma unroll
+                        for (int i = 0; i < kTwBatch; ++i) q[i] = rowp[64 * i];
+#pragma unroll
+                        for (int i = 0; i < kTwBatch; ++i) y[b + i] = cmul(x[b + i], q[i]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
                 cf c[16];
                 wave_fft_inv(y, c, tile_half, t, l, h);
                 float mag[16];
@@ -419,27 +438,33 @@ __global__ __launch_bounds__(512, 2) void grid_cells_wave_shared_kernel(GridPara
 //   stream are neighbouring wavefronts -- and cost ~2 % of the 1 + n_sats transforms they feed), reads the row back in transform order,
 //   runs ONE forward transform, and loops the satellites: replica product (next replica requested first), inverse, statistics.
 // (1 + 32) transforms per 32 cells instead of 36, no fold kernel, no folded rows: HBM sees the samples once and the 32-byte records.
-template <int K, bool COHERENT>
-__global__ __launch_bounds__(512, 2) void grid_cells_wave_fused_kernel(GridParams p) {
+// WAVES = 12 (the default since r06's per-wavefront stamps showed the 8-wavefront kernels bound by two instruction streams per SIMD): three wavefronts
+// per SIMD at <= 170 registers -- the replica is multiplied in straight from L1 / L2 in batches (as the tracking kernels do), no prefetch buffer, 12-24
+// spilled registers -- and still +5.5 % (config 2: 27.04 -> 25.63 ms per launch, profiles/r06_experiments.txt item 8).
+// WAVES = 8 (gyp_debug_set "grid_fused_waves" 8, A/B): the 256-register budget, the next satellite's replica spectrum requested into 64 registers
+// before the current inverse transform.
+template <int K, bool COHERENT, int WAVES = 8>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void grid_cells_wave_fused_kernel(GridParams p) {
+    constexpr bool kPrefetch = WAVES == 8;
     constexpr int G = 32;
     constexpr int N = K * kChips;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cf* tw1024 = reinterpret_cast<cf*>(smem_raw);
     cf* tw2048 = tw1024 + 1024;
     cf* tiles = tw2048 + 1024;
-    for (int i = threadIdx.x; i < 2048; i += 512) tw1024[i] = p.tw_tables[i];
+    for (int i = threadIdx.x; i < 2048; i += 64 * WAVES) tw1024[i] = p.tw_tables[i];
     __syncthreads();
     const int tid = launder(threadIdx.x);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, l = lane & 31, h = lane >> 5;
     cf* row = tiles + wave * kXchWave;                            // the staged row aliases the transpose tile (1088 >= 1024 complex)
     float* tile_half = reinterpret_cast<float*>(row) + h * kXchTile;
-    SatStat* stats = reinterpret_cast<SatStat*>(tiles + 8 * kXchWave) + wave * G;
+    SatStat* stats = reinterpret_cast<SatStat*>(tiles + WAVES * kXchWave) + wave * G;
     const LdsTables t{tw1024, tw2048};
     const int n_units = p.n_streams * p.n_bins;
-    for (int v = blockIdx.x * 8 + wave; v < n_units; v += gridDim.x * 8) {
+    for (int v = blockIdx.x * WAVES + wave; v < n_units; v += gridDim.x * WAVES) {
         // bins vary fastest: the eight wavefronts of a workgroup (and the workgroups of an XCD's contiguous slice) wipe the same samples
-        const int unit_i = (n_units & 7) ? v : xcd_contiguous(v >> 3, n_units >> 3) * 8 + (v & 7);
+        const int unit_i = (WAVES != 8 || (n_units & 7)) ? v : xcd_contiguous(v >> 3, n_units >> 3) * 8 + (v & 7);
         const int bin = unit_i % p.n_bins, stream = unit_i / p.n_bins;
         const double f = p.doppler[bin];
         const double du = f * p.inv_fs;
@@ -449,12 +474,13 @@ __global__ __launch_bounds__(512, 2) void grid_cells_wave_fused_kernel(GridParam
         if (lane < G) { SatStat z; z.v = -1.0f; z.key = 0x7fffffff; z.cnt = 0; z.pad = 0; z.sum = 0.0; stats[lane] = z; }
 #pragma unroll 1
         for (int r = 0; r < K; ++r) {
-            cf prn[32];
+            cf prn[kPrefetch ? 32 : 1];
             auto request_replica = [&](int g) {
+                if constexpr (!kPrefetch) return;
                 const int sat_index = __builtin_amdgcn_readfirstlane(p.sat_ids[g]) - 1;
                 const cf* rep = replica_of(p.replica_table, sat_index) + launder(lane);
 #pragma unroll
-                for (int i = 0; i < 32; ++i) prn[i] = rep[64 * i];
+                for (int i = 0; i < (kPrefetch ? 32 : 1); ++i) prn[i] = rep[64 * i];
             };
             {
                 cf* y_rows[1] = {row};
@@ -475,11 +501,26 @@ __global__ __launch_bounds__(512, 2) void grid_cells_wave_fused_kernel(GridParam
 #pragma unroll 1
             for (int g = 0; g < p.n_sats; ++g) {
                 cf y[32];
+                if constexpr (kPrefetch) {
 #pragma unroll
-                for (int i = 0; i < 32; ++i) y[i] = cmul(x[i], prn[i]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (g + 1 < p.n_sats) request_replica(g + 1);
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int i = 0; i < 32; ++i) y[i] = cmul(x[i], prn[i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g + 1 < p.n_sats) request_replica(g + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    const int sat_index = __builtin_amdgcn_readfirstlane(p.sat_ids[g]) - 1;
+                    const cf* rep_sat = replica_of(p.replica_table, sat_index);
+#pragma unroll
+                    for (int b = 0; b < 32; b += kTwBatch) {
+                        cf q[kTwBatch];
+                        const cf* rowp = rep_sat + 64 * b + launder(lane);
+#pragma unroll
+                        for (int i = 0; i < kTwBatch; ++i) q[i] = rowp[64 * i];
+#pragma unroll
+                        for (int i = 0; i < kTwBatch; ++i) y[b + i] = cmul(x[b + i], q[i]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
                 cf c[16];
                 wave_fft_inv(y, c, tile_half, t, l, h);
                 float mag[16];

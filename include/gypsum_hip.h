@@ -521,6 +521,8 @@ int gyp_ingest_times(const gyp_ingest* ing, int64_t first_ms, int32_t n_ms, doub
  *                               launch partly empty (default: a unit's polyphase branches are cut into runs, merged afterwards)
  *   "no_grid_fused" 0/1 (0)     flat grids that fill the chip (<= 8 samples per chip, single block) fold into rows in HBM first (r05's
  *                               grid_fold_kernel + grid_cells_wave_shared_kernel) instead of one fused kernel per (stream, bin) unit
+ *   "grid_fused_waves" 8 or 12 (12)  wavefronts per workgroup of the fused flat-grid kernel: 12 = three per SIMD at <= 170 registers (the replica
+ *                               multiplied in from L1 / L2 in batches), 8 = two per SIMD at 256 (the next replica prefetched into registers); same cells
  *   "last_grid_path" (read only, gyp_debug_get)  the cells kernel the last gyp_correlate_grid* call took: 1 fused, 2 shared forward
  *                               transforms out of folded rows, 3 one wavefront per cell, 4 one workgroup per cell
  *   "spec_sub_ms" 0, 100..2000 (0)  target length of the sub-blocks of a speculative tracking block (a failed verification costs its

@@ -250,6 +250,12 @@ def test_fused_grid_kernel_against_folded_rows_and_oracle(engine_factory, fs, n_
 
     fused, path = run()
     assert path == 1
+    eng.debug_set("grid_fused_waves", 8)      # the 8-wavefront form of the same kernel (replica prefetched into registers): same arithmetic, same bytes
+    try:
+        fused8, path = run()
+    finally:
+        eng.debug_set("grid_fused_waves", 12)
+    assert path == 1 and fused8.tobytes() == fused.tobytes()
     eng.debug_set("no_grid_fused", 1)
     try:
         rows, path = run()
