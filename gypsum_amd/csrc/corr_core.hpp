@@ -99,8 +99,11 @@ struct LdsTables {
 // 32x32 transpose inside each half-wave: lane l, register g  ->  lane g, register l.  The real parts of all 64
 // lanes go through the wavefront's float tile pair first, then the imaginary parts: no extra registers, no
 // divergence, half the LDS footprint of a complex tile.  perm(g) names the physical register holding row g.
-template <typename Perm>
+// LEAN (the 168-register kernels at three wavefronts per SIMD): the lane's tile addresses are re-derived here from an opaque copy of l -- a
+// few integer instructions per transpose -- instead of living in ~14 registers across the caller's loops (where they were spilled).
+template <bool LEAN = false, typename Perm>
 __device__ __forceinline__ void transpose32(cf (&x)[32], float* tile_half, int l, Perm perm) {
+    if constexpr (LEAN) { l = launder(l); tile_half = launder_lds(tile_half); }
     const float2* row = reinterpret_cast<const float2*>(tile_half + kXchRow * l);
 #pragma unroll
     for (int g = 0; g < 32; ++g) tile_half[kXchRow * g + l] = x[perm(g)].x;
@@ -147,7 +150,7 @@ __device__ __forceinline__ void twiddle_batch(cf (&x)[32], const cf* __restrict_
 // ONES: the radix-2 twiddle pass runs on BOTH half-waves, the even one reading a table of ones (same instruction stream, same
 // cost in issue slots as the masked form -- the masked lanes idle through it anyway -- but no branch, and none of the ~64
 // register copies the allocator spends re-joining the two paths of `if (h)`).  Multiplying by 1 + 0i is exact.
-template <int B = kTwBatch, bool ONES = false>
+template <int B = kTwBatch, bool ONES = false, bool LEAN = false>
 __device__ __forceinline__ void wave_fft_fwd(cf (&x)[32], float* tile_half, const LdsTables& t, int l, int h) {
     if constexpr (ONES) {
         const cf* tab = (h ? t.tw2048 : t.ones) + launder(l);
@@ -166,7 +169,7 @@ __device__ __forceinline__ void wave_fft_fwd(cf (&x)[32], float* tile_half, cons
 #pragma unroll
         for (int b = 0; b < 32; b += B) twiddle_batch<false, true, B>(x, tab, b, [](int g) { return bitrev5(g); });
     }
-    transpose32(x, tile_half, l, [](int g) { return bitrev5(g); });
+    transpose32<LEAN>(x, tile_half, l, [](int g) { return bitrev5(g); });
     __builtin_amdgcn_sched_barrier(0);
     fft32_fwd_nat_br(x);
     __builtin_amdgcn_sched_barrier(0);
@@ -175,7 +178,7 @@ __device__ __forceinline__ void wave_fft_fwd(cf (&x)[32], float* tile_half, cons
 // Inverse transform (un-normalised; the 1/2048 lives in the PRN spectrum table) + half-wave combine.
 // In: physical register i holds bin f = 2*(l + 32*bitrev5(i)) + h.
 // Out: c[j], j = 0..15: lag q = l + 32*(j + 16*h).
-template <int B = kTwBatch>
+template <int B = kTwBatch, bool LEAN = false>
 __device__ __forceinline__ void wave_fft_inv(cf (&x)[32], cf (&c)[16], float* tile_half, const LdsTables& t, int l, int h) {
     __builtin_amdgcn_sched_barrier(0);
     fft32_inv_br_nat(x);
@@ -185,7 +188,7 @@ __device__ __forceinline__ void wave_fft_inv(cf (&x)[32], cf (&c)[16], float* ti
 #pragma unroll
         for (int b = 0; b < 32; b += B) twiddle_batch<true, true, B>(x, tab, b, [](int q) { return q; });
     }
-    transpose32(x, tile_half, l, [](int q) { return q; });
+    transpose32<LEAN>(x, tile_half, l, [](int q) { return q; });
     __builtin_amdgcn_sched_barrier(0);
     fft32_inv_nat_br(x);
     __builtin_amdgcn_sched_barrier(0);

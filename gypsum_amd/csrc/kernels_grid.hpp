@@ -343,10 +343,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void grid_cells_wave_shared_
     const int n_sg = (p.n_sats + gs - 1) / gs;
     const int parts = p.parts > 1 ? p.parts : 1;                 // runs of K / parts polyphase branches (the host picks a divisor of K)
     const int n_groups = p.n_streams * p.n_bins * n_sg * parts;
-    for (int v = blockIdx.x * WAVES + wave; v < n_groups; v += gridDim.x * WAVES) {
+    const int n_wg_items = (n_groups + WAVES - 1) / WAVES;
+    for (int w = blockIdx.x; w < n_wg_items; w += gridDim.x) {
         // satellite groups vary fastest, then the branch runs: the groups that read the SAME rows of a unit are neighbouring wavefronts of
         // one workgroup (the rows come out of L1 / L2 for all but the first), and a unit's items run back to back inside one XCD's slice
-        const int item = (WAVES != 8 || (n_groups & 7)) ? v : xcd_contiguous(v >> 3, n_groups >> 3) * 8 + (v & 7);
+        const int item = xcd_contiguous(w, n_wg_items) * WAVES + wave;
+        if (item >= n_groups) continue;                            // the last workgroup item may be short (no workgroup barriers in this loop)
         const int sg = item % n_sg, part = (item / n_sg) % parts, unit_i = item / (n_sg * parts);
         const int bin = unit_i % p.n_bins, stream = unit_i / p.n_bins;
         const int g_n = min(gs, p.n_sats - sg * gs);
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void grid_cells_wave_shared_
             };
             request_replica(0);
             __builtin_amdgcn_sched_barrier(0);
-            wave_fft_fwd(x, tile_half, t, l, h);
+            wave_fft_fwd<kTwBatch, false, !kPrefetch>(x, tile_half, t, l, h);
 #pragma unroll 1
             for (int g = 0; g < g_n; ++g) {
                 cf y[32];
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void grid_cells_wave_shared_
                     }
                 }
                 cf c[16];
-                wave_fft_inv(y, c, tile_half, t, l, h);
+                wave_fft_inv<kTwBatch, !kPrefetch>(y, c, tile_half, t, l, h);
                 float mag[16];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) mag[j] = __builtin_amdgcn_sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));
@@ -462,9 +464,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void grid_cells_wave_fused_k
     SatStat* stats = reinterpret_cast<SatStat*>(tiles + WAVES * kXchWave) + wave * G;
     const LdsTables t{tw1024, tw2048};
     const int n_units = p.n_streams * p.n_bins;
-    for (int v = blockIdx.x * WAVES + wave; v < n_units; v += gridDim.x * WAVES) {
-        // bins vary fastest: the eight wavefronts of a workgroup (and the workgroups of an XCD's contiguous slice) wipe the same samples
-        const int unit_i = (WAVES != 8 || (n_units & 7)) ? v : xcd_contiguous(v >> 3, n_units >> 3) * 8 + (v & 7);
+    const int n_wg_items = (n_units + WAVES - 1) / WAVES;
+    for (int w = blockIdx.x; w < n_wg_items; w += gridDim.x) {
+        // bins vary fastest: the wavefronts of a workgroup (and the workgroups of an XCD's contiguous slice) wipe the same samples
+        // (workgroup b runs on XCD b % 8: every XCD works through one contiguous eighth of the units, so a (stream, block)'s samples enter ONE L2)
+        const int unit_i = xcd_contiguous(w, n_wg_items) * WAVES + wave;
+        if (unit_i >= n_units) continue;                           // the last item may be short (no workgroup barriers in this loop)
         const int bin = unit_i % p.n_bins, stream = unit_i / p.n_bins;
         const double f = p.doppler[bin];
         const double du = f * p.inv_fs;
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void grid_cells_wave_fused_k
             request_replica(0);
             wave_lds_fence();                                     // every lane has its row values before the transposes overwrite the tile
             __builtin_amdgcn_sched_barrier(0);
-            wave_fft_fwd(x, tile_half, t, l, h);
+            wave_fft_fwd<kTwBatch, false, !kPrefetch>(x, tile_half, t, l, h);
 #pragma unroll 1
             for (int g = 0; g < p.n_sats; ++g) {
                 cf y[32];
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void grid_cells_wave_fused_k
                     }
                 }
                 cf c[16];
-                wave_fft_inv(y, c, tile_half, t, l, h);
+                wave_fft_inv<kTwBatch, !kPrefetch>(y, c, tile_half, t, l, h);
                 float mag[16];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) mag[j] = __builtin_amdgcn_sqrtf(fmaf(c[j].x, c[j].x, c[j].y * c[j].y));

@@ -74,7 +74,8 @@ try:
     commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=REPO, capture_output=True, text=True).stdout.strip()
 except Exception:
     commit = None
-latest = {}
+# a partial visit (say `pmcgrid` with GRID_WORKLOADS=cfg2 after a kernel change) refreshes its own entries and keeps the others, tagged as they were
+latest = json.load(open(dst / "pmc_latest.json")) if (dst / "pmc_latest.json").exists() else {}
 for k, v in entry.items():
     if "track_block_kernel<8, false, 0>" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         fetch, write = v["FETCH_SIZE"]["mean_per_launch"], v["WRITE_SIZE"]["mean_per_launch"]
