@@ -556,7 +556,7 @@ def run_cfg3(eng, comm, args, rng, eng_scan=None) -> dict:
     k3 /= reps
     if not k3[0] > 0:                    # (a lightly loaded bank takes the speculative path: no per-kernel split there)
         k3[0] = trk_ms
-    n_launch = max(1, int(round(k3[3])))  # the library cuts long blocks into launches of <= 500 ms (a launch boundary re-aligns the
+    n_launch = max(1, int(round(k3[3])))  # the library cuts long blocks into launches of <= 250 ms (r03-r05: 500; a launch boundary re-aligns the
                                           # channels of a stream, whose workgroups otherwise drift out of each other's L2 reach)
     # the same scans with gyp_params::acq_reuse_level_records = 0 (every bin of every level correlated again, as the reference does
     # with its cache lookup switched off, acquisition.py:204): bit-identical results, reported beside the default

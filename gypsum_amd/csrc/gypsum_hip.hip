@@ -120,7 +120,7 @@ struct gyp_ctx {
     int n_cus = 256;
     int n_xcd = 8;             // hipDeviceAttributeNumberOfXccs (workgroup b is dispatched to XCD b % n_xcd)
     bool no_pipe = false;      // gyp_debug_set("no_pipe"): A/B switch back to the two-workgroups-per-CU cells kernel
-    int track_chunk_ms = 500;     // gyp_debug_set("track_chunk_ms"): the throughput tracking kernel's launch length (0: whole blocks)
+    int track_chunk_ms = 250;     // gyp_debug_set("track_chunk_ms"): the throughput tracking kernel's launch length (0: whole blocks; r03-r05: 500)
     float symbol_tau = 1e-4f;     // gyp_debug_set("symbol_tau"): |Re peak| / |peak| below which the pseudosymbol is decided in float64 (test hook: 10 = always)
     bool no_shared_fwd = false;   // gyp_debug_set("no_shared_fwd"): A/B switch: flat grids transform every cell's rows themselves again
     int cells_cu_reserve = 0;     // gyp_debug_set("cells_cu_reserve", n): CUs the correlation-cell launches leave free (see launch_cells)
@@ -1424,9 +1424,13 @@ static int track_block_throughput(gyp_bank* bank, TrackBlockParams p, const int3
     // The channels of a stream are independent workgroups that read the same samples; nothing keeps them within an L2's worth
     // (~11 ms of an XCD's resident streams) of each other, and over a 1000-ms launch they drift apart: FETCH_SIZE per
     // millisecond is 1.24x the algorithmic bytes for launches of <= 250 ms and 2.6x for 1000 ms (profiles/r03_drift.txt).  A
-    // launch boundary is a rendezvous: long blocks go through in chunks of 500 ms (the loop state travels in ChanState anyway,
-    // and a block gives the same records however it is cut).  Shorter chunks buy little more traffic and cost a host-fed
-    // pipeline its overlap: the chip drains at every boundary and the upload stream's widen kernel takes it whole.
+    // launch boundary is a rendezvous: long blocks go through in chunks (the loop state travels in ChanState anyway, and a block
+    // gives the same records however it is cut).  r03-r05: 500 ms (1.3-1.5x).  How far the workgroups of a stream drift depends on
+    // their relative pace, and with the staging instructions of r06's gain correction 500-ms launches counted 2.0x at an unchanged
+    // kernel time (profiles/r06_experiments.txt item 9).  r06: 250 ms -- 1.29x, the same 58.6 ms of tracking kernels per
+    // 1536-channel x 1000-ms step (125 ms: 1.23x), resident throughput unchanged; the price is a host-fed pipeline's overlap --
+    // the chip drains at every boundary and the upload stream's widen kernel takes it whole: int8-fed 0.960 -> 0.938 of the
+    // resident rate (profiles/r06zf_chunk_sweep.txt, r06zf_chunk_legs.txt).
     const int chunk = (only_if || ctx->track_chunk_ms <= 0) ? p.n_ms : ctx->track_chunk_ms;
     ctx->track_launches = (p.n_ms + chunk - 1) / chunk;
     for (int b0 = 0; b0 < p.n_ms; b0 += chunk) {

@@ -534,7 +534,7 @@ int gyp_ingest_times(const gyp_ingest* ing, int64_t first_ms, int32_t n_ms, doub
  *   "no_spec" 0/1 (0)           lightly loaded banks use the throughput kernel too
  *   "spec_redo" 0/1 (1)         0: a failed speculation is re-run on the throughput kernel (r03 behaviour)
  *   "spec_debug" 0/1 (0)        per-ms window dump for gyp_debug_spec_read
- *   "track_chunk_ms" 0 | >= 20 (500)   launch length of the throughput tracking kernel (0: whole blocks)
+ *   "track_chunk_ms" 0 | >= 20 (250)   launch length of the throughput tracking kernel (0: whole blocks)
  *   "exact_prefetch" 0/1 (0)    dll_exact_wave_kernel with its next window software-prefetched (A/B: measured slower, profiles/r04_exact_ab.txt)
  *   "prof_wave" 0..7 (0)        which wavefront of workgroup 0 stamps the counters of gyp_debug_track_profile
  *   "symbol_tau" 0..100 (1e-4)  |Re peak| / |peak| below which dll_scan_kernel decides the pseudosymbol in float64 (test: 10 = always)
@@ -559,7 +559,7 @@ int gyp_debug_spec_read(gyp_bank* bank, float* out, int32_t n_floats, int32_t* b
 /* Debug / measurement: HIP events on the context's stream around the three stages behind gyp_track_block(_dev) on the
  * throughput path (banks of more than one channel per CU): enable != 0 arms it; out4 (may be NULL) receives, for the last
  * call, {ms in track_block_kernel (all its launches), ms in the dll_exact kernel, ms in dll_scan_kernel, number of
- * track_block_kernel launches: blocks longer than 500 ms go through in chunks, gyp_debug_set "track_chunk_ms"} -- zeros when that call
+ * track_block_kernel launches: blocks longer than 250 ms go through in chunks, gyp_debug_set "track_chunk_ms"} -- zeros when that call
  * ran on the speculative path (lightly loaded banks), which has no such split.  bench.py's per-kernel roofline uses it. */
 int gyp_debug_track_timing(gyp_ctx* ctx, int enable, float* out4);
 /* Debug / telemetry (either tracking path): repairs_out[n_chan] = milliseconds of the last gyp_track_block(_dev) call in which

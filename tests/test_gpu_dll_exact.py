@@ -125,7 +125,7 @@ def test_forced_repairs_leave_records_and_state_exact(fs):
     n_ms, n_sats = (409, 4) if n <= 8184 else (209, 3)
     iq, inits = _scene_and_inits(fs, n, n_ms, n_sats, 880 + n)
     ref = _oracle_rows(iq, inits, fs, n, n_ms)
-    # (GYP_TRACK_CHUNK_MS: the throughput kernel goes through a block in several launches -- 500 ms each by default, 37 here so
+    # (GYP_TRACK_CHUNK_MS: the throughput kernel goes through a block in several launches -- 250 ms each by default, 37 here so
     # that launch boundaries fall inside these 400-ms blocks and inside runs of repaired milliseconds)
     runs = [("throughput", {"GYP_NO_SPEC": 1}), ("throughput, biased", {"GYP_NO_SPEC": 1, "GYP_DLL_PROV_BIAS": 20.0}),
             ("throughput, biased, 37-ms launches", {"GYP_NO_SPEC": 1, "GYP_DLL_PROV_BIAS": 20.0, "GYP_TRACK_CHUNK_MS": 37}),
@@ -375,6 +375,6 @@ def test_debug_switches_are_range_checked(engine_factory):
         with pytest.raises(GypsumHipError):
             eng.debug_set(name, bad_value)
     before = eng.debug_get("track_chunk_ms")
-    eng.debug_set("track_chunk_ms", 250)
-    assert eng.debug_get("track_chunk_ms") == 250
+    eng.debug_set("track_chunk_ms", 300)
+    assert eng.debug_get("track_chunk_ms") == 300
     eng.debug_set("track_chunk_ms", before)
