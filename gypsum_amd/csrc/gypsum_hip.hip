@@ -120,6 +120,9 @@ struct gyp_ctx {
     int n_cus = 256;
     int n_xcd = 8;             // hipDeviceAttributeNumberOfXccs (workgroup b is dispatched to XCD b % n_xcd)
     bool no_pipe = false;      // gyp_debug_set("no_pipe"): A/B switch back to the two-workgroups-per-CU cells kernel
+    int widen_wg_per_cu = 2;      // gyp_debug_set("widen_wg_per_cu"): workgroups per CU of the ingest widen kernel's persistent grid (1..8).  It runs on the
+                                  // upload stream BESIDE the previous block's kernels: with 8 per CU (r02-r05) it took the chip at every launch boundary of the
+                                  // trackers; 2 per CU leave them their slots -- int8-fed / resident 0.934-0.942 -> 0.949-0.953 (profiles/r06zi / r06zj_widen_grid.txt)
     int track_chunk_ms = 250;     // gyp_debug_set("track_chunk_ms"): the throughput tracking kernel's launch length (0: whole blocks; r03-r05: 500)
     float symbol_tau = 1e-4f;     // gyp_debug_set("symbol_tau"): |Re peak| / |peak| below which the pseudosymbol is decided in float64 (test hook: 10 = always)
     bool no_shared_fwd = false;   // gyp_debug_set("no_shared_fwd"): A/B switch: flat grids transform every cell's rows themselves again
@@ -2000,7 +2003,7 @@ namespace {
 struct DebugKnob { const char* name; double lo, hi; bool integral; };
 const DebugKnob kDebugKnobs[] = {
     {"no_pipe", 0, 1, true}, {"no_shared_fwd", 0, 1, true}, {"no_acq_split", 0, 1, true}, {"no_spec", 0, 1, true},
-    {"spec_debug", 0, 1, true}, {"acq_lanes", 1, gyp_ctx::kMaxAcqLanes, true}, {"track_chunk_ms", 0, 1e6, true},
+    {"spec_debug", 0, 1, true}, {"acq_lanes", 1, gyp_ctx::kMaxAcqLanes, true}, {"track_chunk_ms", 0, 1e6, true}, {"widen_wg_per_cu", 1, 8, true},
     {"symbol_tau", 0, 100, false}, {"dll_prov_bias", -1e6, 1e6, false}, {"spec_fail_at", -1, 2147483647.0, true},
     {"spec_redo", 0, 1, true}, {"spec_sub_ms", 0, 2000, true}, {"exact_prefetch", 0, 1, true}, {"prof_wave", 0, 7, true}, {"no_grid_parts", 0, 1, true}, {"no_grid_fused", 0, 1, true}, {"grid_fused_waves", 8, 12, true}, {"cells_cu_reserve", 0, 128, true},
 };
@@ -2024,6 +2027,7 @@ static int debug_apply(gyp_ctx* ctx, const char* name, double v, bool set, doubl
     GYP_KNOB_NUM("spec_sub_ms", spec_sub_ms, int)
     GYP_KNOB_NUM("acq_lanes", acq_lanes, int)
     GYP_KNOB_NUM("track_chunk_ms", track_chunk_ms, int)
+    GYP_KNOB_NUM("widen_wg_per_cu", widen_wg_per_cu, int)
     GYP_KNOB_NUM("symbol_tau", symbol_tau, float)
     GYP_KNOB_NUM("dll_prov_bias", dll_prov_bias, double)
     GYP_KNOB_NUM("spec_fail_at", spec_fail_at, int)
@@ -2298,7 +2302,7 @@ static int ingest_enqueue_upload(gyp_ingest* g, gyp_ingest::Upload* u, bool wait
     HIP_TRY(ctx, hipMemcpyAsync(dst, g->host[slot], bytes, hipMemcpyHostToDevice, g->copy_stream));
     HIP_TRY(ctx, hipEventRecord(g->uploaded[d], g->copy_stream));
     if (g->fmt != kFmtF32) {
-        const int grid = (int)std::min<size_t>((words / 16 + 255) / 256 + 1, (size_t)ctx->n_cus * 8);
+        const int grid = (int)std::min<size_t>((words / 16 + 255) / 256 + 1, (size_t)ctx->n_cus * ctx->widen_wg_per_cu);
         switch (g->fmt) {
             case kFmtI8: hipLaunchKernelGGL(ingest_widen_kernel<int8_t>, dim3(grid), dim3(256), 0, g->copy_stream, (const int8_t*)dst, g->dev_iq[d], words, g->scale); break;
             case kFmtU8: hipLaunchKernelGGL(ingest_widen_kernel<uint8_t>, dim3(grid), dim3(256), 0, g->copy_stream, (const uint8_t*)dst, g->dev_iq[d], words, g->scale); break;
@@ -2490,7 +2494,7 @@ int gyp_ingest_next_dev(gyp_ingest* g, const float** iq_dev_out, int64_t* first_
 int gyp_widen_iq_dev(gyp_ctx* ctx, int32_t fmt, const void* raw_dev, uint64_t n_words, float scale, float* out_dev) {
     if (!ctx || !raw_dev || !out_dev) return ctx ? fail(ctx, GYP_E_BAD_ARG, "gyp_widen_iq_dev: bad argument") : GYP_E_BAD_ARG;
     if (n_words == 0) return GYP_OK;
-    const int grid = (int)std::min<uint64_t>((n_words / 16 + 255) / 256 + 1, (uint64_t)ctx->n_cus * 8);
+    const int grid = (int)std::min<uint64_t>((n_words / 16 + 255) / 256 + 1, (uint64_t)ctx->n_cus * ctx->widen_wg_per_cu);
     switch (fmt) {
         case GYP_FMT_I8: hipLaunchKernelGGL(ingest_widen_kernel<int8_t>, dim3(grid), dim3(256), 0, ctx->stream, (const int8_t*)raw_dev, out_dev, (size_t)n_words, scale); break;
         case GYP_FMT_U8: hipLaunchKernelGGL(ingest_widen_kernel<uint8_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint8_t*)raw_dev, out_dev, (size_t)n_words, scale); break;

@@ -74,7 +74,7 @@ class GypsumEngine:
     # process creates (tests/, tools/) export GYP_TEST_HOOKS=1 next to the switch; without it the variables below do nothing.
     _ENV_HOOKS = {"GYP_NO_PIPE": "no_pipe", "GYP_NO_SHARED_FWD": "no_shared_fwd", "GYP_NO_GRID_PARTS": "no_grid_parts", "GYP_NO_GRID_FUSED": "no_grid_fused", "GYP_GRID_FUSED_WAVES": "grid_fused_waves", "GYP_NO_ACQ_SPLIT": "no_acq_split",
                   "GYP_NO_SPEC": "no_spec", "GYP_SPEC_DEBUG": "spec_debug", "GYP_ACQ_LANES": "acq_lanes",
-                  "GYP_TRACK_CHUNK_MS": "track_chunk_ms", "GYP_SYMBOL_TAU": "symbol_tau", "GYP_DLL_PROV_BIAS": "dll_prov_bias",
+                  "GYP_TRACK_CHUNK_MS": "track_chunk_ms", "GYP_WIDEN_WG_PER_CU": "widen_wg_per_cu", "GYP_SYMBOL_TAU": "symbol_tau", "GYP_DLL_PROV_BIAS": "dll_prov_bias",
                   "GYP_SPEC_FAIL_AT": "spec_fail_at", "GYP_SPEC_REDO": "spec_redo", "GYP_SPEC_SUB_MS": "spec_sub_ms", "GYP_EXACT_PREFETCH": "exact_prefetch", "GYP_PROF_WAVE": "prof_wave"}
 
     def _apply_test_hooks(self) -> None:

@@ -535,6 +535,7 @@ int gyp_ingest_times(const gyp_ingest* ing, int64_t first_ms, int32_t n_ms, doub
  *   "spec_redo" 0/1 (1)         0: a failed speculation is re-run on the throughput kernel (r03 behaviour)
  *   "spec_debug" 0/1 (0)        per-ms window dump for gyp_debug_spec_read
  *   "track_chunk_ms" 0 | >= 20 (250)   launch length of the throughput tracking kernel (0: whole blocks)
+ *   "widen_wg_per_cu" 1..8 (2)  workgroups per CU of the widen kernel's persistent grid (gyp_widen_iq_dev, the ingest ring); same output for any value
  *   "exact_prefetch" 0/1 (0)    dll_exact_wave_kernel with its next window software-prefetched (A/B: measured slower, profiles/r04_exact_ab.txt)
  *   "prof_wave" 0..7 (0)        which wavefront of workgroup 0 stamps the counters of gyp_debug_track_profile
  *   "symbol_tau" 0..100 (1e-4)  |Re peak| / |peak| below which dll_scan_kernel decides the pseudosymbol in float64 (test: 10 = always)
