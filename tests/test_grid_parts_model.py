@@ -53,3 +53,47 @@ def test_runs_merged_in_branch_order_equal_the_whole_cell(k, seed, with_ties):
             got = fold(got, p_)
         assert got["v"] == want["v"] and got["key"] == want["key"] and got["cnt"] == want["cnt"], (k, parts)
         assert abs(got["sum"] - want["sum"]) <= 1e-12 * want["sum"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# r06: the unit order of the one-wavefront-per-unit flat-grid kernels (grid_cells_wave_fused_kernel / grid_cells_wave_shared_kernel,
+# csrc/kernels_grid.hpp).  A workgroup of WAVES wavefronts takes workgroup ITEMS of WAVES consecutive units; item w of the persistent grid
+# goes through xcd_contiguous (csrc/corr_core.hpp) so that workgroup b -- which runs on XCD b % 8 -- works through one contiguous eighth of
+# the units; the last item may be short.  Restated here: every unit is visited exactly once for any unit count, wavefront count and grid
+# size, and with a grid that is a multiple of eight every XCD's units form one contiguous range.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def xcd_contiguous(b, n):
+    x, slot, q, r = b & 7, b >> 3, n >> 3, n & 7
+    return x * q + min(x, r) + slot
+
+
+def visited_units(n_units, waves, grid):
+    n_items = (n_units + waves - 1) // waves
+    seen = []
+    for block in range(grid):
+        for w in range(block, n_items, grid):          # for (w = blockIdx.x; w < n_wg_items; w += gridDim.x)
+            for wave in range(waves):
+                unit = xcd_contiguous(w, n_items) * waves + wave
+                if unit < n_units:                     # if (unit_i >= n_units) continue;
+                    seen.append((unit, block % 8))
+    return seen
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.integers(1, 5000), st.sampled_from([8, 12]), st.integers(1, 300))
+def test_flat_grid_unit_order_visits_every_unit_once(n_units, waves, grid):
+    units = sorted(u for u, _ in visited_units(n_units, waves, grid))
+    assert units == list(range(n_units))
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.integers(64, 20000), st.sampled_from([8, 12]), st.sampled_from([8, 64, 256]))
+def test_flat_grid_unit_order_gives_each_xcd_one_contiguous_range(n_units, waves, grid):
+    by_xcd = {}
+    for unit, xcd in visited_units(n_units, waves, grid):
+        by_xcd.setdefault(xcd, []).append(unit)
+    spans = sorted((min(v), max(v), len(v)) for v in by_xcd.values())
+    for lo, hi, count in spans:
+        assert hi - lo + 1 == count                    # contiguous
+    for (_, hi, _), (lo, _, _) in zip(spans, spans[1:]):
+        assert lo == hi + 1                            # and the ranges tile the units
