@@ -168,6 +168,35 @@ def test_device_blocks_equal_numpy_recombination(tmp_path, dtype):
     ing.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,fmt", [(np.int8, "GYP_FMT_I8"), (np.uint8, "GYP_FMT_U8"), (np.int16, "GYP_FMT_I16")])
+def test_widen_kernel_output_does_not_depend_on_its_grid(dtype, fmt):
+    """gyp_widen_iq_dev walks its input grid-stride: 1, 2 (the default since r06) or 8 workgroups per CU (`gyp_debug_set "widen_wg_per_cu"`)
+    and a word count with a ragged tail all give float(raw) * scale, word for word."""
+    from gypsum_amd.engine import default_engine
+
+    eng = default_engine(FS, N)
+    rng = np.random.default_rng(5)
+    info = np.iinfo(dtype)
+    n_words = 3 * 1_000_003 + 7                      # not a multiple of the 16-byte vectors
+    raw = rng.integers(info.min, info.max, size=n_words, endpoint=True).astype(dtype)
+    scale = 0.03 / 100.0
+    want = raw.astype(np.float32) * np.float32(scale)
+    d_raw = eng.alloc(raw.nbytes).upload(raw)
+    d_out = eng.alloc(n_words * 4)
+    before = eng.debug_get("widen_wg_per_cu")
+    try:
+        for per_cu in (1, 2, 8):
+            eng.debug_set("widen_wg_per_cu", per_cu)
+            d_out.upload(np.full(n_words, np.float32(-7.0)))          # (so that every run has to write every word)
+            eng.widen_iq_dev(getattr(_lib, fmt), d_raw.ptr.value, n_words, d_out.ptr.value, scale)
+            got = d_out.download(np.float32, n_words)
+            assert np.array_equal(got, want), f"widen_wg_per_cu {per_cu}"
+    finally:
+        eng.debug_set("widen_wg_per_cu", before)
+    assert before == 2
+
+
 def test_provider_accepts_the_reference_descriptor(tmp_path):
     """AntennaSampleProviderBackedByFile(InputFileInfo) as upstream constructs it (antenna_sample_provider.py:80-86)."""
     from gypsum_amd.radio_input import (InputFileInfo, InputFileType, get_input_source_by_file_name,
