@@ -29,8 +29,9 @@ extern "C" {
 #endif
 
 /* 203: gyp_debug_spec_layout_for added (sub-block length by rate: ~167 ms at 2.046 Msps, r06), gyp_grid_best_bins_refined_dev added (float64
- *      tie-break of the flat grids' best-bin selection); new gyp_debug_set names (no_grid_fused, spec_sub_ms) and the read-only
- *      "last_grid_path" / "last_grid_refined_rows".
+ *      tie-break of the flat grids' best-bin selection); new gyp_debug_set names (no_grid_fused, grid_fused_waves, spec_sub_ms,
+ *      widen_wg_per_cu) and the read-only "last_grid_path" / "last_grid_refined_rows"; defaults changed at the end of r06 (same results):
+ *      track_chunk_ms 500 -> 250, the widen kernel's grid 8 -> 2 workgroups per CU.
  * 202: gyp_memcpy_d2h_async added (per-ms records leave the device on a copy stream while the next block is tracked).
  * 201: gyp_debug_set / gyp_debug_get / gyp_debug_spec_redo_read / gyp_debug_spec_layout added (the library no longer reads GYP_* environment switches).
  * 200: gyp_chan_out carries the float64 early/late pair (80 bytes), gyp_track_rec::path_info, gyp_debug_track_profile writes
