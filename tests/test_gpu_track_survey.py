@@ -478,7 +478,7 @@ def _bank_specs(seed0, n_pull_in, n_lock):
 def test_bench_shaped_banks_against_the_oracle(engine_factory, fs, n_pull_in, n_lock, n_ms, path, seed0):
     """the configuration the headline number is measured on -- a multi-stream bank that takes
     `track_block_throughput` by its size (no `no_spec`), stream base addressing, hundreds of channels on `xcd_contiguous`, two workgroups
-    per CU, 500-ms launch cuts -- and the 25..256-channel regime (`track_block_speculative_rerun`) against the reference arithmetic
+    per CU, launch cuts every 250 ms (500 until the end of r06) -- and the 25..256-channel regime (`track_block_speculative_rerun`) against the reference arithmetic
     (tracker.py:331-389) through the float64 oracle: every integer of gyp_track_rec (pseudosymbol, int(self.phase) code phase, prompt
     arg-max, lock flag, nudge flag) equal, prompt |.| within 1e-4, SURVEY d2 scenes (12 channels per stream) and lock-regime scenes
     (2-4 channels per stream) in the same bank."""
