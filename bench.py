@@ -1381,15 +1381,17 @@ def main() -> None:
         k_vals = [v for v in k_ms.values() if isinstance(v, (int, float))]
         # `roofline` names the BINDING resource (FP32 vector issue, not HBM, not MFMA) and carries the HBM view
         # north_star asks for inside the same dict (the driver's record keeps this dict whole)
+        traffic_stale = ((bool(traffic_rec.get("kernel_ms_during_counter_pass")) and
+                          abs(traffic_rec["kernel_ms_during_counter_pass"] / dom["ms"] - 1.0) > 0.15) if traffic_rec else None)
         roofline = {"bound": "fp32_valu", "kernel": dom["kernel"], "achieved": round(valu_tf, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(valu_tf / VALU_PEAK_TFLOPS, 5),
                     "valu_frac": round(valu_tf / VALU_PEAK_TFLOPS, 5), "valu_achieved_tflops": round(valu_tf, 3),
                     "hbm_frac": round(hbm_gbps / HBM_PEAK_GBS, 5), "hbm_achieved_gbps": round(hbm_gbps, 2), "hbm_peak_gbps": HBM_PEAK_GBS,
                     "algorithmic_flop_per_launch": dom["flops"], "algorithmic_bytes_per_launch": dom["bytes"],
                     "traffic": traffic,
-                    "traffic_over_algorithmic": round(traffic / dom["bytes"], 3) if traffic else None,
-                    "traffic_stale": (bool(traffic_rec.get("kernel_ms_during_counter_pass")) and
-                                      abs(traffic_rec["kernel_ms_during_counter_pass"] / dom["ms"] - 1.0) > 0.15) if traffic_rec else None,
+                    # (no ratio if the counters were collected on launches of another length: r06zg's line divided 500-ms counters by 250-ms bytes)
+                    "traffic_over_algorithmic": round(traffic / dom["bytes"], 3) if traffic and not traffic_stale else None,
+                    "traffic_stale": traffic_stale,
                     "kernel_ms_per_launch": round(dom["ms"], 4),
                     **({"launches_per_step": dom["launches_per_step"], "unit_per_launch": dom["unit_per_launch"]}
                        if "launches_per_step" in dom else {}),
